@@ -1,0 +1,208 @@
+/* mpibwa_amd.h — C ABI of the MI355X-native BWA-MEM hot path.
+ *
+ * This header is the drop-in boundary for mpiBWA's alignment call
+ *     mem_process_seqs(opt, bwt, bns, pac, n_processed, n, seqs, pes0)
+ * (reference: src/bwamem.h:134, called from src/mainParallel.c:1314, :2355,
+ * :3093 and src/mainParallelByChromosome.c:1249, :2502, :3407).
+ *
+ * Everything here is plain C: pointers, sizes, PODs.  No torch / HIP types
+ * cross the boundary.  The struct layouts below are re-declared from the
+ * reference's documented x86-64 layouts so that a host program compiled
+ * against the reference headers can pass its own objects unchanged:
+ *     mem_opt_t     src/bwamem.h:25-57   (168 bytes)
+ *     mem_pestat_t  src/bwamem.h:81-85   (32 bytes)
+ *     bseq1_t       src/bwa.h:30-33      (48 bytes)
+ *     bwt_t         src/bwt.h:46-58      (1120 bytes incl. cnt_table)
+ *     bntann1_t     src/bntseq.h:41-48   (40 bytes)
+ *     bntamb1_t     src/bntseq.h:50-54   (16 bytes)
+ *     bntseq_t      src/bntseq.h:56-64   (56 bytes)
+ * Sizes are checked with static asserts in mpibwa_amd/csrc/abi_check.cpp.
+ */
+#ifndef MPIBWA_AMD_H
+#define MPIBWA_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- flag bits of mem_opt_t::flag (src/bwamem.h:14-23) ---- */
+#define MEM_F_PE             0x2
+#define MEM_F_NOPAIRING      0x4
+#define MEM_F_ALL            0x8
+#define MEM_F_NO_MULTI       0x10
+#define MEM_F_NO_RESCUE      0x20
+#define MEM_F_REF_HDR        0x100
+#define MEM_F_SOFTCLIP       0x200
+#define MEM_F_SMARTPE        0x400
+#define MEM_F_PRIMARY5       0x800
+#define MEM_F_KEEP_SUPP_MAPQ 0x1000
+
+typedef uint64_t bwtint_t;
+
+typedef struct {
+	int a, b;
+	int o_del, e_del;
+	int o_ins, e_ins;
+	int pen_unpaired;
+	int pen_clip5, pen_clip3;
+	int w;
+	int zdrop;
+	uint64_t max_mem_intv;
+	int T;
+	int flag;
+	int min_seed_len;
+	int min_chain_weight;
+	int max_chain_extend;
+	float split_factor;
+	int split_width;
+	int max_occ;
+	int max_chain_gap;
+	int n_threads;
+	int chunk_size;
+	float mask_level;
+	float drop_ratio;
+	float XA_drop_ratio;
+	float mask_level_redun;
+	float mapQ_coef_len;
+	int mapQ_coef_fac;
+	int max_ins;
+	int max_matesw;
+	int max_XA_hits, max_XA_hits_alt;
+	int8_t mat[25];
+} mem_opt_t;
+
+typedef struct {
+	int low, high;
+	int failed;
+	double avg, std;
+} mem_pestat_t;
+
+typedef struct {
+	int l_seq, id;
+	char *name, *comment, *seq, *qual, *sam;
+} bseq1_t;
+
+typedef struct {
+	bwtint_t primary;
+	bwtint_t L2[5];
+	bwtint_t seq_len;
+	bwtint_t bwt_size;      /* in 32-bit words */
+	uint32_t *bwt;          /* occ-interleaved BWT, 64 B per 128 bases */
+	uint32_t cnt_table[256];
+	int sa_intv;
+	bwtint_t n_sa;
+	bwtint_t *sa;
+} bwt_t;
+
+typedef struct {
+	int64_t offset;
+	int32_t len;
+	int32_t n_ambs;
+	uint32_t gi;
+	int32_t is_alt;
+	char *name, *anno;
+} bntann1_t;
+
+typedef struct {
+	int64_t offset;
+	int32_t len;
+	char amb;
+} bntamb1_t;
+
+typedef struct {
+	int64_t l_pac;
+	int32_t n_seqs;
+	uint32_t seed;
+	bntann1_t *anns;
+	int32_t n_holes;
+	bntamb1_t *ambs;
+	FILE *fp_pac;
+} bntseq_t;
+
+/* in-memory index handle, same fields as the reference's bwaidx_t
+ * (src/bwa.h:20-28) so `.map` images can be attached in place. */
+typedef struct {
+	bwt_t    *bwt;
+	bntseq_t *bns;
+	uint8_t  *pac;
+	int       is_shm;
+	int64_t   l_mem;
+	uint8_t  *mem;
+} bwaidx_t;
+
+/* ------------------------------------------------------------------ */
+/* The drop-in entry point (replaces src/bwamem.c:1205-1234).          */
+/*                                                                     */
+/* Same argument meaning, same in/out contract on seqs[] (seq[] is     */
+/* overwritten with nt4 codes, seqs[i].sam is malloc()ed and owned by  */
+/* the caller), same stderr messages, failures abort.  The index       */
+/* (bwt,bns,pac) must have been uploaded with mi355x_index_upload()    */
+/* first; calling without a usable MI355X device aborts loudly — there */
+/* is no CPU fallback.                                                 */
+/* ------------------------------------------------------------------ */
+void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const bntseq_t *bns, const uint8_t *pac,
+                      int64_t n_processed, int n, bseq1_t *seqs, const mem_pestat_t *pes0);
+
+/* option / scoring helpers used by the caller's CLI parsing
+ * (src/bwamem.c:48-84, src/bwa.c:109-119, src/bwa.c:16-17). */
+mem_opt_t *mem_opt_init(void);
+void bwa_fill_scmat(int a, int b, int8_t mat[25]);
+extern int  bwa_verbose;
+extern char bwa_rg_id[256];
+
+/* index attach / load (src/bwa.c:262-345: bwa_idx_load_from_disk, bwa_mem2idx) */
+bwaidx_t *bwa_idx_load_from_disk(const char *prefix, int which);
+int       bwa_mem2idx(int64_t l_mem, uint8_t *mem, bwaidx_t *idx);
+void      bwa_idx_destroy(bwaidx_t *idx);
+
+/* ---- MI355X-specific additions (no reference equivalent) ---- */
+
+/* Select device `local_rank`, re-home the FM-index (64-B aligned occ blocks),
+ * the sampled SA and the 2-bit pac into HBM.  Returns 0 on success; aborts if
+ * no gfx950 device is usable. */
+int  mi355x_index_upload(int local_rank, const bwt_t *bwt, const bntseq_t *bns, const uint8_t *pac);
+/* Device pointers + sizes of the three index arrays, for the RCCL broadcast
+ * done by the host program (rank 0 uploads, others call mi355x_index_alloc
+ * then receive into these buffers). */
+int  mi355x_index_alloc(int local_rank, const bwt_t *bwt_meta, const bntseq_t *bns);
+int  mi355x_index_buffers(void **d_bwt, size_t *bwt_bytes, void **d_sa, size_t *sa_bytes, void **d_pac, size_t *pac_bytes);
+void mi355x_finalize(void);
+
+/* own bwa-compatible index builder (formats of src/bwt.c:385-462,
+ * src/bntseq.c:66-96,275-328). Writes prefix.{pac,ann,amb,bwt,sa}. */
+int  mi355x_index_build(const char *fasta, const char *prefix);
+
+/* ---- stage-level entry points (used by tests/bench for kernel parity and
+ *      roofline measurement; each runs ONLY the named HIP kernel) ---- */
+
+/* SMEM seeding (mem_collect_intv, src/bwamem.c:114-162) for n reads.
+ * seqs: concatenated nt4 bytes, off[n+1] offsets.  Output: per read up to
+ * `cap` intervals (x0,x1,x2,info) = 4 x uint64 each, count in n_out[i],
+ * sorted by info.  Returns 0, or -1 if some read overflowed `cap`. */
+int mi355x_smem_batch(const mem_opt_t *opt, int n, const uint8_t *seqs, const int64_t *off,
+                      int cap, uint64_t *intv_out, int *n_out, double *kernel_ms, uint64_t *algo_bytes);
+/* Suffix-array lookup (bwt_sa, src/bwt.c:86-96) for n BWT rows. */
+int mi355x_sa_batch(int n, const uint64_t *k, uint64_t *sa_out, double *kernel_ms, uint64_t *algo_bytes);
+/* Banded extension (ksw_extend2, src/ksw.c:380-479) for n independent jobs.
+ * q/t: concatenated nt4 bytes; per job 5 ints in out: score,qle,tle,gtle,gscore,max_off (6). */
+int mi355x_extend_batch(const mem_opt_t *opt, int n, const uint8_t *q, const int64_t *qoff,
+                        const uint8_t *t, const int64_t *toff, const int *w, const int *h0,
+                        const int *end_bonus, int *out6, double *kernel_ms, uint64_t *cells);
+
+/* timing of the last mem_process_seqs() call, per stage (ms) */
+typedef struct {
+	double total_ms, h2d_ms, smem_ms, sa_ms, chain_ms, ext_ms, regs_ms, pestat_ms, sam_ms;
+	double k_smem_ms, k_sa_ms, k_ext_ms;        /* HIP-event kernel times */
+	uint64_t smem_bytes, sa_bytes, ext_cells;    /* algorithmic work counted on device */
+	uint64_t n_reads, n_intv, n_seeds, n_chains, n_ext;
+} mi355x_stats_t;
+void mi355x_last_stats(mi355x_stats_t *st);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
