@@ -15,7 +15,7 @@
  *     bwt_t         src/bwt.h:46-58      (1120 bytes incl. cnt_table)
  *     bntann1_t     src/bntseq.h:41-48   (40 bytes)
  *     bntamb1_t     src/bntseq.h:50-54   (16 bytes)
- *     bntseq_t      src/bntseq.h:56-64   (56 bytes)
+ *     bntseq_t      src/bntseq.h:56-64   (48 bytes)
  * Sizes are checked with static asserts in mpibwa_amd/csrc/abi_check.cpp.
  */
 #ifndef MPIBWA_AMD_H

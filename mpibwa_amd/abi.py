@@ -1,0 +1,148 @@
+"""ctypes mirror of include/mpibwa_amd.h (the reference's x86-64 struct layouts:
+src/bwamem.h:25-85, src/bwa.h:20-33, src/bwt.h:46-62, src/bntseq.h:41-64)."""
+import ctypes as C
+
+MEM_F_PE = 0x2
+MEM_F_NOPAIRING = 0x4
+MEM_F_ALL = 0x8
+MEM_F_NO_MULTI = 0x10
+MEM_F_NO_RESCUE = 0x20
+MEM_F_REF_HDR = 0x100
+MEM_F_SOFTCLIP = 0x200
+MEM_F_SMARTPE = 0x400
+MEM_F_PRIMARY5 = 0x800
+MEM_F_KEEP_SUPP_MAPQ = 0x1000
+
+
+class mem_opt_t(C.Structure):
+    _fields_ = [
+        ("a", C.c_int), ("b", C.c_int),
+        ("o_del", C.c_int), ("e_del", C.c_int),
+        ("o_ins", C.c_int), ("e_ins", C.c_int),
+        ("pen_unpaired", C.c_int),
+        ("pen_clip5", C.c_int), ("pen_clip3", C.c_int),
+        ("w", C.c_int),
+        ("zdrop", C.c_int),
+        ("max_mem_intv", C.c_uint64),
+        ("T", C.c_int),
+        ("flag", C.c_int),
+        ("min_seed_len", C.c_int),
+        ("min_chain_weight", C.c_int),
+        ("max_chain_extend", C.c_int),
+        ("split_factor", C.c_float),
+        ("split_width", C.c_int),
+        ("max_occ", C.c_int),
+        ("max_chain_gap", C.c_int),
+        ("n_threads", C.c_int),
+        ("chunk_size", C.c_int),
+        ("mask_level", C.c_float),
+        ("drop_ratio", C.c_float),
+        ("XA_drop_ratio", C.c_float),
+        ("mask_level_redun", C.c_float),
+        ("mapQ_coef_len", C.c_float),
+        ("mapQ_coef_fac", C.c_int),
+        ("max_ins", C.c_int),
+        ("max_matesw", C.c_int),
+        ("max_XA_hits", C.c_int), ("max_XA_hits_alt", C.c_int),
+        ("mat", C.c_int8 * 25),
+    ]
+
+
+class mem_pestat_t(C.Structure):
+    _fields_ = [("low", C.c_int), ("high", C.c_int), ("failed", C.c_int), ("avg", C.c_double), ("std", C.c_double)]
+
+
+class bseq1_t(C.Structure):
+    _fields_ = [("l_seq", C.c_int), ("id", C.c_int), ("name", C.c_void_p), ("comment", C.c_void_p),
+                ("seq", C.c_void_p), ("qual", C.c_void_p), ("sam", C.c_void_p)]
+
+
+class bwt_t(C.Structure):
+    _fields_ = [("primary", C.c_uint64), ("L2", C.c_uint64 * 5), ("seq_len", C.c_uint64), ("bwt_size", C.c_uint64),
+                ("bwt", C.POINTER(C.c_uint32)), ("cnt_table", C.c_uint32 * 256), ("sa_intv", C.c_int),
+                ("n_sa", C.c_uint64), ("sa", C.POINTER(C.c_uint64))]
+
+
+class bntann1_t(C.Structure):
+    _fields_ = [("offset", C.c_int64), ("len", C.c_int32), ("n_ambs", C.c_int32), ("gi", C.c_uint32),
+                ("is_alt", C.c_int32), ("name", C.c_char_p), ("anno", C.c_char_p)]
+
+
+class bntamb1_t(C.Structure):
+    _fields_ = [("offset", C.c_int64), ("len", C.c_int32), ("amb", C.c_char)]
+
+
+class bntseq_t(C.Structure):
+    _fields_ = [("l_pac", C.c_int64), ("n_seqs", C.c_int32), ("seed", C.c_uint32), ("anns", C.POINTER(bntann1_t)),
+                ("n_holes", C.c_int32), ("ambs", C.POINTER(bntamb1_t)), ("fp_pac", C.c_void_p)]
+
+
+class bwaidx_t(C.Structure):
+    _fields_ = [("bwt", C.POINTER(bwt_t)), ("bns", C.POINTER(bntseq_t)), ("pac", C.POINTER(C.c_uint8)),
+                ("is_shm", C.c_int), ("l_mem", C.c_int64), ("mem", C.POINTER(C.c_uint8))]
+
+
+class mi355x_stats_t(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("total_ms", "h2d_ms", "smem_ms", "sa_ms", "chain_ms", "ext_ms", "regs_ms",
+                                          "pestat_ms", "sam_ms", "k_smem_ms", "k_sa_ms", "k_ext_ms")] + \
+               [(n, C.c_uint64) for n in ("smem_bytes", "sa_bytes", "ext_cells", "n_reads", "n_intv", "n_seeds",
+                                          "n_chains", "n_ext")]
+
+
+assert C.sizeof(mem_opt_t) == 168
+assert C.sizeof(mem_pestat_t) == 32
+assert C.sizeof(bseq1_t) == 48
+assert C.sizeof(bwt_t) == 1120
+assert C.sizeof(bntann1_t) == 40
+assert C.sizeof(bntamb1_t) == 16
+assert C.sizeof(bntseq_t) == 48
+
+
+class SeqBatch:
+    """Owns the C buffers behind a bseq1_t[n] array, built the way mpiBWA's main does
+    (src/mainParallel.c:1257-1301): NUL-terminated name/seq/qual strings, mates interleaved."""
+
+    def __init__(self, libc, reads, with_qual=True, comment=None):
+        # reads: list of (name:str, seq1:bytes, seq2:bytes|None)
+        self.libc = libc
+        flat = []
+        for name, s1, s2 in reads:
+            flat.append((name, s1))
+            if s2 is not None:
+                flat.append((name, s2))
+        self.n = len(flat)
+        self.arr = (bseq1_t * self.n)()
+        self._keep = []
+        for i, (name, s) in enumerate(flat):
+            nb = C.create_string_buffer(name.encode())
+            sb = C.create_string_buffer(bytes(s))
+            self._keep += [nb, sb]
+            self.arr[i].l_seq = len(s)
+            self.arr[i].id = 0
+            self.arr[i].name = C.addressof(nb)
+            self.arr[i].seq = C.addressof(sb)
+            self.arr[i].comment = None
+            if comment is not None:
+                cb = C.create_string_buffer(comment.encode())
+                self._keep.append(cb)
+                self.arr[i].comment = C.addressof(cb)
+            if with_qual:
+                qb = C.create_string_buffer(b"I" * len(s))
+                self._keep.append(qb)
+                self.arr[i].qual = C.addressof(qb)
+            else:
+                self.arr[i].qual = None
+            self.arr[i].sam = None
+
+    def take_sam(self):
+        """Collect seqs[i].sam strings and free() them as the caller in mainParallel.c:1390 does."""
+        out = []
+        for i in range(self.n):
+            p = self.arr[i].sam
+            if p:
+                out.append(C.string_at(p))
+                self.libc.free(C.c_void_p(p))
+                self.arr[i].sam = None
+            else:
+                out.append(b"")
+        return out

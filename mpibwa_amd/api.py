@@ -1,0 +1,139 @@
+"""ctypes binding of libmpibwa_amd.so — the host-side mirror of the reference's
+operator interface (mem_opt_init / bwa_idx_load / mem_process_seqs)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+libc = C.CDLL("libc.so.6")
+libc.free.argtypes = [C.c_void_p]
+
+EXPORTS = [
+    "mem_process_seqs", "mem_opt_init", "bwa_fill_scmat", "bwa_idx_load_from_disk", "bwa_mem2idx", "bwa_idx_destroy",
+    "mi355x_index_upload", "mi355x_index_alloc", "mi355x_index_buffers", "mi355x_finalize", "mi355x_index_build",
+    "mi355x_smem_batch", "mi355x_sa_batch", "mi355x_extend_batch", "mi355x_last_stats",
+]
+
+
+def load_library(build_if_missing=True):
+    """Load the product library.  Fails loudly if it is absent and cannot be built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = os.path.join(HERE, "libmpibwa_amd.so")
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise RuntimeError("libmpibwa_amd.so is missing: run python -m mpibwa_amd.build")
+        from .build import build
+        build()
+    lib = C.CDLL(path)
+    P = C.POINTER
+
+    def sig(name, restype, argtypes):
+        fn = getattr(lib, name)  # AttributeError here = the library does not export what include/mpibwa_amd.h declares
+        fn.restype = restype
+        fn.argtypes = argtypes
+
+    sig("mem_opt_init", P(abi.mem_opt_t), [])
+    sig("bwa_idx_load_from_disk", P(abi.bwaidx_t), [C.c_char_p, C.c_int])
+    sig("mi355x_index_build", C.c_int, [C.c_char_p, C.c_char_p])
+    sig("mem_process_seqs", None, [P(abi.mem_opt_t), P(abi.bwt_t), P(abi.bntseq_t), P(C.c_uint8), C.c_int64, C.c_int,
+                                   P(abi.bseq1_t), P(abi.mem_pestat_t)])
+    sig("mi355x_index_upload", C.c_int, [C.c_int, P(abi.bwt_t), P(abi.bntseq_t), P(C.c_uint8)])
+    sig("mi355x_smem_batch", C.c_int, [P(abi.mem_opt_t), C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                       C.c_void_p, P(C.c_double), P(C.c_uint64)])
+    sig("mi355x_sa_batch", C.c_int, [C.c_int, C.c_void_p, C.c_void_p, P(C.c_double), P(C.c_uint64)])
+    sig("mi355x_extend_batch", C.c_int, [P(abi.mem_opt_t), C.c_int] + [C.c_void_p] * 8 + [P(C.c_double), P(C.c_uint64)])
+    sig("mi355x_last_stats", None, [P(abi.mi355x_stats_t)])
+    sig("mi355x_finalize", None, [])
+    _LIB = lib
+    return lib
+
+
+def build_index(fasta, prefix):
+    lib = load_library()
+    if lib.mi355x_index_build(fasta.encode(), prefix.encode()) != 0:
+        raise RuntimeError("index build failed")
+
+
+class Engine:
+    """One rank = one GPU: loads a bwa index, uploads it to HBM and aligns batches."""
+
+    def __init__(self, prefix, device=0, upload=True):
+        self.lib = load_library()
+        self.idx = self.lib.bwa_idx_load_from_disk(prefix.encode(), 7)
+        self.bwt = self.idx.contents.bwt
+        self.bns = self.idx.contents.bns
+        self.pac = self.idx.contents.pac
+        self.uploaded = False
+        if upload:
+            if self.lib.mi355x_index_upload(device, self.bwt, self.bns, self.pac) != 0:
+                raise RuntimeError("mi355x_index_upload failed")
+            self.uploaded = True
+
+    def opt(self, **kw):
+        o = self.lib.mem_opt_init()
+        for k, v in kw.items():
+            setattr(o.contents, k, v)
+        return o
+
+    def process(self, opt, reads, n_processed=0, pes0=None, with_qual=True, comment=None):
+        batch = abi.SeqBatch(libc, reads, with_qual=with_qual, comment=comment)
+        self.lib.mem_process_seqs(opt, self.bwt, self.bns, self.pac, n_processed, batch.n, batch.arr, pes0)
+        return batch.take_sam()
+
+    def process_batch(self, opt, batch, n_processed=0, pes0=None):
+        self.lib.mem_process_seqs(opt, self.bwt, self.bns, self.pac, n_processed, batch.n, batch.arr, pes0)
+
+    def stats(self):
+        st = abi.mi355x_stats_t()
+        self.lib.mi355x_last_stats(C.byref(st))
+        return {k: getattr(st, k) for k, _ in st._fields_}
+
+    # ---- stage-level kernels ----
+    def smem(self, opt, seqs, cap=256):
+        """seqs: list of uint8 code arrays → list of (n_i,4) uint64 arrays sorted by info."""
+        off = np.zeros(len(seqs) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(s) for s in seqs])
+        flat = np.concatenate(seqs).astype(np.uint8) if len(seqs) else np.zeros(0, np.uint8)
+        out = np.zeros((len(seqs), cap, 4), dtype=np.uint64)
+        cnt = np.zeros(len(seqs), dtype=np.int32)
+        ms = C.c_double(0)
+        nbytes = C.c_uint64(0)
+        rc = self.lib.mi355x_smem_batch(opt, len(seqs), flat.ctypes.data, off.ctypes.data, cap, out.ctypes.data,
+                                        cnt.ctypes.data, C.byref(ms), C.byref(nbytes))
+        if rc != 0:
+            raise RuntimeError("mi355x_smem_batch overflowed cap=%d" % cap)
+        return [out[i, :cnt[i]].copy() for i in range(len(seqs))], ms.value, nbytes.value
+
+    def sa(self, ks):
+        ks = np.ascontiguousarray(ks, dtype=np.uint64)
+        out = np.zeros(len(ks), dtype=np.uint64)
+        ms = C.c_double(0)
+        nbytes = C.c_uint64(0)
+        self.lib.mi355x_sa_batch(len(ks), ks.ctypes.data, out.ctypes.data, C.byref(ms), C.byref(nbytes))
+        return out, ms.value, nbytes.value
+
+    def extend(self, opt, qs, ts, w, h0, end_bonus):
+        n = len(qs)
+        qoff = np.zeros(n + 1, dtype=np.int64)
+        qoff[1:] = np.cumsum([len(s) for s in qs])
+        toff = np.zeros(n + 1, dtype=np.int64)
+        toff[1:] = np.cumsum([len(s) for s in ts])
+        qf = np.concatenate(qs).astype(np.uint8)
+        tf = np.concatenate(ts).astype(np.uint8)
+        w = np.ascontiguousarray(w, dtype=np.int32)
+        h0 = np.ascontiguousarray(h0, dtype=np.int32)
+        eb = np.ascontiguousarray(end_bonus, dtype=np.int32)
+        out = np.zeros((n, 6), dtype=np.int32)
+        ms = C.c_double(0)
+        cells = C.c_uint64(0)
+        self.lib.mi355x_extend_batch(opt, n, qf.ctypes.data, qoff.ctypes.data, tf.ctypes.data, toff.ctypes.data,
+                                     w.ctypes.data, h0.ctypes.data, eb.ctypes.data, out.ctypes.data, C.byref(ms),
+                                     C.byref(cells))
+        return out, ms.value, cells.value

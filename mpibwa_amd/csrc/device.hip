@@ -1,0 +1,274 @@
+// device.hip — device management, index residency in HBM and the stage-level C entry points.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "device.h"
+
+namespace mbw {
+
+#define HIP_OK(call)                                                                                             \
+	do {                                                                                                         \
+		hipError_t e_ = (call);                                                                                  \
+		if (e_ != hipSuccess) die("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);    \
+	} while (0)
+
+static DevIndex g_idx;
+DevIndex &dev_index() { return g_idx; }
+
+void *DevBuf::ensure(size_t bytes)
+{
+	if (bytes > cap) {
+		if (p) HIP_OK(hipFree(p));
+		size_t want = bytes + bytes / 4 + 256;
+		HIP_OK(hipMalloc(&p, want));
+		cap = want;
+	}
+	return p;
+}
+void DevBuf::release()
+{
+	if (p) (void)hipFree(p);
+	p = nullptr; cap = 0;
+}
+
+static void require_device(int local_rank)
+{
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n == 0)
+		die("no HIP device visible: the alignment hot path runs on MI355X only, there is no CPU fallback");
+	HIP_OK(hipSetDevice(local_rank % n));
+	hipDeviceProp_t prop;
+	HIP_OK(hipGetDeviceProperties(&prop, local_rank % n));
+	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+		die("device %d is %s; this library carries gfx950 (MI355X) code objects only", local_rank % n, prop.gcnArchName);
+	g_idx.device = local_rank % n;
+}
+
+static void alloc_index(const bwt_t *bwt, const bntseq_t *bns)
+{
+	if (g_idx.d_blk) { (void)hipFree(g_idx.d_blk); (void)hipFree(g_idx.d_sa); (void)hipFree(g_idx.d_pac); }
+	g_idx.blk_bytes = ((size_t)bwt->bwt_size * 4 + 63) / 64 * 64 + 64;   // whole 64-B blocks + one pad block
+	g_idx.sa_bytes = (size_t)bwt->n_sa * 8;
+	g_idx.pac_bytes = (size_t)bns->l_pac / 4 + 1 + 16;
+	HIP_OK(hipMalloc(&g_idx.d_blk, g_idx.blk_bytes));
+	HIP_OK(hipMalloc(&g_idx.d_sa, g_idx.sa_bytes));
+	HIP_OK(hipMalloc(&g_idx.d_pac, g_idx.pac_bytes));
+	HIP_OK(hipMemset(g_idx.d_blk, 0, g_idx.blk_bytes));
+	HIP_OK(hipMemset(g_idx.d_pac, 0, g_idx.pac_bytes));
+	FmDev &fm = g_idx.fm;
+	fm.blk = g_idx.d_blk; fm.sa = (const uint64_t *)g_idx.d_sa;
+	fm.primary = bwt->primary; fm.seq_len = bwt->seq_len;
+	for (int i = 0; i < 5; ++i) fm.L2[i] = bwt->L2[i];
+	int sh = 0;
+	while ((1 << sh) < bwt->sa_intv) ++sh;
+	if ((1 << sh) != bwt->sa_intv) die("SA sampling interval %d is not a power of two", bwt->sa_intv);
+	fm.sa_shift = sh;
+	g_idx.l_pac = bns->l_pac;
+}
+
+} // namespace mbw
+
+using namespace mbw;
+
+extern "C" int mi355x_index_alloc(int local_rank, const bwt_t *bwt, const bntseq_t *bns)
+{
+	require_device(local_rank);
+	alloc_index(bwt, bns);
+	g_idx.ready = true;
+	return 0;
+}
+
+extern "C" int mi355x_index_upload(int local_rank, const bwt_t *bwt, const bntseq_t *bns, const uint8_t *pac)
+{
+	require_device(local_rank);
+	alloc_index(bwt, bns);
+	HIP_OK(hipMemcpy(g_idx.d_blk, bwt->bwt, (size_t)bwt->bwt_size * 4, hipMemcpyHostToDevice));
+	HIP_OK(hipMemcpy(g_idx.d_sa, bwt->sa, g_idx.sa_bytes, hipMemcpyHostToDevice));
+	HIP_OK(hipMemcpy(g_idx.d_pac, pac, (size_t)bns->l_pac / 4 + 1, hipMemcpyHostToDevice));
+	g_idx.ready = true;
+	return 0;
+}
+
+extern "C" int mi355x_index_buffers(void **d_bwt, size_t *bwt_bytes, void **d_sa, size_t *sa_bytes, void **d_pac,
+                                    size_t *pac_bytes)
+{
+	if (!g_idx.ready) return -1;
+	*d_bwt = g_idx.d_blk; *bwt_bytes = g_idx.blk_bytes;
+	*d_sa = g_idx.d_sa; *sa_bytes = g_idx.sa_bytes;
+	*d_pac = g_idx.d_pac; *pac_bytes = g_idx.pac_bytes;
+	return 0;
+}
+
+extern "C" void mi355x_finalize(void)
+{
+	if (g_idx.d_blk) { (void)hipFree(g_idx.d_blk); (void)hipFree(g_idx.d_sa); (void)hipFree(g_idx.d_pac); }
+	g_idx = DevIndex();
+}
+
+namespace mbw {
+
+static void need_index()
+{
+	if (!g_idx.ready) die("index not resident on the device: call mi355x_index_upload() first");
+}
+
+struct Timer {
+	hipEvent_t a, b;
+	Timer() { HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); }
+	~Timer() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
+	void start(hipStream_t s) { HIP_OK(hipEventRecord(a, s)); }
+	double stop(hipStream_t s)
+	{
+		HIP_OK(hipEventRecord(b, s));
+		HIP_OK(hipEventSynchronize(b));
+		float ms = 0;
+		HIP_OK(hipEventElapsedTime(&ms, a, b));
+		return ms;
+	}
+};
+
+SmemParams smem_params(const mem_opt_t *opt)
+{
+	SmemParams sp;
+	sp.min_seed_len = opt->min_seed_len;
+	sp.split_len = (int)(opt->min_seed_len * opt->split_factor + .499);   // src/bwamem.c:118
+	sp.split_width = opt->split_width;
+	sp.max_mem_intv = (int)opt->max_mem_intv;
+	return sp;
+}
+
+// band clamp of src/ksw.c:395-407 (host side, double arithmetic as in the reference)
+int clamp_band(const mem_opt_t *opt, int qlen, int w, int end_bonus)
+{
+	int mx = 0;
+	for (int i = 0; i < 25; ++i) mx = std::max(mx, (int)opt->mat[i]);
+	int max_ins = (int)((double)(qlen * mx + end_bonus - opt->o_ins) / opt->e_ins + 1.);
+	int max_del = (int)((double)(qlen * mx + end_bonus - opt->o_del) / opt->e_del + 1.);
+	w = std::min(w, std::max(max_ins, 1));
+	w = std::min(w, std::max(max_del, 1));
+	return w;
+}
+
+} // namespace mbw
+
+extern "C" int mi355x_smem_batch(const mem_opt_t *opt, int n, const uint8_t *seqs, const int64_t *off, int cap,
+                                 uint64_t *intv_out, int *n_out, double *kernel_ms, uint64_t *algo_bytes)
+{
+	need_index();
+	if (n <= 0) return 0;
+	hipStream_t st = 0;
+	int max_len = 0;
+	for (int i = 0; i < n; ++i) max_len = std::max(max_len, (int)(off[i + 1] - off[i]));
+	size_t total = off[n];
+	uint8_t *d_seq; int64_t *d_off; uint64_t *d_out; int *d_nout; unsigned long long *d_cnt; void *d_scr;
+	HIP_OK(hipMalloc(&d_seq, total + 16));
+	HIP_OK(hipMalloc(&d_off, (size_t)(n + 1) * 8));
+	HIP_OK(hipMalloc(&d_out, (size_t)n * cap * 32));
+	HIP_OK(hipMalloc(&d_nout, (size_t)n * 4));
+	HIP_OK(hipMalloc(&d_cnt, 64));
+	size_t per_quad = 0;
+	int n_quads = smem_grid_quads(max_len, &per_quad);
+	HIP_OK(hipMalloc(&d_scr, per_quad * n_quads));
+	HIP_OK(hipMemcpy(d_seq, seqs, total, hipMemcpyHostToDevice));
+	HIP_OK(hipMemcpy(d_off, off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
+	HIP_OK(hipMemset(d_cnt, 0, 64));
+	HIP_OK(hipMemset(d_nout, 0, (size_t)n * 4));
+	Timer tm;
+	tm.start(st);
+	launch_smem(st, g_idx.fm, smem_params(opt), n, d_seq, d_off, cap, d_out, d_nout, max_len, d_cnt, d_scr, per_quad,
+	            n_quads);
+	double ms = tm.stop(st);
+	HIP_OK(hipGetLastError());
+	unsigned long long cnt[8];
+	HIP_OK(hipMemcpy(cnt, d_cnt, 64, hipMemcpyDeviceToHost));
+	HIP_OK(hipMemcpy(n_out, d_nout, (size_t)n * 4, hipMemcpyDeviceToHost));
+	HIP_OK(hipMemcpy(intv_out, d_out, (size_t)n * cap * 32, hipMemcpyDeviceToHost));
+	(void)hipFree(d_seq); (void)hipFree(d_off); (void)hipFree(d_out); (void)hipFree(d_nout); (void)hipFree(d_cnt);
+	(void)hipFree(d_scr);
+	// order by info (the reference sorts with an unstable introsort keyed on info only, src/bwamem.c:161;
+	// equal keys are identical records, so any order of ties is the same byte sequence)
+	uint64_t n_intv = 0;
+	for (int i = 0; i < n; ++i) {
+		int m = std::min(n_out[i], cap);
+		Intv *a = (Intv *)(intv_out + (size_t)i * cap * 4);
+		std::sort(a, a + m, [](const Intv &x, const Intv &y) { return x.info < y.info; });
+		n_intv += m;
+	}
+	if (kernel_ms) *kernel_ms = ms;
+	if (algo_bytes) *algo_bytes = cnt[1] * 64 + total + n_intv * 32;   // 64 B per occ block + read + output
+	return cnt[2] ? -1 : 0;
+}
+
+extern "C" int mi355x_sa_batch(int n, const uint64_t *k, uint64_t *sa_out, double *kernel_ms, uint64_t *algo_bytes)
+{
+	need_index();
+	if (n <= 0) return 0;
+	hipStream_t st = 0;
+	uint64_t *d_k, *d_o; unsigned long long *d_cnt;
+	HIP_OK(hipMalloc(&d_k, (size_t)n * 8));
+	HIP_OK(hipMalloc(&d_o, (size_t)n * 8));
+	HIP_OK(hipMalloc(&d_cnt, 64));
+	HIP_OK(hipMemcpy(d_k, k, (size_t)n * 8, hipMemcpyHostToDevice));
+	HIP_OK(hipMemset(d_cnt, 0, 64));
+	Timer tm;
+	tm.start(st);
+	launch_sa(st, g_idx.fm, n, d_k, d_o, d_cnt);
+	double ms = tm.stop(st);
+	HIP_OK(hipGetLastError());
+	unsigned long long cnt[8];
+	HIP_OK(hipMemcpy(cnt, d_cnt, 64, hipMemcpyDeviceToHost));
+	HIP_OK(hipMemcpy(sa_out, d_o, (size_t)n * 8, hipMemcpyDeviceToHost));
+	(void)hipFree(d_k); (void)hipFree(d_o); (void)hipFree(d_cnt);
+	if (kernel_ms) *kernel_ms = ms;
+	if (algo_bytes) *algo_bytes = cnt[1] * 64 + (uint64_t)n * 8;   // 64 B per LF step + the sampled SA word
+	return 0;
+}
+
+extern "C" int mi355x_extend_batch(const mem_opt_t *opt, int n, const uint8_t *q, const int64_t *qoff, const uint8_t *t,
+                                   const int64_t *toff, const int *w, const int *h0, const int *end_bonus, int *out6,
+                                   double *kernel_ms, uint64_t *cells)
+{
+	int nd = 0;
+	if (hipGetDeviceCount(&nd) != hipSuccess || nd == 0) die("no HIP device visible (no CPU fallback)");
+	if (n <= 0) return 0;
+	hipStream_t st = 0;
+	std::vector<int> wc(n);
+	int max_qlen = 0;
+	for (int i = 0; i < n; ++i) {
+		int ql = (int)(qoff[i + 1] - qoff[i]);
+		max_qlen = std::max(max_qlen, ql);
+		wc[i] = clamp_band(opt, ql, w[i], end_bonus[i]);
+	}
+	uint8_t *d_q, *d_t; int64_t *d_qo, *d_to; int *d_w, *d_h0, *d_out; unsigned long long *d_cells;
+	HIP_OK(hipMalloc(&d_q, qoff[n] + 16)); HIP_OK(hipMalloc(&d_t, toff[n] + 16));
+	HIP_OK(hipMalloc(&d_qo, (size_t)(n + 1) * 8)); HIP_OK(hipMalloc(&d_to, (size_t)(n + 1) * 8));
+	HIP_OK(hipMalloc(&d_w, (size_t)n * 4)); HIP_OK(hipMalloc(&d_h0, (size_t)n * 4));
+	HIP_OK(hipMalloc(&d_out, (size_t)n * 24)); HIP_OK(hipMalloc(&d_cells, 8));
+	HIP_OK(hipMemcpy(d_q, q, qoff[n], hipMemcpyHostToDevice));
+	HIP_OK(hipMemcpy(d_t, t, toff[n], hipMemcpyHostToDevice));
+	HIP_OK(hipMemcpy(d_qo, qoff, (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
+	HIP_OK(hipMemcpy(d_to, toff, (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
+	HIP_OK(hipMemcpy(d_w, wc.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+	HIP_OK(hipMemcpy(d_h0, h0, (size_t)n * 4, hipMemcpyHostToDevice));
+	HIP_OK(hipMemset(d_cells, 0, 8));
+	ExtParams ep;
+	memcpy(ep.mat, opt->mat, 25);
+	ep.o_del = opt->o_del; ep.e_del = opt->e_del; ep.o_ins = opt->o_ins; ep.e_ins = opt->e_ins; ep.zdrop = opt->zdrop;
+	Timer tm;
+	tm.start(st);
+	launch_extend(st, ep, n, d_q, d_qo, d_t, d_to, d_w, d_h0, nullptr, d_out, d_cells, max_qlen);
+	double ms = tm.stop(st);
+	HIP_OK(hipGetLastError());
+	unsigned long long c = 0;
+	HIP_OK(hipMemcpy(&c, d_cells, 8, hipMemcpyDeviceToHost));
+	HIP_OK(hipMemcpy(out6, d_out, (size_t)n * 24, hipMemcpyDeviceToHost));
+	(void)hipFree(d_q); (void)hipFree(d_t); (void)hipFree(d_qo); (void)hipFree(d_to); (void)hipFree(d_w);
+	(void)hipFree(d_h0); (void)hipFree(d_out); (void)hipFree(d_cells);
+	if (kernel_ms) *kernel_ms = ms;
+	if (cells) *cells = c;
+	return 0;
+}

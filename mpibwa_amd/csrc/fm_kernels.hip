@@ -1,0 +1,385 @@
+// fm_kernels.hip — FM-index kernels for gfx950: SMEM seeding and suffix-array lookup.
+//
+// Replaces, on the device, the reference's
+//   mem_collect_intv          src/bwamem.c:114-162   (3-pass SMEM seeding)
+//   bwt_smem1a                src/bwt.c:289-351
+//   bwt_seed_strategy1        src/bwt.c:358-379
+//   bwt_extend / bwt_2occ4    src/bwt.c:262-275, 189-220
+//   bwt_sa / bwt_invPsi       src/bwt.c:86-96, 53-59
+//
+// Design (MI355X-first, not a translation):
+//  * One read (or one SA task) per QUAD of lanes, 16 per wavefront.  An occ
+//    block is 64 B = 4 lanes x 16 B, so every FM-index access is one fully
+//    coalesced 64-B request; lane c of the quad then counts base c, so the
+//    four child intervals of bwt_extend come out one per lane with no
+//    reduction, and the data exchange inside the quad is DPP quad_perm
+//    (register-to-register, no LDS).
+//  * Popcount on the packed 2-bit words instead of the reference's byte
+//    lookup table: no table traffic at all.
+//  * Every quad runs a small state machine whose loop body contains exactly
+//    one bwt_extend, so quads that are in different phases (forward sweep,
+//    backward sweep, re-seeding, LAST-like pass) or on reads of different
+//    length never serialise each other; a quad that finishes a read pulls the
+//    next one from a global counter (persistent grid, every wave exits when
+//    the counter runs past n_reads).
+//  * The per-read interval list of bwt_smem1a lives in LDS (one list, compacted
+//    in place: the reference's prev/curr ping-pong never grows), spilling to a
+//    per-quad HBM scratch only beyond LCAP entries.
+#include <hip/hip_runtime.h>
+#include "device.h"
+
+namespace mbw {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+#define LCAP 32            // interval-list entries kept in LDS per quad
+#define SMEM_BLOCK 256     // 4 waves = 64 quads per workgroup
+
+template <int CTRL>
+__device__ __forceinline__ u32 dpp(u32 v)
+{
+	return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL>
+__device__ __forceinline__ u64 dpp64(u64 v)
+{
+	return (u64)dpp<CTRL>((u32)(v >> 32)) << 32 | dpp<CTRL>((u32)v);
+}
+// quad_perm selectors
+#define QP(a, b, c, d) ((a) | (b) << 2 | (c) << 4 | (d) << 6)
+
+// Occ(c, k) for the lane's own base c; k is already shifted for the '$' row.
+// `v` is this lane's 16 B of the 64-B block: lanes 0,1 hold the four 64-bit
+// running counts, lanes 2,3 the eight packed words.
+__device__ __forceinline__ u64 quad_occ(uint4 v, u64 k, int c)
+{
+	// running count of base c: u64 #c lives in lane c>>1, half c&1
+	u32 a0 = dpp<QP(0, 0, 1, 1)>(v.x), a1 = dpp<QP(0, 0, 1, 1)>(v.y);
+	u32 a2 = dpp<QP(0, 0, 1, 1)>(v.z), a3 = dpp<QP(0, 0, 1, 1)>(v.w);
+	u64 cnt = (c & 1) ? ((u64)a3 << 32 | a2) : ((u64)a1 << 32 | a0);
+	u32 w[8];
+	w[0] = dpp<QP(2, 2, 2, 2)>(v.x); w[1] = dpp<QP(2, 2, 2, 2)>(v.y);
+	w[2] = dpp<QP(2, 2, 2, 2)>(v.z); w[3] = dpp<QP(2, 2, 2, 2)>(v.w);
+	w[4] = dpp<QP(3, 3, 3, 3)>(v.x); w[5] = dpp<QP(3, 3, 3, 3)>(v.y);
+	w[6] = dpp<QP(3, 3, 3, 3)>(v.z); w[7] = dpp<QP(3, 3, 3, 3)>(v.w);
+	const u32 pat = 0x55555555u * (u32)c;
+	const int kk = (int)(k & 127) + 1;      // number of symbols of this block that are counted (1..128)
+	u32 n = 0;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		int m = kk - 16 * i;                // symbols of word i that are counted
+		m = m < 0 ? 0 : (m > 16 ? 16 : m);
+		u32 mask = (u32)(0xFFFFFFFF00000000ull >> (2 * m));
+		u32 y = ~(w[i] ^ pat);
+		n += __popc(y & (y >> 1) & 0x55555555u & mask);
+	}
+	return cnt + n;
+}
+
+// bwt_extend for one quad: lane c receives child interval c.
+// Returns the number of distinct occ blocks touched (1 or 2).
+__device__ __forceinline__ int quad_extend(const FmDev &fm, u64 x0, u64 x1, u64 x2, bool back, int c,
+                                           u64 &o0, u64 &o1, u64 &o2)
+{
+	const uint4 *blk = (const uint4 *)fm.blk;
+	u64 p = back ? x0 : x1;                  // the side searched in the BWT (always >= 1)
+	u64 k = p - 1, l = k + x2;
+	u64 ka = k - (k >= fm.primary), la = l - (l >= fm.primary);
+	uint4 vk = blk[(ka >> 7) * 4 + c];
+	uint4 vl = blk[(la >> 7) * 4 + c];
+	u64 tk = quad_occ(vk, ka, c), tl = quad_occ(vl, la, c);
+	u64 a = fm.L2[c] + 1 + tk, s = tl - tk;
+	// mirrored side: children are laid out T,G,C,A behind the (possible) sentinel
+	u64 base = (back ? x1 : x0) + ((p <= fm.primary && p + x2 - 1 >= fm.primary) ? 1 : 0);
+	u64 s1 = s + (c < 3 ? dpp64<QP(1, 2, 3, 3)>(s) : 0);
+	u64 s2 = s1 + (c < 2 ? dpp64<QP(2, 3, 2, 3)>(s1) : 0);
+	u64 mir = base + (s2 - s);
+	o0 = back ? a : mir;
+	o1 = back ? mir : a;
+	o2 = s;
+	return (ka >> 7) == (la >> 7) ? 1 : 2;
+}
+
+struct QuadList {
+	u64 *lds;      // LCAP x 4 u64 of this quad
+	u64 *spill;    // per-quad HBM scratch for entries >= LCAP
+};
+
+__device__ __forceinline__ void list_store(const QuadList &L, int e, int c, u64 x0, u64 x1, u64 x2, u64 end)
+{
+	u64 v = c == 0 ? x0 : c == 1 ? x1 : c == 2 ? x2 : end;
+	if (e < LCAP) L.lds[e * 4 + c] = v;
+	else L.spill[(size_t)(e - LCAP) * 4 + c] = v;
+}
+__device__ __forceinline__ void list_load(const QuadList &L, int e, u64 &x0, u64 &x1, u64 &x2, u64 &end)
+{
+	const u64 *p = e < LCAP ? L.lds + e * 4 : L.spill + (size_t)(e - LCAP) * 4;
+	x0 = p[0]; x1 = p[1]; x2 = p[2]; end = p[3];
+}
+
+enum { ST_PICK = 0, ST_FWD = 1, ST_BWD = 2, ST_P3 = 3, ST_DONE = 4 };
+
+__global__ void __launch_bounds__(SMEM_BLOCK)
+smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ seq, const int64_t *__restrict__ off,
+            int cap, u64 *__restrict__ out, int *__restrict__ nout_arr, u64 *counters, u64 *scratch,
+            size_t scratch_u64_per_quad)
+{
+	__shared__ u64 lds_list[(SMEM_BLOCK / 4) * LCAP * 4];
+	const int lane = threadIdx.x & 63, c = lane & 3, qlead = lane & ~3;
+	const int quad_in_blk = threadIdx.x >> 2;
+	const size_t quad_gid = (size_t)blockIdx.x * (SMEM_BLOCK / 4) + quad_in_blk;
+	QuadList L;
+	L.lds = lds_list + quad_in_blk * LCAP * 4;
+	L.spill = scratch + quad_gid * scratch_u64_per_quad;
+
+	int st = ST_PICK, pass = 0;
+	int rd = 0, len = 0, x = 0, i = 0, j = 0, np = 0, nc = 0, top = 0, min_intv = 1, ret = 0, last_start = -1;
+	int nout = 0, k2 = 0, old_n = 0, cb = -1, last_push_end = 0;
+	const uint8_t *q = seq;
+	u64 ik0 = 0, ik1 = 0, ik2 = 0, ik_end = 0, lastc_x2 = 0;
+	u64 p0 = 0, p1 = 0, p2 = 0, p_end = 0;   // backward: the list entry being extended
+	u64 *myout = out;
+	u32 nblk = 0;
+	bool overflow = false;
+
+	// start the forward sweep of bwt_smem1a at position x
+	auto begin_smem = [&](int xs, int mi) {
+		x = xs; min_intv = mi < 1 ? 1 : mi;
+		int b = q[xs];
+		ik0 = fm.L2[b] + 1; ik2 = fm.L2[b + 1] - fm.L2[b]; ik1 = fm.L2[3 - b] + 1; ik_end = xs + 1;
+		i = xs + 1; top = 0; st = ST_FWD;
+	};
+	auto push_fwd = [&]() {
+		list_store(L, top, c, ik0, ik1, ik2, ik_end);
+		last_push_end = (int)ik_end;
+		++top;
+	};
+	auto set_cb = [&]() { cb = (i < 0 || q[i] > 3) ? -1 : (int)q[i]; };
+	auto fwd_done = [&]() {   // the list holds `top` entries, longest match last pushed
+		ret = last_push_end; np = top; i = x - 1; j = 0; nc = 0; last_start = -1; st = ST_BWD;
+		set_cb();
+	};
+	auto call_done = [&]() {
+		if (pass == 1) x = ret;
+		st = ST_PICK;
+	};
+	auto emit = [&](u64 e0, u64 e1, u64 e2, int start, int end) {
+		if (end - start < sp.min_seed_len) return;
+		if (nout < cap) {
+			u64 v = c == 0 ? e0 : c == 1 ? e1 : c == 2 ? e2 : ((u64)start << 32 | (u32)end);
+			myout[(size_t)nout * 4 + c] = v;
+		} else overflow = true;
+		++nout;
+	};
+
+	for (;;) {
+		bool need = false, back = false;
+		u64 e0 = 0, e1 = 0, e2 = 0;
+		// ---- bookkeeping until this quad needs one bwt_extend (or is out of work) ----
+		while (!need && st != ST_DONE) {
+			if (st == ST_PICK) {
+				if (pass == 0) {
+					int r = 0;
+					if (c == 0) r = (int)atomicAdd(&counters[0], 1ull);
+					r = __shfl(r, qlead);
+					if (r >= n_reads) { st = ST_DONE; break; }
+					rd = r; q = seq + off[r]; len = (int)(off[r + 1] - off[r]);
+					myout = out + (size_t)r * cap * 4;
+					nout = 0; x = 0; overflow = false; nblk = 0;
+					pass = len < sp.min_seed_len ? 4 : 1;   // src/bwamem.c:260: shorter than a seed => no intervals
+				}
+				if (pass == 1) {
+					while (x < len && q[x] > 3) ++x;
+					if (x >= len) { pass = 2; k2 = 0; old_n = nout < cap ? nout : cap; }
+					else begin_smem(x, 1);
+				} else if (pass == 2) {
+					bool found = false;
+					while (k2 < old_n) {
+						u64 info = myout[(size_t)k2 * 4 + 3], xx2 = myout[(size_t)k2 * 4 + 2];
+						++k2;
+						int s = (int)(info >> 32), e = (int)(u32)info;
+						if (e - s < sp.split_len || xx2 > (u64)sp.split_width) continue;
+						begin_smem((s + e) >> 1, (int)xx2 + 1);
+						found = true;
+						break;
+					}
+					if (!found) { pass = 3; x = 0; }
+				} else if (pass == 3) {
+					if (sp.max_mem_intv <= 0) pass = 4;
+					else {
+						while (x < len && q[x] > 3) ++x;
+						if (x >= len) pass = 4;
+						else {
+							int b = q[x];
+							ik0 = fm.L2[b] + 1; ik2 = fm.L2[b + 1] - fm.L2[b]; ik1 = fm.L2[3 - b] + 1;
+							i = x + 1; st = ST_P3;
+						}
+					}
+				} else if (pass == 4) {   // read finished
+					if (c == 0) {
+						nout_arr[rd] = nout;
+						atomicAdd(&counters[1], (u64)nblk);
+						if (overflow) atomicAdd(&counters[2], 1ull);
+					}
+					pass = 0;
+				}
+			} else if (st == ST_FWD) {
+				if (i == len || q[i] > 3) { push_fwd(); fwd_done(); }
+				else { need = true; back = false; e0 = ik0; e1 = ik1; e2 = ik2; }
+			} else if (st == ST_BWD) {
+				if (cb < 0) {
+					// start of the read or an ambiguous base: only the longest live match can be maximal
+					list_load(L, top - 1, p0, p1, p2, p_end);
+					if (last_start < 0 || i + 1 < last_start) emit(p0, p1, p2, i + 1, (int)p_end);
+					call_done();
+				} else if (j == np) {
+					if (nc == 0) call_done();
+					else { np = nc; --i; j = 0; nc = 0; set_cb(); }
+				} else {
+					list_load(L, top - 1 - j, p0, p1, p2, p_end);
+					need = true; back = true; e0 = p0; e1 = p1; e2 = p2;
+				}
+			} else { // ST_P3
+				if (i == len) { x = len; st = ST_PICK; }
+				else if (q[i] > 3) { x = i + 1; st = ST_PICK; }
+				else { need = true; back = false; e0 = ik0; e1 = ik1; e2 = ik2; }
+			}
+		}
+		if (__ballot(st != ST_DONE) == 0) break;
+		if (need) {
+			u64 o0, o1, o2;
+			nblk += quad_extend(fm, e0, e1, e2, back, c, o0, o1, o2);
+			int csel = back ? cb : 3 - (int)q[i];
+			u64 s0 = __shfl(o0, qlead | csel), s1 = __shfl(o1, qlead | csel), s2 = __shfl(o2, qlead | csel);
+			if (st == ST_FWD) {
+				bool stop = false;
+				if (s2 != ik2) {
+					push_fwd();
+					if (s2 < (u64)min_intv) { fwd_done(); stop = true; }
+				}
+				if (!stop) { ik0 = s0; ik1 = s1; ik2 = s2; ik_end = i + 1; ++i; }
+			} else if (st == ST_BWD) {
+				if (s2 < (u64)min_intv) {
+					if (nc == 0 && (last_start < 0 || i + 1 < last_start)) {
+						emit(p0, p1, p2, i + 1, (int)p_end);
+						last_start = i + 1;
+					}
+				} else if (nc == 0 || s2 != lastc_x2) {
+					list_store(L, top - 1 - nc, c, s0, s1, s2, p_end);
+					++nc; lastc_x2 = s2;
+				}
+				++j;
+			} else { // ST_P3
+				if (s2 < (u64)sp.max_mem_intv && i - x >= sp.min_seed_len) {
+					if (s2 > 0) emit(s0, s1, s2, x, i + 1);
+					x = i + 1; st = ST_PICK;
+				} else { ik0 = s0; ik1 = s1; ik2 = s2; ++i; }
+			}
+		}
+	}
+}
+
+int smem_grid_quads(int max_len, size_t *scratch_per_quad)
+{
+	int n_blocks = 256 * 2;    // 2 workgroups (64 KB LDS each) per CU
+	size_t ent = max_len + 1 > LCAP ? (size_t)(max_len + 1 - LCAP) : 0;
+	*scratch_per_quad = (ent * 4 + 4) * sizeof(u64);
+	return n_blocks * (SMEM_BLOCK / 4);
+}
+
+void launch_smem(void *stream, const FmDev &fm, const SmemParams &sp, int n_reads, const uint8_t *d_seq,
+                 const int64_t *d_off, int cap, uint64_t *d_out, int *d_nout, int max_len,
+                 unsigned long long *d_counters, void *d_scratch, size_t scratch_bytes_per_quad, int n_quads)
+{
+	(void)max_len;
+	int n_blocks = n_quads / (SMEM_BLOCK / 4);
+	int want = (n_reads + SMEM_BLOCK / 4 - 1) / (SMEM_BLOCK / 4);
+	if (want < 1) want = 1;
+	if (n_blocks > want) n_blocks = want;
+	hipLaunchKernelGGL(smem_kernel, dim3(n_blocks), dim3(SMEM_BLOCK), 0, (hipStream_t)stream, fm, sp, n_reads, d_seq,
+	                   d_off, cap, (u64 *)d_out, d_nout, (u64 *)d_counters, (u64 *)d_scratch,
+	                   scratch_bytes_per_quad / sizeof(u64));
+}
+
+// ---------------------------------------------------------------------------
+// Suffix-array lookup: LF-walk to the next sampled row, one task per quad.
+// Each step reads exactly one occ block (the BWT symbol at the row and the
+// rank of that symbol live in the same 64 bytes).
+// ---------------------------------------------------------------------------
+#define SA_BLOCK 256
+
+__global__ void __launch_bounds__(SA_BLOCK)
+sa_kernel(FmDev fm, int n, const u64 *__restrict__ ks, u64 *__restrict__ out, u64 *counters)
+{
+	const int lane = threadIdx.x & 63, c = lane & 3, qlead = lane & ~3;
+	const uint4 *blk = (const uint4 *)fm.blk;
+	const u64 mask = ((u64)1 << fm.sa_shift) - 1;
+	bool done = false, have = false;
+	u64 k = 0, steps = 0;
+	int task = 0;
+	u32 nsteps = 0;
+	for (;;) {
+		// fetch / retire
+		while (!done && (!have || (k & mask) == 0)) {
+			if (have) {
+				if (c == 0) out[task] = steps + fm.sa[k >> fm.sa_shift];
+				have = false;
+			}
+			int t = 0;
+			if (c == 0) t = (int)atomicAdd(&counters[0], 1ull);
+			t = __shfl(t, qlead);
+			if (t >= n) { done = true; break; }
+			task = t; k = ks[t]; steps = 0; have = true;
+		}
+		if (__ballot(!done) == 0) break;
+		if (!done) {
+			++steps; ++nsteps;
+			if (k == fm.primary) k = 0;   // src/bwt.c:58
+			else {
+				u64 x = k - (k > fm.primary);
+				uint4 v = blk[(x >> 7) * 4 + c];
+				// the symbol at x: word (x&127)>>4 sits in lane 2 + (word>>2), component word&3
+				int wi = (int)(x & 127) >> 4;
+				u32 mine = (wi & 3) == 0 ? v.x : (wi & 3) == 1 ? v.y : (wi & 3) == 2 ? v.z : v.w;
+				u32 word = __shfl(mine, qlead | (2 + (wi >> 2)));
+				int sym = (word >> ((~(u32)x & 15) << 1)) & 3;
+				// rank of sym up to and including x: lanes 2,3 count their four words, lane sym>>1 adds the running count
+				u64 part = 0;
+				if (c >= 2) {
+					const u32 pat = 0x55555555u * (u32)sym;
+					const int kk = (int)(x & 127) + 1 - (c == 3 ? 64 : 0);
+					u32 w4[4] = {v.x, v.y, v.z, v.w};
+					u32 cnt = 0;
+#pragma unroll
+					for (int i2 = 0; i2 < 4; ++i2) {
+						int m = kk - 16 * i2;
+						m = m < 0 ? 0 : (m > 16 ? 16 : m);
+						u32 msk = (u32)(0xFFFFFFFF00000000ull >> (2 * m));
+						u32 y = ~(w4[i2] ^ pat);
+						cnt += __popc(y & (y >> 1) & 0x55555555u & msk);
+					}
+					part = cnt;
+				} else if (c == (sym >> 1)) {
+					part = (sym & 1) ? ((u64)v.w << 32 | v.z) : ((u64)v.y << 32 | v.x);
+				}
+				part += dpp64<QP(1, 0, 3, 2)>(part);
+				part += dpp64<QP(2, 3, 0, 1)>(part);
+				k = fm.L2[sym] + part;
+			}
+		}
+	}
+	if (c == 0 && nsteps) atomicAdd(&counters[1], (u64)nsteps);
+}
+
+void launch_sa(void *stream, const FmDev &fm, int n, const uint64_t *d_k, uint64_t *d_out, unsigned long long *d_counters)
+{
+	int want = (n + SA_BLOCK / 4 - 1) / (SA_BLOCK / 4);
+	int n_blocks = 256 * 8;
+	if (want < 1) want = 1;
+	if (n_blocks > want) n_blocks = want;
+	hipLaunchKernelGGL(sa_kernel, dim3(n_blocks), dim3(SA_BLOCK), 0, (hipStream_t)stream, fm, n, (const u64 *)d_k,
+	                   (u64 *)d_out, (u64 *)d_counters);
+}
+
+} // namespace mbw

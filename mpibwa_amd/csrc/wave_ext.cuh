@@ -1,0 +1,172 @@
+// wave_ext.cuh — banded affine-gap seed extension by ONE wavefront (device code).
+//
+// Bit-exact counterpart of ksw_extend2 (src/ksw.c:380-479).  The reference's
+// decisions are row-sequential (the live column range of row i+1 depends on
+// the zeros of row i, z-drop and the best cell are tested per row), so rows
+// stay sequential here and the 64 lanes work across the columns of a row:
+//   * H(i-1,j-1)/E(i,j) live in an LDS array exactly like the reference's
+//     eh[] (including the stale cells it re-reads when the range re-grows);
+//   * the F recurrence  F(i,j+1) = max(F(i,j) - e_ins, max(M(i,j)-oe_ins, 0))
+//     only depends on M, so it is a max-plus prefix scan: with
+//     g_k = t_k + k*e_ins,  F(i,j) = max(A, max_{k<j} g_k + e_ins) - j*e_ins,
+//     computed with DPP row shifts / row broadcasts (no LDS traffic);
+//   * the row maximum with the reference's tie rule (largest j wins) is a
+//     wave max followed by a ballot.
+// No MFMA: integer DP with a data-dependent band is not a contraction.
+#ifndef MBW_WAVE_EXT_CUH
+#define MBW_WAVE_EXT_CUH
+#include <hip/hip_runtime.h>
+
+namespace mbw {
+
+#define WX_NEG (-(1 << 29))
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int wx_dpp(int old, int v)
+{
+	return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, false);
+}
+
+// inclusive prefix max over the 64 lanes (identity WX_NEG)
+__device__ __forceinline__ int wx_scan_max(int v)
+{
+	v = max(v, wx_dpp<0x111, 0xf>(WX_NEG, v));   // row_shr:1
+	v = max(v, wx_dpp<0x112, 0xf>(WX_NEG, v));   // row_shr:2
+	v = max(v, wx_dpp<0x114, 0xf>(WX_NEG, v));   // row_shr:4
+	v = max(v, wx_dpp<0x118, 0xf>(WX_NEG, v));   // row_shr:8
+	v = max(v, wx_dpp<0x142, 0xa>(WX_NEG, v));   // row_bcast:15 -> rows 1,3
+	v = max(v, wx_dpp<0x143, 0xc>(WX_NEG, v));   // row_bcast:31 -> rows 2,3
+	return v;
+}
+// value of the previous lane (lane 0 gets `first`)
+__device__ __forceinline__ int wx_prev_lane(int v, int first)
+{
+	return wx_dpp<0x138, 0xf>(first, v);         // wave_shr:1
+}
+
+struct WxParams {
+	int8_t mat[25];
+	int o_del, e_del, o_ins, e_ins, zdrop;
+};
+
+struct WxResult { int score, qle, tle, gtle, gscore, max_off; };
+
+// QF(j)  -> query base 0..4 at column j  (evaluated per lane)
+// TF(i)  -> target base 0..4 at row i    (evaluated per lane for prefetching 64 rows at a time)
+// H, E   -> LDS (or global) arrays of qlen+1 ints owned by this wave
+// `w` must already be clamped like src/ksw.c:395-407 (see wx_clamp_band on the host side).
+template <typename QF, typename TF>
+__device__ __forceinline__ WxResult wave_extend(int qlen, QF qf, int tlen, TF tf, const WxParams &P, int w, int h0,
+                                                int *H, int *E, unsigned long long &cells)
+{
+	const int lane = threadIdx.x & 63;
+	const int oe_del = P.o_del + P.e_del, oe_ins = P.o_ins + P.e_ins, e_del = P.e_del, e_ins = P.e_ins;
+	// first row (src/ksw.c:389-393)
+	for (int j = lane; j <= qlen; j += 64) {
+		int v = 0;
+		if (j == 0) v = h0;
+		else {
+			int t = h0 - oe_ins - (j - 1) * e_ins;   // H[j] while the chain H[j-1] > e_ins holds
+			// H[1] = max(h0-oe_ins,0); H[j] = H[j-1]-e_ins as long as H[j-1] > e_ins
+			int h1 = h0 > oe_ins ? h0 - oe_ins : 0;
+			if (j == 1) v = h1;
+			else v = (h1 - (j - 2) * e_ins > e_ins) ? t : 0;
+		}
+		H[j] = v; E[j] = 0;
+	}
+	__builtin_amdgcn_wave_barrier();
+	int best = h0, best_i = -1, best_j = -1, best_ie = -1, gscore = -1, max_off = 0;
+	int beg = 0, end = qlen;
+	int tv = 0, tv_base = -64;
+	for (int i = 0; i < tlen; ++i) {
+		if (i - tv_base >= 64) { tv_base = i; tv = (i + lane < tlen) ? (int)tf(i + lane) : 4; }
+		const int tb = __builtin_amdgcn_readlane(tv, i - tv_base);
+		const int m0 = P.mat[tb * 5 + 0], m1 = P.mat[tb * 5 + 1], m2 = P.mat[tb * 5 + 2], m3 = P.mat[tb * 5 + 3],
+		          m4 = P.mat[tb * 5 + 4];
+		if (beg < i - w) beg = i - w;
+		if (end > i + w + 1) end = i + w + 1;
+		if (end > qlen) end = qlen;
+		int hleft0 = 0;
+		if (beg == 0) { hleft0 = h0 - (P.o_del + e_del * (i + 1)); if (hleft0 < 0) hleft0 = 0; }
+		int rowmax = 0, rowmax_j = -1;
+		int A = beg * e_ins;                       // F(i,beg) = 0
+		if (beg < end) {
+			const int s0 = beg >> 6, s1 = (end - 1) >> 6;
+			int diag0 = H[s0 << 6];                // pre-read of the strip's first cell (see below)
+			for (int s = s0; s <= s1; ++s) {
+				const int j = (s << 6) + lane;
+				const bool act = j >= beg && j < end;
+				int diag = lane == 0 ? diag0 : (j <= qlen ? H[j] : 0);
+				int e = j <= qlen ? E[j] : 0;
+				// the last lane writes H[64(s+1)], which is the next strip's first diagonal: read it first
+				const int nxt = (s + 1) << 6;
+				if (nxt <= qlen) diag0 = H[nxt];
+				int qb = act ? (int)qf(j) : 4;
+				int sc = qb == 0 ? m0 : qb == 1 ? m1 : qb == 2 ? m2 : qb == 3 ? m3 : m4;
+				int M = diag ? diag + sc : 0;
+				int tI = M - oe_ins; tI = tI > 0 ? tI : 0;
+				int g = act ? tI + j * e_ins : WX_NEG;
+				int incl = wx_scan_max(g);
+				int excl = wx_prev_lane(incl, WX_NEG);
+				int f = max(A, excl + e_ins) - j * e_ins;
+				int h = max(max(M, e), f);
+				int tD = M - oe_del; tD = tD > 0 ? tD : 0;
+				int en = max(e - e_del, tD);
+				if (j == beg) H[j] = hleft0;
+				if (act) { H[j + 1] = h; E[j] = en; }
+				A = max(A, __builtin_amdgcn_readlane(incl, 63) + e_ins);
+				// row maximum, largest column wins ties
+				int hv = act ? h : -1;
+				int red = wx_scan_max(hv);
+				int smax = __builtin_amdgcn_readlane(red, 63);
+				if (smax >= rowmax) {
+					unsigned long long bal = __ballot(act && h == smax);
+					if (bal) { rowmax = smax; rowmax_j = (s << 6) + 63 - __clzll(bal); }
+				}
+			}
+			cells += (unsigned long long)(end - beg);
+		} else if (lane == 0) H[end] = hleft0;     // empty range: eh[end].h = h1 (src/ksw.c:447)
+		if (lane == 0) E[end] = 0;
+		__builtin_amdgcn_wave_barrier();
+		const int h1 = H[end];
+		const int jfin = beg < end ? end : beg;    // value of the reference's column counter after its loop
+		if (jfin == qlen) {
+			if (h1 >= gscore) best_ie = i;
+			if (h1 > gscore) gscore = h1;
+		}
+		if (rowmax == 0) break;
+		if (rowmax > best) {
+			best = rowmax; best_i = i; best_j = rowmax_j;
+			int d = rowmax_j - i; d = d < 0 ? -d : d;
+			if (d > max_off) max_off = d;
+		} else if (P.zdrop > 0) {
+			int di = i - best_i, dj = rowmax_j - best_j;
+			if (di > dj) { if (best - rowmax - (di - dj) * e_del > P.zdrop) break; }
+			else { if (best - rowmax - (dj - di) * e_ins > P.zdrop) break; }
+		}
+		// live range of the next row: first / last cell of [beg,end] with H or E non-zero
+		if (beg > end) beg = end;                  // (unreachable in practice; keeps the scans in bounds)
+		int nb = end;
+		for (int s = beg >> 6; s <= (end - 1) >> 6 && nb == end && beg < end; ++s) {
+			const int j = (s << 6) + lane;
+			bool nz = j >= beg && j < end && (H[j] != 0 || E[j] != 0);
+			unsigned long long bal = __ballot(nz);
+			if (bal) nb = (s << 6) + __ffsll((long long)bal) - 1;
+		}
+		int ne = nb - 1;                           // value of j when the downward scan finds nothing
+		for (int s = end >> 6; s >= nb >> 6; --s) {
+			const int j = (s << 6) + lane;
+			bool nz = j >= nb && j <= end && (H[j] != 0 || E[j] != 0);
+			unsigned long long bal = __ballot(nz);
+			if (bal) { ne = (s << 6) + 63 - __clzll(bal); break; }
+		}
+		beg = nb;
+		end = ne + 2 < qlen ? ne + 2 : qlen;
+	}
+	WxResult r;
+	r.score = best; r.qle = best_j + 1; r.tle = best_i + 1; r.gtle = best_ie + 1; r.gscore = gscore; r.max_off = max_off;
+	return r;
+}
+
+} // namespace mbw
+#endif
