@@ -92,8 +92,11 @@ __device__ __forceinline__ int quad_extend(const FmDev &fm, u64 x0, u64 x1, u64 
 	u64 a = fm.L2[c] + 1 + tk, s = tl - tk;
 	// mirrored side: children are laid out T,G,C,A behind the (possible) sentinel
 	u64 base = (back ? x1 : x0) + ((p <= fm.primary && p + x2 - 1 >= fm.primary) ? 1 : 0);
-	u64 s1 = s + (c < 3 ? dpp64<QP(1, 2, 3, 3)>(s) : 0);
-	u64 s2 = s1 + (c < 2 ? dpp64<QP(2, 3, 2, 3)>(s1) : 0);
+	// (DPP reads must stay outside any lane-divergent branch: a disabled source lane reads as garbage)
+	u64 n1 = dpp64<QP(1, 2, 3, 3)>(s);
+	u64 s1 = s + (c < 3 ? n1 : 0);
+	u64 n2 = dpp64<QP(2, 3, 2, 3)>(s1);
+	u64 s2 = s1 + (c < 2 ? n2 : 0);
 	u64 mir = base + (s2 - s);
 	o0 = back ? a : mir;
 	o1 = back ? mir : a;

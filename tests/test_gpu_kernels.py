@@ -34,6 +34,10 @@ def test_smem_kernel_matches_oracle(engine, genome, reads_pe, reads_var):
     got, ms, nbytes = engine.smem(opt, seqs, cap=512)
     total_in = 0
     for s, a in zip(seqs, got):
+        if len(s) < 19:   # src/bwamem.c:260: reads shorter than a seed never reach mem_collect_intv
+            assert len(a) == 0
+            total_in += len(s)
+            continue
         b = fm.collect_intv(s)
         assert a.shape == b.shape, (len(s), a.shape, b.shape)
         assert (a == b).all()
