@@ -31,7 +31,7 @@ def build(force=False, verbose=False):
     hdrs.append(os.path.join(HERE, "..", "include", "mpibwa_amd.h"))
     objs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
-    common = ["-O3", "-std=c++17", "-fPIC", "-g1", "-Wall", "-Wno-unused-function", "-Wno-unused-result",
+    common = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-g1", "-Wall", "-Wno-unused-function", "-Wno-unused-result",
               "-I", CSRC, "-I", os.path.join(HERE, "..", "include")]
     for s in srcs:
         o = os.path.join(HERE, "build", os.path.basename(s) + ".o")

@@ -1,0 +1,227 @@
+// c2a_kernel.hip — chain -> alignment regions on the device, one wavefront per read.
+//
+// Device counterpart of mem_chain2aln (src/bwamem.c:632-786) including its
+// calls to bns_fetch_seq (the reference window is never materialised: target
+// bases are read straight from the 2-bit pac in HBM, src/bntseq.c:398-446)
+// and ksw_extend2 (wave_ext.cuh).  The seed loop of one read is sequentially
+// dependent (a seed is skipped when an earlier extension of ANY chain of the
+// read already covers it, src/bwamem.c:671-706), so one wavefront owns one
+// read: the scalar control flow is wave-uniform and every inner loop (the
+// containment tests over earlier regions, the overlap test over the other
+// seeds, seed coverage, and the DP rows) runs across the 64 lanes.
+//
+// Floating-point decisions of the reference are resolved on the host into
+// integer tables indexed by length (gap[], bound5[], bound3[], ceil95[],
+// thr10[]), so the device does integer work only.
+#include <hip/hip_runtime.h>
+#include "device.h"
+#include "wave_ext.cuh"
+
+namespace mbw {
+
+typedef long long i64;
+
+__device__ __forceinline__ i64 wave_min_i64(i64 v)
+{
+	for (int o = 32; o > 0; o >>= 1) { i64 t = __shfl_xor(v, o); v = t < v ? t : v; }
+	return v;
+}
+__device__ __forceinline__ i64 wave_max_i64(i64 v)
+{
+	for (int o = 32; o > 0; o >>= 1) { i64 t = __shfl_xor(v, o); v = t > v ? t : v; }
+	return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+	return v;
+}
+
+// base at position p of the doubled reference (forward strand followed by its reverse complement)
+__device__ __forceinline__ int ref_base(const uint8_t *pac, i64 l_pac, i64 p)
+{
+	if (p >= l_pac) {
+		i64 f = (l_pac << 1) - 1 - p;
+		return 3 - ((pac[f >> 2] >> ((~f & 3) << 1)) & 3);
+	}
+	return (pac[p >> 2] >> ((~p & 3) << 1)) & 3;
+}
+
+#define C2A_WAVES 4
+#define SRT_MARK 0xFFFFFFFFu
+
+__global__ void __launch_bounds__(64 * C2A_WAVES)
+c2a_kernel(C2aParams P, WxParams X, int n_reads, const uint8_t *__restrict__ seq, const int64_t *__restrict__ off,
+           const int *__restrict__ chain_off, const DevChain *__restrict__ chains, const DevSeed *__restrict__ seeds,
+           unsigned int *srt, const int *__restrict__ reg_off, DevReg *regs, int *n_regs, const int *__restrict__ tab,
+           int tab_stride, const uint8_t *__restrict__ pac, unsigned long long *counters, int max_len)
+{
+	extern __shared__ int lds[];
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int rd = blockIdx.x * C2A_WAVES + wave;
+	if (rd >= n_reads) return;
+	int *H = lds + (size_t)wave * 2 * (max_len + 2);
+	int *E = H + (max_len + 2);
+	const int *gap = tab, *bound5 = tab + tab_stride, *bound3 = tab + 2 * tab_stride, *ceil95 = tab + 3 * tab_stride,
+	          *thr10 = tab + 4 * tab_stride;
+	const uint8_t *q = seq + off[rd];
+	const int lq = (int)(off[rd + 1] - off[rd]);
+	DevReg *av = regs + reg_off[rd];
+	int nav = 0;
+	unsigned long long cells = 0, n_ext = 0;
+	const i64 l_pac = P.l_pac;
+
+	for (int ci = chain_off[rd]; ci < chain_off[rd + 1]; ++ci) {
+		const DevChain C = chains[ci];
+		const int n = C.n_seeds;
+		if (n == 0) continue;
+		const DevSeed *sd = seeds + C.seed_beg;
+		unsigned int *ord = srt + C.seed_beg;
+		// widest reference span any seed of the chain could reach (src/bwamem.c:642-658)
+		i64 lo = l_pac << 1, hi = 0;
+		for (int i = lane; i < n; i += 64) {
+			const DevSeed t = sd[i];
+			i64 b = t.rbeg - (t.qbeg + gap[t.qbeg]);
+			int tail = lq - t.qbeg - t.len;
+			i64 e = t.rbeg + t.len + (tail + gap[tail]);
+			lo = b < lo ? b : lo;
+			hi = e > hi ? e : hi;
+		}
+		i64 rmax0 = wave_min_i64(lo), rmax1 = wave_max_i64(hi);
+		rmax0 = rmax0 > 0 ? rmax0 : 0;
+		rmax1 = rmax1 < l_pac << 1 ? rmax1 : l_pac << 1;
+		if (rmax0 < l_pac && l_pac < rmax1) {   // never cross the strand boundary
+			if (sd[0].rbeg < l_pac) rmax1 = l_pac;
+			else rmax0 = l_pac;
+		}
+		// bns_fetch_seq clamps to the contig that holds the first seed
+		rmax0 = rmax0 > C.far_beg ? rmax0 : C.far_beg;
+		rmax1 = rmax1 < C.far_end ? rmax1 : C.far_end;
+
+		for (int k = n - 1; k >= 0; --k) {
+			const DevSeed s = sd[ord[k]];
+			// ---- is the seed already inside an earlier extension of this read? ----
+			bool hit = false;
+			for (int i0 = 0; i0 < nav && !hit; i0 += 64) {
+				int i = i0 + lane;
+				bool h = false;
+				if (i < nav) {
+					const DevReg p = av[i];
+					if (!(s.rbeg < p.rb || s.rbeg + s.len > p.re || s.qbeg < p.qb || s.qbeg + s.len > p.qe) &&
+					    !(s.len - p.seedlen0 > thr10[lq])) {
+						int qd = s.qbeg - p.qb; i64 rd_ = s.rbeg - p.rb;
+						int mg = gap[qd < rd_ ? qd : (int)rd_];
+						int w = mg < p.w ? mg : p.w;
+						if (qd - rd_ < w && rd_ - qd < w) h = true;
+						else {
+							qd = p.qe - (s.qbeg + s.len); rd_ = p.re - (s.rbeg + s.len);
+							mg = gap[qd < rd_ ? qd : (int)rd_];
+							w = mg < p.w ? mg : p.w;
+							if (qd - rd_ < w && rd_ - qd < w) h = true;
+						}
+					}
+				}
+				hit = __ballot(h) != 0;
+			}
+			if (hit) {   // extend anyway if a long overlapping seed of the chain sits on another diagonal
+				bool other = false;
+				for (int i0 = k + 1; i0 < n && !other; i0 += 64) {
+					int i = i0 + lane;
+					bool h = false;
+					if (i < n && ord[i] != SRT_MARK) {
+						const DevSeed t = sd[ord[i]];
+						if (!(t.len < ceil95[s.len])) {
+							if (s.qbeg <= t.qbeg && s.qbeg + s.len - t.qbeg >= s.len >> 2 && t.qbeg - s.qbeg != t.rbeg - s.rbeg) h = true;
+							if (t.qbeg <= s.qbeg && t.qbeg + t.len - s.qbeg >= s.len >> 2 && s.qbeg - t.qbeg != s.rbeg - t.rbeg) h = true;
+						}
+					}
+					other = __ballot(h) != 0;
+				}
+				if (!other) {
+					if (lane == 0) ord[k] = SRT_MARK;
+					continue;
+				}
+			}
+			// ---- new region ----
+			DevReg a;
+			a.rb = a.re = 0; a.qb = a.qe = 0;
+			a.rid = C.rid; a.score = a.truesc = -1; a.w = P.w; a.seedcov = 0; a.seedlen0 = s.len; a.frac_rep = C.frac_rep;
+			int aw0 = P.w, aw1 = P.w;
+			if (s.qbeg) {   // left extension: both sequences reversed
+				const int qlen = s.qbeg;
+				const i64 tlen64 = s.rbeg - rmax0;
+				const int tlen = (int)tlen64;
+				WxResult r{};
+				for (int i = 0; i < 2; ++i) {
+					int prev = a.score;
+					aw0 = P.w << i;
+					int wc = aw0 < bound5[qlen] ? aw0 : bound5[qlen];
+					r = wave_extend(qlen, [&](int j) { return q[s.qbeg - 1 - j]; }, tlen,
+					                [&](int t) { return ref_base(pac, l_pac, s.rbeg - 1 - t); }, X, wc, s.len * P.a, H, E, cells);
+					++n_ext;
+					a.score = r.score;
+					if (a.score == prev || r.max_off < (aw0 >> 1) + (aw0 >> 2)) break;
+				}
+				if (r.gscore <= 0 || r.gscore <= a.score - P.pen_clip5) {   // local
+					a.qb = s.qbeg - r.qle; a.rb = s.rbeg - r.tle; a.truesc = a.score;
+				} else {                                                    // reaches the read start
+					a.qb = 0; a.rb = s.rbeg - r.gtle; a.truesc = r.gscore;
+				}
+			} else { a.score = a.truesc = s.len * P.a; a.qb = 0; a.rb = s.rbeg; }
+			if (s.qbeg + s.len != lq) {   // right extension
+				const int sc0 = a.score, qe = s.qbeg + s.len;
+				const i64 re = s.rbeg + s.len - rmax0;
+				const int qlen = lq - qe, tlen = (int)(rmax1 - rmax0 - re);
+				WxResult r{};
+				for (int i = 0; i < 2; ++i) {
+					int prev = a.score;
+					aw1 = P.w << i;
+					int wc = aw1 < bound3[qlen] ? aw1 : bound3[qlen];
+					r = wave_extend(qlen, [&](int j) { return q[qe + j]; }, tlen,
+					                [&](int t) { return ref_base(pac, l_pac, s.rbeg + s.len + t); }, X, wc, sc0, H, E, cells);
+					++n_ext;
+					a.score = r.score;
+					if (a.score == prev || r.max_off < (aw1 >> 1) + (aw1 >> 2)) break;
+				}
+				if (r.gscore <= 0 || r.gscore <= a.score - P.pen_clip3) {
+					a.qe = qe + r.qle; a.re = rmax0 + re + r.tle; a.truesc += a.score - sc0;
+				} else {
+					a.qe = lq; a.re = rmax0 + re + r.gtle; a.truesc += r.gscore - sc0;
+				}
+			} else { a.qe = lq; a.re = s.rbeg + s.len; }
+			// seed coverage
+			int cov = 0;
+			for (int i = lane; i < n; i += 64) {
+				const DevSeed t = sd[i];
+				if (t.qbeg >= a.qb && t.qbeg + t.len <= a.qe && t.rbeg >= a.rb && t.rbeg + t.len <= a.re) cov += t.len;
+			}
+			a.seedcov = wave_sum_i32(cov);
+			a.w = aw0 > aw1 ? aw0 : aw1;
+			if (lane == 0) av[nav] = a;
+			++nav;
+			__builtin_amdgcn_wave_barrier();
+		}
+	}
+	if (lane == 0) {
+		n_regs[rd] = nav;
+		atomicAdd(&counters[0], cells);
+		atomicAdd(&counters[1], n_ext);
+	}
+}
+
+void launch_c2a(void *stream, const C2aParams &P, const ExtParams &ep, int n_reads, const uint8_t *d_seq, const int64_t *d_off,
+                const int *d_chain_off, const DevChain *d_chains, const DevSeed *d_seeds, unsigned int *d_srt, const int *d_reg_off,
+                DevReg *d_regs, int *d_nregs, const int *d_tab, int tab_stride, const uint8_t *d_pac, unsigned long long *d_counters,
+                int max_len)
+{
+	WxParams X;
+	for (int i = 0; i < 25; ++i) X.mat[i] = ep.mat[i];
+	X.o_del = ep.o_del; X.e_del = ep.e_del; X.o_ins = ep.o_ins; X.e_ins = ep.e_ins; X.zdrop = ep.zdrop;
+	size_t shmem = (size_t)C2A_WAVES * 2 * (max_len + 2) * sizeof(int);
+	int n_blocks = (n_reads + C2A_WAVES - 1) / C2A_WAVES;
+	hipLaunchKernelGGL(c2a_kernel, dim3(n_blocks), dim3(64 * C2A_WAVES), shmem, (hipStream_t)stream, P, X, n_reads, d_seq, d_off,
+	                   d_chain_off, d_chains, d_seeds, d_srt, d_reg_off, d_regs, d_nregs, d_tab, tab_stride, d_pac, d_counters,
+	                   max_len);
+}
+
+} // namespace mbw

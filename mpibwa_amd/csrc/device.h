@@ -59,5 +59,38 @@ void launch_extend(void *stream, const ExtParams &ep, int n, const uint8_t *d_q,
                    const uint8_t *d_t, const int64_t *d_toff, const int *d_w, const int *d_h0, const int *d_eb,
                    int *d_out6, unsigned long long *d_cells, int max_qlen);
 
+// ---- chain -> region kernel (c2a_kernel.hip) ----
+struct DevSeed { int64_t rbeg; int32_t qbeg, len; };           // 16 B
+struct DevChain {
+	int64_t far_beg, far_end;    // bounds of the chain's contig on the chain's strand (doubled coordinate)
+	int32_t seed_beg, n_seeds;   // into the flat seed / order arrays
+	int32_t rid;
+	float frac_rep;
+};
+struct DevReg {                  // the fields of mem_alnreg_t that mem_chain2aln fills (src/bwamem.c:708-783)
+	int64_t rb, re;
+	int32_t qb, qe, rid, score, truesc, w, seedcov, seedlen0;
+	float frac_rep;
+	int32_t pad;
+};
+struct C2aParams {
+	int64_t l_pac;
+	int a, w, pen_clip5, pen_clip3;
+};
+void launch_c2a(void *stream, const C2aParams &P, const ExtParams &ep, int n_reads, const uint8_t *d_seq, const int64_t *d_off,
+                const int *d_chain_off, const DevChain *d_chains, const DevSeed *d_seeds, unsigned int *d_srt, const int *d_reg_off,
+                DevReg *d_regs, int *d_nregs, const int *d_tab, int tab_stride, const uint8_t *d_pac, unsigned long long *d_counters,
+                int max_len);
+
+// ---- seed enumeration between SMEM and SA lookup (fm_kernels.hip) ----
+// per read: sort intervals by info, l_rep (src/bwamem.c:265-272) and the number of SA rows to look up
+void launch_seed_prep(void *stream, int n_reads, int cap, uint64_t *d_intv, const int *d_nintv, int max_occ, int *d_nseeds, int *d_lrep);
+// per read: write the SA rows and (qbeg,len) of every seed in mem_chain's order (src/bwamem.c:273-283)
+void launch_seed_enum(void *stream, int n_reads, int cap, const uint64_t *d_intv, const int *d_nintv, int max_occ,
+                      const int64_t *d_seed_off, uint64_t *d_rows, int32_t *d_qbeg_len);
+
+SmemParams smem_params(const mem_opt_t *opt);
+int clamp_band(const mem_opt_t *opt, int qlen, int w, int end_bonus);
+
 } // namespace mbw
 #endif

@@ -385,4 +385,71 @@ void launch_sa(void *stream, const FmDev &fm, int n, const uint64_t *d_k, uint64
 	                   (u64 *)d_out, (u64 *)d_counters);
 }
 
+// ---------------------------------------------------------------------------
+// Seed enumeration: one thread per read (tiny integer work, L2-resident data).
+// ---------------------------------------------------------------------------
+__global__ void seed_prep_kernel(int n_reads, int cap, u64 *intv, const int *__restrict__ nintv, int max_occ,
+                                 int *__restrict__ nseeds, int *__restrict__ lrep)
+{
+	int r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_reads) return;
+	int n = nintv[r] < cap ? nintv[r] : cap;
+	ulonglong4 *a = (ulonglong4 *)(intv + (size_t)r * cap * 4);
+	// insertion sort by info (.w); equal keys are identical records (same substring => same bi-interval)
+	for (int i = 1; i < n; ++i) {
+		ulonglong4 v = a[i];
+		int j = i - 1;
+		while (j >= 0 && a[j].w > v.w) { a[j + 1] = a[j]; --j; }
+		a[j + 1] = v;
+	}
+	int b = 0, e = 0, l_rep = 0, total = 0;
+	for (int i = 0; i < n; ++i) {
+		ulonglong4 v = a[i];
+		int sb = (int)(v.w >> 32), se = (int)(u32)v.w;
+		if (v.z > (u64)max_occ) {
+			if (sb > e) { l_rep += e - b; b = sb; e = se; }
+			else e = e > se ? e : se;
+		}
+		u64 step = v.z > (u64)max_occ ? v.z / max_occ : 1;
+		u64 cnt = (v.z + step - 1) / step;
+		total += (int)(cnt < (u64)max_occ ? cnt : (u64)max_occ);
+	}
+	l_rep += e - b;
+	nseeds[r] = total;
+	lrep[r] = l_rep;
+}
+
+__global__ void seed_enum_kernel(int n_reads, int cap, const u64 *__restrict__ intv, const int *__restrict__ nintv, int max_occ,
+                                 const int64_t *__restrict__ seed_off, u64 *__restrict__ rows, int32_t *__restrict__ qbeg_len)
+{
+	int r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_reads) return;
+	int n = nintv[r] < cap ? nintv[r] : cap;
+	const ulonglong4 *a = (const ulonglong4 *)(intv + (size_t)r * cap * 4);
+	int64_t o = seed_off[r];
+	for (int i = 0; i < n; ++i) {
+		ulonglong4 v = a[i];
+		int qbeg = (int)(v.w >> 32), slen = (int)(u32)v.w - qbeg;
+		u64 step = v.z > (u64)max_occ ? v.z / max_occ : 1;
+		int count = 0;
+		for (u64 k = 0; k < v.z && count < max_occ; k += step, ++count) {
+			rows[o] = v.x + k;
+			qbeg_len[2 * o] = qbeg; qbeg_len[2 * o + 1] = slen;
+			++o;
+		}
+	}
+}
+
+void launch_seed_prep(void *stream, int n_reads, int cap, uint64_t *d_intv, const int *d_nintv, int max_occ, int *d_nseeds, int *d_lrep)
+{
+	hipLaunchKernelGGL(seed_prep_kernel, dim3((n_reads + 127) / 128), dim3(128), 0, (hipStream_t)stream, n_reads, cap, (u64 *)d_intv,
+	                   d_nintv, max_occ, d_nseeds, d_lrep);
+}
+void launch_seed_enum(void *stream, int n_reads, int cap, const uint64_t *d_intv, const int *d_nintv, int max_occ,
+                      const int64_t *d_seed_off, uint64_t *d_rows, int32_t *d_qbeg_len)
+{
+	hipLaunchKernelGGL(seed_enum_kernel, dim3((n_reads + 127) / 128), dim3(128), 0, (hipStream_t)stream, n_reads, cap,
+	                   (const u64 *)d_intv, d_nintv, max_occ, d_seed_off, (u64 *)d_rows, d_qbeg_len);
+}
+
 } // namespace mbw

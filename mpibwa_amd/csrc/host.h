@@ -1,0 +1,100 @@
+// host.h — host-side stages of the hot path (everything that is not one of the HIP kernels yet).
+#ifndef MBW_HOST_H
+#define MBW_HOST_H
+#include "internal.h"
+#include <string>
+#include <vector>
+
+namespace mbw {
+
+struct HSeed {           // mem_seed_t, src/bwamem.c:168-172
+	int64_t rbeg;
+	int32_t qbeg, len;
+	int32_t score;
+};
+
+struct HChain {          // mem_chain_t, src/bwamem.c:174-181
+	int64_t pos = 0;
+	int rid = 0, first = -1;
+	uint32_t w = 0;
+	int kept = 0, is_alt = 0;
+	float frac_rep = 0;
+	std::vector<HSeed> seeds;
+};
+
+struct HReg {            // mem_alnreg_t, src/bwamem.h:59-77
+	int64_t rb = 0, re = 0;
+	int qb = 0, qe = 0;
+	int rid = 0;
+	int score = 0, truesc = 0, sub = 0, alt_sc = 0, csub = 0, sub_n = 0;
+	int w = 0, seedcov = 0, secondary = 0, secondary_all = 0, seedlen0 = 0;
+	int n_comp = 0, is_alt = 0;
+	float frac_rep = 0;
+	uint64_t hash = 0;
+};
+typedef std::vector<HReg> HRegV;
+
+struct HAln {            // mem_aln_t, src/bwamem.h:87-98 (cigar + MD kept as separate members)
+	int64_t pos = 0;
+	int rid = 0, flag = 0;
+	uint32_t is_rev = 0, is_alt = 0, mapq = 0, NM = 0;
+	std::vector<uint32_t> cigar;
+	std::string md;
+	bool has_xa = false;
+	std::string xa;
+	int score = 0, sub = 0, alt_sc = 0;
+	int n_cigar() const { return (int)cigar.size(); }
+};
+
+struct KswResult { int score, te, qe, score2, te2, tb, qb; };   // kswr_t, src/ksw.h:14-20
+
+// ---- reference geometry helpers (src/bntseq.c) ----
+int  bns_pos2rid(const bntseq_t *bns, int64_t pos_f);
+int  bns_intv2rid(const bntseq_t *bns, int64_t rb, int64_t re);
+inline int64_t bns_depos(const bntseq_t *bns, int64_t pos, int *is_rev)
+{
+	return (*is_rev = (pos >= bns->l_pac)) ? (bns->l_pac << 1) - 1 - pos : pos;
+}
+std::vector<uint8_t> bns_get_seq(int64_t l_pac, const uint8_t *pac, int64_t beg, int64_t end, bool *ok);
+std::vector<uint8_t> bns_fetch_seq(const bntseq_t *bns, const uint8_t *pac, int64_t *beg, int64_t mid, int64_t *end, int *rid);
+
+// ---- DP on the host (src/ksw.c) ----
+int ksw_global2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat, int o_del, int e_del,
+                int o_ins, int e_ins, int w, std::vector<uint32_t> *cigar);
+KswResult ksw_align2(int qlen, uint8_t *query, int tlen, uint8_t *target, const int8_t *mat, int o_del, int e_del,
+                     int o_ins, int e_ins, int xtra);
+#define KSW_XBYTE  0x10000
+#define KSW_XSTOP  0x20000
+#define KSW_XSUBO  0x40000
+#define KSW_XSTART 0x80000
+
+// ---- per-read stages ----
+int  cal_max_gap(const mem_opt_t *opt, int qlen);
+void chains_from_seeds(const mem_opt_t *opt, const bntseq_t *bns, int l_query, const HSeed *seeds, int n_seeds, int l_rep,
+                       std::vector<HChain> &chains);
+void chain_filter(const mem_opt_t *opt, std::vector<HChain> &chains);
+void filter_chained_seeds(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, int l_query, const uint8_t *query,
+                          std::vector<HChain> &chains);
+int  sort_dedup_patch(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, uint8_t *query, HRegV &regs);
+int  mark_primary_se(const mem_opt_t *opt, HRegV &a, int64_t id);
+void reorder_primary5(int T, HRegV &a);
+int  approx_mapq_se(const mem_opt_t *opt, const HReg *a);
+bool gen_cigar2(const int8_t mat[25], int o_del, int e_del, int o_ins, int e_ins, int w_, int64_t l_pac, const uint8_t *pac,
+                int l_query, uint8_t *query, int64_t rb, int64_t re, int *score, std::vector<uint32_t> *cigar, std::string *md, int *NM);
+HAln reg2aln(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, int l_query, const char *query, const HReg *ar);
+void reg2sam(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, bseq1_t *s, HRegV &a, int extra_flag, const HAln *m);
+
+// ---- per-batch / per-pair stages (src/bwamem_pair.c) ----
+void pestat(const mem_opt_t *opt, int64_t l_pac, int n, const HRegV *regs, mem_pestat_t pes[4]);
+int  sam_pe(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, const mem_pestat_t pes[4], uint64_t id, bseq1_t s[2],
+            HRegV a[2]);
+
+inline uint64_t hash_64(uint64_t key)   // Thomas Wang's 64-bit mix, as in src/utils.h:98-109
+{
+	key += ~(key << 32); key ^= (key >> 22); key += ~(key << 13); key ^= (key >> 8);
+	key += (key << 3);   key ^= (key >> 15); key += ~(key << 27); key ^= (key >> 31);
+	return key;
+}
+
+} // namespace mbw
+#endif

@@ -1,0 +1,342 @@
+// host_pair.cpp — paired-end stages (host):
+//   mem_pestat   insert-size distribution over the whole batch    src/bwamem_pair.c:46-109
+//   mem_matesw   mate rescue by local alignment in the window     src/bwamem_pair.c:111-180
+//   mem_pair     best consistent pair                             src/bwamem_pair.c:182-243
+//   mem_sam_pe   pairing decision, MAPQ and the two SAM records   src/bwamem_pair.c:250-393
+#include "host.h"
+#include "sortutil.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace mbw {
+
+void aln2sam_pub(const mem_opt_t *opt, const bntseq_t *bns, std::string &str, const bseq1_t *s, int n, const HAln *list, int which,
+                 const HAln *m);
+bool gen_alt(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, const HRegV &a, int l_query, const char *query,
+             std::vector<std::string> &xa, std::vector<char> &has);
+char *sam_to_c(const std::string &s);
+
+// orientation (0 FF, 1 FR, 2 RF, 3 RR) and distance of two hits given in the doubled coordinate
+static inline int infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t *dist)
+{
+	int r1 = (b1 >= l_pac), r2 = (b2 >= l_pac);
+	int64_t p2 = r1 == r2 ? b2 : (l_pac << 1) - 1 - b2;   // mate projected on read 1's strand
+	*dist = p2 > b1 ? p2 - b1 : b1 - p2;
+	return (r1 == r2 ? 0 : 1) ^ (p2 > b1 ? 0 : 3);
+}
+
+static int cal_sub(const mem_opt_t *opt, const HRegV &r)
+{
+	size_t j;
+	for (j = 1; j < r.size(); ++j) {
+		int b_max = r[j].qb > r[0].qb ? r[j].qb : r[0].qb;
+		int e_min = r[j].qe < r[0].qe ? r[j].qe : r[0].qe;
+		if (e_min > b_max) {
+			int min_l = r[j].qe - r[j].qb < r[0].qe - r[0].qb ? r[j].qe - r[j].qb : r[0].qe - r[0].qb;
+			if (e_min - b_max >= min_l * opt->mask_level) break;
+		}
+	}
+	return j < r.size() ? r[j].score : opt->min_seed_len * opt->a;
+}
+
+void pestat(const mem_opt_t *opt, int64_t l_pac, int n, const HRegV *regs, mem_pestat_t pes[4])
+{
+	std::vector<uint64_t> isize[4];
+	memset(pes, 0, 4 * sizeof(mem_pestat_t));
+	for (int i = 0; i < n >> 1; ++i) {
+		const HRegV &r0 = regs[i << 1 | 0], &r1 = regs[i << 1 | 1];
+		if (r0.empty() || r1.empty()) continue;
+		if (cal_sub(opt, r0) > 0.8 * r0[0].score) continue;   // only unique hits vote
+		if (cal_sub(opt, r1) > 0.8 * r1[0].score) continue;
+		if (r0[0].rid != r1[0].rid) continue;
+		int64_t is;
+		int dir = infer_dir(l_pac, r0[0].rb, r1[0].rb, &is);
+		if (is && is <= opt->max_ins) isize[dir].push_back(is);
+	}
+	if (bwa_verbose >= 3)
+		fprintf(stderr, "[M::%s] # candidate unique pairs for (FF, FR, RF, RR): (%ld, %ld, %ld, %ld)\n", "mem_pestat",
+		        (long)isize[0].size(), (long)isize[1].size(), (long)isize[2].size(), (long)isize[3].size());
+	for (int d = 0; d < 4; ++d) {
+		mem_pestat_t *r = &pes[d];
+		std::vector<uint64_t> &q = isize[d];
+		if (q.size() < 10) {
+			fprintf(stderr, "[M::%s] skip orientation %c%c as there are not enough pairs\n", "mem_pestat", "FR"[d >> 1 & 1], "FR"[d & 1]);
+			r->failed = 1;
+			continue;
+		} else fprintf(stderr, "[M::%s] analyzing insert size distribution for orientation %c%c...\n", "mem_pestat", "FR"[d >> 1 & 1], "FR"[d & 1]);
+		ks_introsort(q.size(), q.data(), [](uint64_t a, uint64_t b) { return a < b; });
+		int p25 = (int)q[(int)(.25 * q.size() + .499)];
+		int p50 = (int)q[(int)(.50 * q.size() + .499)];
+		int p75 = (int)q[(int)(.75 * q.size() + .499)];
+		r->low = (int)(p25 - 2.0 * (p75 - p25) + .499);
+		if (r->low < 1) r->low = 1;
+		r->high = (int)(p75 + 2.0 * (p75 - p25) + .499);
+		fprintf(stderr, "[M::%s] (25, 50, 75) percentile: (%d, %d, %d)\n", "mem_pestat", p25, p50, p75);
+		fprintf(stderr, "[M::%s] low and high boundaries for computing mean and std.dev: (%d, %d)\n", "mem_pestat", r->low, r->high);
+		size_t x = 0;
+		r->avg = 0;
+		for (uint64_t v : q)
+			if (v >= (uint64_t)r->low && v <= (uint64_t)r->high) { r->avg += v; ++x; }
+		r->avg /= x;
+		r->std = 0;
+		for (uint64_t v : q)
+			if (v >= (uint64_t)r->low && v <= (uint64_t)r->high) r->std += (v - r->avg) * (v - r->avg);
+		r->std = sqrt(r->std / x);
+		fprintf(stderr, "[M::%s] mean and std.dev: (%.2f, %.2f)\n", "mem_pestat", r->avg, r->std);
+		r->low = (int)(p25 - 3.0 * (p75 - p25) + .499);
+		r->high = (int)(p75 + 3.0 * (p75 - p25) + .499);
+		if (r->low > r->avg - 4.0 * r->std) r->low = (int)(r->avg - 4.0 * r->std + .499);
+		if (r->high < r->avg + 4.0 * r->std) r->high = (int)(r->avg + 4.0 * r->std + .499);
+		if (r->low < 1) r->low = 1;
+		fprintf(stderr, "[M::%s] low and high boundaries for proper pairs: (%d, %d)\n", "mem_pestat", r->low, r->high);
+	}
+	size_t max = 0;
+	for (int d = 0; d < 4; ++d) max = max > isize[d].size() ? max : isize[d].size();
+	for (int d = 0; d < 4; ++d)
+		if (pes[d].failed == 0 && isize[d].size() < max * 0.05) {
+			pes[d].failed = 1;
+			fprintf(stderr, "[M::%s] skip orientation %c%c\n", "mem_pestat", "FR"[d >> 1 & 1], "FR"[d & 1]);
+		}
+}
+
+static int matesw(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, const mem_pestat_t pes[4], const HReg *a, int l_ms,
+                  const uint8_t *ms, HRegV &ma)
+{
+	int64_t l_pac = bns->l_pac;
+	int skip[4], n = 0, rid = -1;
+	for (int r = 0; r < 4; ++r) skip[r] = pes[r].failed ? 1 : 0;
+	for (size_t i = 0; i < ma.size(); ++i) {   // orientations already explained by an existing mate hit
+		int64_t dist;
+		int r = infer_dir(l_pac, a->rb, ma[i].rb, &dist);
+		if (dist >= pes[r].low && dist <= pes[r].high) skip[r] = 1;
+	}
+	if (skip[0] + skip[1] + skip[2] + skip[3] == 4) return 0;
+	for (int r = 0; r < 4; ++r) {
+		if (skip[r]) continue;
+		int is_rev = (r >> 1 != (r & 1));   // mate must be reverse-complemented
+		int is_larger = !(r >> 1);          // mate lies at the larger coordinate
+		std::vector<uint8_t> seq(ms, ms + l_ms), ref;
+		if (is_rev)
+			for (int i = 0; i < l_ms; ++i) seq[l_ms - 1 - i] = ms[i] < 4 ? 3 - ms[i] : 4;
+		int64_t rb, re;
+		if (!is_rev) {
+			rb = is_larger ? a->rb + pes[r].low : a->rb - pes[r].high;
+			re = (is_larger ? a->rb + pes[r].high : a->rb - pes[r].low) + l_ms;
+		} else {
+			rb = (is_larger ? a->rb + pes[r].low : a->rb - pes[r].high) - l_ms;
+			re = is_larger ? a->rb + pes[r].high : a->rb - pes[r].low;
+		}
+		if (rb < 0) rb = 0;
+		if (re > l_pac << 1) re = l_pac << 1;
+		if (rb < re) ref = bns_fetch_seq(bns, pac, &rb, (rb + re) >> 1, &re, &rid);
+		if (a->rid == rid && re - rb >= opt->min_seed_len) {
+			int xtra = KSW_XSUBO | KSW_XSTART | (l_ms * opt->a < 250 ? KSW_XBYTE : 0) | (opt->min_seed_len * opt->a);
+			KswResult aln = ksw_align2(l_ms, seq.data(), (int)(re - rb), ref.data(), opt->mat, opt->o_del, opt->e_del, opt->o_ins,
+			                           opt->e_ins, xtra);
+			if (aln.score >= opt->min_seed_len && aln.qb >= 0) {
+				HReg b;
+				b.rid = a->rid;
+				b.is_alt = a->is_alt;
+				b.qb = is_rev ? l_ms - (aln.qe + 1) : aln.qb;
+				b.qe = is_rev ? l_ms - aln.qb : aln.qe + 1;
+				b.rb = is_rev ? (l_pac << 1) - (rb + aln.te + 1) : rb + aln.tb;
+				b.re = is_rev ? (l_pac << 1) - (rb + aln.tb) : rb + aln.te + 1;
+				b.score = aln.score;
+				b.csub = aln.score2;
+				b.secondary = -1;
+				b.seedcov = (int)((b.re - b.rb < b.qe - b.qb ? b.re - b.rb : b.qe - b.qb) >> 1);
+				// keep `ma` ordered by score: insert before the first strictly lower score
+				size_t at = 0;
+				while (at < ma.size() && !(ma[at].score < b.score)) ++at;
+				ma.insert(ma.begin() + at, b);
+			}
+			++n;
+		}
+		if (n) sort_dedup_patch(opt, 0, 0, 0, ma);
+	}
+	return n;
+}
+
+struct Pair64 { uint64_t x, y; };
+static inline bool pair_lt(const Pair64 &a, const Pair64 &b) { return a.x < b.x || (a.x == b.x && a.y < b.y); }
+
+static int pair_hits(const mem_opt_t *opt, const bntseq_t *bns, const mem_pestat_t pes[4], HRegV a[2], int id, int *sub, int *n_sub,
+                     int z[2], int n_pri[2])
+{
+	std::vector<Pair64> v, u;
+	int y[4], ret;
+	int64_t l_pac = bns->l_pac;
+	for (int r = 0; r < 2; ++r)
+		for (int i = 0; i < n_pri[r]; ++i) {
+			const HReg *e = &a[r][i];
+			Pair64 key;
+			key.x = e->rb < l_pac ? e->rb : (l_pac << 1) - 1 - e->rb;   // forward-strand position
+			key.x = (uint64_t)e->rid << 32 | (key.x - bns->anns[e->rid].offset);
+			key.y = (uint64_t)e->score << 32 | i << 2 | (e->rb >= l_pac) << 1 | r;
+			v.push_back(key);
+		}
+	ks_introsort(v.size(), v.data(), pair_lt);
+	y[0] = y[1] = y[2] = y[3] = -1;
+	for (size_t i = 0; i < v.size(); ++i) {
+		for (int r = 0; r < 2; ++r) {
+			int dir = r << 1 | (v[i].y >> 1 & 1), which;
+			if (pes[dir].failed) continue;
+			which = r << 1 | ((v[i].y & 1) ^ 1);
+			if (y[which] < 0) continue;
+			for (int k = y[which]; k >= 0; --k) {
+				if ((int)(v[k].y & 3) != which) continue;
+				int64_t dist = (int64_t)v[i].x - v[k].x;
+				if (dist > pes[dir].high) break;
+				if (dist < pes[dir].low) continue;
+				double ns = (dist - pes[dir].avg) / pes[dir].std;
+				int q = (int)((v[i].y >> 32) + (v[k].y >> 32) + .721 * log(2. * erfc(fabs(ns) * M_SQRT1_2)) * opt->a + .499);
+				if (q < 0) q = 0;
+				Pair64 p;
+				p.y = (uint64_t)k << 32 | i;
+				p.x = (uint64_t)q << 32 | (hash_64(p.y ^ id << 8) & 0xffffffffU);
+				u.push_back(p);
+			}
+		}
+		y[v[i].y & 3] = (int)i;
+	}
+	if (!u.empty()) {
+		int tmp = opt->a + opt->b;
+		tmp = tmp > opt->o_del + opt->e_del ? tmp : opt->o_del + opt->e_del;
+		tmp = tmp > opt->o_ins + opt->e_ins ? tmp : opt->o_ins + opt->e_ins;
+		ks_introsort(u.size(), u.data(), pair_lt);
+		int i = (int)(u.back().y >> 32), k = (int)(u.back().y << 32 >> 32);
+		z[v[i].y & 1] = (int)(v[i].y << 32 >> 34);
+		z[v[k].y & 1] = (int)(v[k].y << 32 >> 34);
+		ret = (int)(u.back().x >> 32);
+		*sub = u.size() > 1 ? (int)(u[u.size() - 2].x >> 32) : 0;
+		*n_sub = 0;
+		for (long j = (long)u.size() - 2; j >= 0; --j)
+			if (*sub - (int)(u[j].x >> 32) <= tmp) ++*n_sub;
+	} else { ret = 0; *sub = 0; *n_sub = 0; }
+	return ret;
+}
+
+#define RAW_MAPQ(diff, a) ((int)(6.02 * (diff) / (a) + .499))
+
+int sam_pe(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, const mem_pestat_t pes[4], uint64_t id, bseq1_t s[2], HRegV a[2])
+{
+	int n = 0, z[2] = {0, 0}, o, subo = 0, n_sub = 0, extra_flag = 1, n_pri[2];
+	HAln h[2];
+	bool paired_path = false;
+
+	if (!(opt->flag & MEM_F_NO_RESCUE)) {   // mate rescue from the best hits of each end
+		HRegV b[2];
+		for (int i = 0; i < 2; ++i)
+			for (size_t j = 0; j < a[i].size(); ++j)
+				if (a[i][j].score >= a[i][0].score - opt->pen_unpaired) b[i].push_back(a[i][j]);
+		for (int i = 0; i < 2; ++i)
+			for (size_t j = 0; j < b[i].size() && (int)j < opt->max_matesw; ++j)
+				n += matesw(opt, bns, pac, pes, &b[i][j], s[!i].l_seq, (uint8_t *)s[!i].seq, a[!i]);
+	}
+	n_pri[0] = mark_primary_se(opt, a[0], id << 1 | 0);
+	n_pri[1] = mark_primary_se(opt, a[1], id << 1 | 1);
+	if (opt->flag & MEM_F_PRIMARY5) {
+		reorder_primary5(opt->T, a[0]);
+		reorder_primary5(opt->T, a[1]);
+	}
+	if (!(opt->flag & MEM_F_NOPAIRING) && n_pri[0] && n_pri[1] &&
+	    (o = pair_hits(opt, bns, pes, a, (int)id, &subo, &n_sub, z, n_pri)) > 0) {
+		int is_multi[2], q_pe, score_un, q_se[2];
+		for (int i = 0; i < 2; ++i) {   // an end with several good primary hits is left to the single-end logic
+			int j;
+			for (j = 1; j < n_pri[i]; ++j)
+				if (a[i][j].secondary < 0 && a[i][j].score >= opt->T) break;
+			is_multi[i] = j < n_pri[i] ? 1 : 0;
+		}
+		if (!is_multi[0] && !is_multi[1]) {
+			paired_path = true;
+			score_un = a[0][0].score + a[1][0].score - opt->pen_unpaired;
+			subo = subo > score_un ? subo : score_un;
+			q_pe = RAW_MAPQ(o - subo, opt->a);
+			if (n_sub > 0) q_pe -= (int)(4.343 * log(n_sub + 1) + .499);
+			if (q_pe < 0) q_pe = 0;
+			if (q_pe > 60) q_pe = 60;
+			q_pe = (int)(q_pe * (1. - .5 * (a[0][0].frac_rep + a[1][0].frac_rep)) + .499);
+			if (o > score_un) {   // the pair beats the two best single-end hits
+				HReg *c[2] = {&a[0][z[0]], &a[1][z[1]]};
+				for (int i = 0; i < 2; ++i) {
+					if (c[i]->secondary >= 0) { c[i]->sub = a[i][c[i]->secondary].score; c[i]->secondary = -2; }
+					q_se[i] = approx_mapq_se(opt, c[i]);
+				}
+				q_se[0] = q_se[0] > q_pe ? q_se[0] : q_pe < q_se[0] + 40 ? q_pe : q_se[0] + 40;
+				q_se[1] = q_se[1] > q_pe ? q_se[1] : q_pe < q_se[1] + 40 ? q_pe : q_se[1] + 40;
+				extra_flag |= 2;
+				// cap by the tandem-repeat score
+				q_se[0] = q_se[0] < RAW_MAPQ(c[0]->score - c[0]->csub, opt->a) ? q_se[0] : RAW_MAPQ(c[0]->score - c[0]->csub, opt->a);
+				q_se[1] = q_se[1] < RAW_MAPQ(c[1]->score - c[1]->csub, opt->a) ? q_se[1] : RAW_MAPQ(c[1]->score - c[1]->csub, opt->a);
+			} else {
+				z[0] = z[1] = 0;
+				q_se[0] = approx_mapq_se(opt, &a[0][0]);
+				q_se[1] = approx_mapq_se(opt, &a[1][0]);
+			}
+			for (int i = 0; i < 2; ++i) {
+				int k = a[i][z[i]].secondary_all;
+				if (k >= 0 && k < n_pri[i]) {   // the chosen hit was secondary: swap roles with its parent
+					for (size_t j = 0; j < a[i].size(); ++j)
+						if (a[i][j].secondary_all == k || (int)j == k) a[i][j].secondary_all = z[i];
+					a[i][z[i]].secondary_all = -1;
+				}
+			}
+			std::vector<std::string> xa[2];
+			std::vector<char> has[2];
+			bool have_xa[2] = {false, false};
+			if (!(opt->flag & MEM_F_ALL))
+				for (int i = 0; i < 2; ++i) have_xa[i] = gen_alt(opt, bns, pac, a[i], s[i].l_seq, s[i].seq, xa[i], has[i]);
+			std::vector<HAln> aa[2];
+			HAln g[2];
+			for (int i = 0; i < 2; ++i) {
+				h[i] = reg2aln(opt, bns, pac, s[i].l_seq, s[i].seq, &a[i][z[i]]);
+				h[i].mapq = q_se[i] & 0xff;
+				h[i].flag |= 0x40 << i | extra_flag;
+				if (have_xa[i] && has[i][z[i]]) { h[i].has_xa = true; h[i].xa = xa[i][z[i]]; }
+				aa[i].push_back(h[i]);
+				if (n_pri[i] < (int)a[i].size()) {   // the read also has ALT hits
+					HReg *p = &a[i][n_pri[i]];
+					if (p->score < opt->T || p->secondary >= 0 || !p->is_alt) continue;
+					g[i] = reg2aln(opt, bns, pac, s[i].l_seq, s[i].seq, p);
+					g[i].flag |= 0x800 | 0x40 << i | extra_flag;
+					if (have_xa[i] && has[i][n_pri[i]]) { g[i].has_xa = true; g[i].xa = xa[i][n_pri[i]]; }
+					aa[i].push_back(g[i]);
+				}
+			}
+			std::string str;
+			for (size_t i = 0; i < aa[0].size(); ++i) aln2sam_pub(opt, bns, str, &s[0], (int)aa[0].size(), aa[0].data(), (int)i, &h[1]);
+			s[0].sam = sam_to_c(str);
+			str.clear();
+			for (size_t i = 0; i < aa[1].size(); ++i) aln2sam_pub(opt, bns, str, &s[1], (int)aa[1].size(), aa[1].data(), (int)i, &h[0]);
+			s[1].sam = sam_to_c(str);
+			if (strcmp(s[0].name, s[1].name) != 0) die("paired reads have different names: \"%s\", \"%s\"", s[0].name, s[1].name);
+		}
+	}
+	if (paired_path) return n;
+
+	// no usable pair: report the ends independently
+	for (int i = 0; i < 2; ++i) {
+		int which = -1;
+		if (!a[i].empty()) {
+			if (a[i][0].score >= opt->T) which = 0;
+			else if (n_pri[i] < (int)a[i].size() && a[i][n_pri[i]].score >= opt->T) which = n_pri[i];
+		}
+		h[i] = reg2aln(opt, bns, pac, s[i].l_seq, s[i].seq, which >= 0 ? &a[i][which] : 0);
+	}
+	if (!(opt->flag & MEM_F_NOPAIRING) && h[0].rid == h[1].rid && h[0].rid >= 0) {   // still flag a proper pair if the top hits form one
+		int64_t dist;
+		int d = infer_dir(bns->l_pac, a[0][0].rb, a[1][0].rb, &dist);
+		if (!pes[d].failed && dist >= pes[d].low && dist <= pes[d].high) extra_flag |= 2;
+	}
+	reg2sam(opt, bns, pac, &s[0], a[0], 0x41 | extra_flag, &h[1]);
+	reg2sam(opt, bns, pac, &s[1], a[1], 0x81 | extra_flag, &h[0]);
+	if (strcmp(s[0].name, s[1].name) != 0) die("paired reads have different names: \"%s\", \"%s\"", s[0].name, s[1].name);
+	return n;
+}
+
+} // namespace mbw

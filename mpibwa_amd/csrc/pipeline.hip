@@ -1,0 +1,358 @@
+// pipeline.hip — mem_process_seqs(): the drop-in batch driver (replaces src/bwamem.c:1161-1234).
+//
+// The reference runs worker1 (seed -> chain -> extend, per read) and worker2
+// (pairing -> SAM, per pair) over pthreads with a batch-wide mem_pestat
+// barrier in between.  Here the batch is processed stage by stage:
+//
+//   host   nt4-encode, pack reads                              (bwamem.c:1057-1058)
+//   GPU    SMEM seeding                 smem_kernel            (bwamem.c:114-162)
+//   GPU    interval sort / seed enumeration                    (bwamem.c:161, 265-283)
+//   GPU    suffix-array lookup          sa_kernel              (bwt.c:86-96)
+//   host   chaining + chain filters     (ordered-map logic)    (bwamem.c:251-385, 598-617)
+//   GPU    chain -> regions, banded DP  c2a_kernel             (bwamem.c:632-786, ksw.c:380-479)
+//   host   dedup / patch, pestat, mate rescue, pairing, CIGAR, SAM text
+//
+// There is no CPU fallback for the GPU stages: without a gfx950 device the call aborts.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+#include <sys/resource.h>
+#include <sys/time.h>
+
+#include "device.h"
+#include "host.h"
+
+namespace mbw {
+
+#define HIP_OK(call)                                                                                             \
+	do {                                                                                                         \
+		hipError_t e_ = (call);                                                                                  \
+		if (e_ != hipSuccess) die("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);    \
+	} while (0)
+
+static mi355x_stats_t g_stats;
+
+static int host_threads(const mem_opt_t *opt)
+{
+	if (const char *e = getenv("MPIBWA_HOST_THREADS")) { int v = atoi(e); if (v > 0) return v; }
+	int hw = (int)std::thread::hardware_concurrency();
+	int t = std::max(opt->n_threads, hw > 0 ? hw : 1);
+	return std::min(t, 64);
+}
+
+template <class F>
+static void parallel_for(int n_threads, int n, int chunk, F f)
+{
+	if (n <= 0) return;
+	if (n_threads <= 1 || n <= chunk) { for (int i = 0; i < n; ++i) f(i); return; }
+	std::atomic<int> next(0);
+	auto work = [&]() {
+		for (;;) {
+			int b = next.fetch_add(chunk);
+			if (b >= n) break;
+			int e = std::min(n, b + chunk);
+			for (int i = b; i < e; ++i) f(i);
+		}
+	};
+	std::vector<std::thread> th;
+	for (int t = 1; t < n_threads; ++t) th.emplace_back(work);
+	work();
+	for (auto &t : th) t.join();
+}
+
+static double now_ms()
+{
+	return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static double cpu_sec()
+{
+	struct rusage r;
+	getrusage(RUSAGE_SELF, &r);
+	return r.ru_utime.tv_sec + r.ru_stime.tv_sec + 1e-6 * (r.ru_utime.tv_usec + r.ru_stime.tv_usec);
+}
+
+struct EvTimer {
+	hipEvent_t a, b;
+	EvTimer() { HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); }
+	~EvTimer() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
+	void start(hipStream_t s) { HIP_OK(hipEventRecord(a, s)); }
+	void stop(hipStream_t s) { HIP_OK(hipEventRecord(b, s)); }
+	double ms() { HIP_OK(hipEventSynchronize(b)); float m = 0; HIP_OK(hipEventElapsedTime(&m, a, b)); return m; }
+};
+
+// device work buffers, grown on demand and kept across calls
+struct Workspace {
+	DevBuf seq, off, intv, nintv, cnt, scratch, nseeds, lrep, seed_off, rows, qbl, sa;
+	DevBuf chain_off, chains, seeds, srt, reg_off, regs, nregs, tab;
+	const void *host_bwt = nullptr;
+};
+static Workspace g_ws;
+
+} // namespace mbw
+
+using namespace mbw;
+
+extern "C" void mi355x_last_stats(mi355x_stats_t *st) { *st = g_stats; }
+
+extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const bntseq_t *bns, const uint8_t *pac,
+                                 int64_t n_processed, int n, bseq1_t *seqs, const mem_pestat_t *pes0)
+{
+	const double t_begin = now_ms(), c_begin = cpu_sec();
+	DevIndex &ix = dev_index();
+	if (!ix.ready || g_ws.host_bwt != (const void *)bwt->bwt) {
+		// first call with this index: make it resident (one rank per GPU; LOCAL_RANK as set by torchrun / mpirun wrappers)
+		int lr = 0;
+		if (const char *e = getenv("LOCAL_RANK")) lr = atoi(e);
+		else if (const char *e2 = getenv("OMPI_COMM_WORLD_LOCAL_RANK")) lr = atoi(e2);
+		else if (const char *e3 = getenv("MV2_COMM_WORLD_LOCAL_RANK")) lr = atoi(e3);
+		if (!ix.ready) mi355x_index_upload(lr, bwt, bns, pac);
+		g_ws.host_bwt = (const void *)bwt->bwt;
+	}
+	HIP_OK(hipSetDevice(ix.device));
+	memset(&g_stats, 0, sizeof g_stats);
+	if (n <= 0) return;
+	const int n_thr = host_threads(opt);
+	const bool pe = (opt->flag & MEM_F_PE) != 0;
+	hipStream_t st = 0;
+	Workspace &W = g_ws;
+	EvTimer ev_smem, ev_sa, ev_ext;
+
+	// ---- 1. encode + pack ----
+	std::vector<int64_t> off(n + 1);
+	off[0] = 0;
+	int max_len = 0;
+	for (int i = 0; i < n; ++i) { off[i + 1] = off[i] + seqs[i].l_seq; max_len = std::max(max_len, seqs[i].l_seq); }
+	std::vector<uint8_t> flat(off[n] + 16);
+	parallel_for(n_thr, n, 4096, [&](int i) {
+		char *s = seqs[i].seq;
+		uint8_t *d = flat.data() + off[i];
+		for (int k = 0; k < seqs[i].l_seq; ++k) {
+			s[k] = s[k] < 4 ? s[k] : (char)nt4_table[(uint8_t)s[k]];
+			d[k] = (uint8_t)s[k];
+		}
+	});
+	if ((size_t)max_len + 2 > 9000) die("read of %d bp exceeds the on-chip band buffers of this build (max 8998 bp)", max_len);
+	double t1 = now_ms();
+	uint8_t *d_seq = (uint8_t *)W.seq.ensure(flat.size());
+	int64_t *d_off = (int64_t *)W.off.ensure((size_t)(n + 1) * 8);
+	HIP_OK(hipMemcpyAsync(d_seq, flat.data(), flat.size(), hipMemcpyHostToDevice, st));
+	HIP_OK(hipMemcpyAsync(d_off, off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+	unsigned long long *d_cnt = (unsigned long long *)W.cnt.ensure(256);
+
+	// ---- 2. SMEM seeding (retry with a larger per-read capacity in the rare overflow case) ----
+	int cap = std::max(64, std::min(max_len, 96));
+	uint64_t *d_intv; int *d_nintv;
+	unsigned long long cnt[8];
+	size_t per_quad = 0;
+	int n_quads = smem_grid_quads(max_len, &per_quad);
+	void *d_scr = W.scratch.ensure(per_quad * n_quads);
+	for (;;) {
+		d_intv = (uint64_t *)W.intv.ensure((size_t)n * cap * 32);
+		d_nintv = (int *)W.nintv.ensure((size_t)n * 4);
+		HIP_OK(hipMemsetAsync(d_cnt, 0, 256, st));
+		ev_smem.start(st);
+		launch_smem(st, ix.fm, smem_params(opt), n, d_seq, d_off, cap, d_intv, d_nintv, max_len, d_cnt, d_scr, per_quad, n_quads);
+		ev_smem.stop(st);
+		HIP_OK(hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, st));
+		HIP_OK(hipStreamSynchronize(st));
+		HIP_OK(hipGetLastError());
+		g_stats.k_smem_ms += ev_smem.ms();
+		if (cnt[2] == 0) break;
+		cap *= 4;
+	}
+	g_stats.smem_bytes = cnt[1] * 64 + (uint64_t)off[n];
+	double t2 = now_ms();
+
+	// ---- 3. seed enumeration + SA lookup ----
+	int *d_nseeds = (int *)W.nseeds.ensure((size_t)n * 4), *d_lrep = (int *)W.lrep.ensure((size_t)n * 4);
+	launch_seed_prep(st, n, cap, d_intv, d_nintv, opt->max_occ, d_nseeds, d_lrep);
+	std::vector<int> nseeds(n), lrep(n), nintv(n);
+	HIP_OK(hipMemcpyAsync(nseeds.data(), d_nseeds, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+	HIP_OK(hipMemcpyAsync(lrep.data(), d_lrep, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+	HIP_OK(hipMemcpyAsync(nintv.data(), d_nintv, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+	HIP_OK(hipStreamSynchronize(st));
+	std::vector<int64_t> seed_off(n + 1);
+	seed_off[0] = 0;
+	uint64_t n_intv = 0;
+	for (int i = 0; i < n; ++i) { seed_off[i + 1] = seed_off[i] + nseeds[i]; n_intv += nintv[i]; }
+	const int64_t S = seed_off[n];
+	g_stats.smem_bytes += n_intv * 32;
+	g_stats.n_intv = n_intv; g_stats.n_seeds = S;
+	std::vector<uint64_t> sa(S);
+	std::vector<int32_t> qbl(2 * S);
+	if (S > 0) {
+		int64_t *d_seed_off = (int64_t *)W.seed_off.ensure((size_t)(n + 1) * 8);
+		uint64_t *d_rows = (uint64_t *)W.rows.ensure((size_t)S * 8), *d_sa = (uint64_t *)W.sa.ensure((size_t)S * 8);
+		int32_t *d_qbl = (int32_t *)W.qbl.ensure((size_t)S * 8);
+		HIP_OK(hipMemcpyAsync(d_seed_off, seed_off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+		launch_seed_enum(st, n, cap, d_intv, d_nintv, opt->max_occ, d_seed_off, d_rows, d_qbl);
+		if (S > 0x7fffffff) die("too many seeds in one batch");
+		HIP_OK(hipMemsetAsync(d_cnt, 0, 256, st));
+		ev_sa.start(st);
+		launch_sa(st, ix.fm, (int)S, d_rows, d_sa, d_cnt);
+		ev_sa.stop(st);
+		HIP_OK(hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, st));
+		HIP_OK(hipMemcpyAsync(sa.data(), d_sa, (size_t)S * 8, hipMemcpyDeviceToHost, st));
+		HIP_OK(hipMemcpyAsync(qbl.data(), d_qbl, (size_t)S * 8, hipMemcpyDeviceToHost, st));
+		HIP_OK(hipStreamSynchronize(st));
+		HIP_OK(hipGetLastError());
+		g_stats.k_sa_ms = ev_sa.ms();
+		g_stats.sa_bytes = cnt[1] * 64 + (uint64_t)S * 8;
+	}
+	double t3 = now_ms();
+
+	// ---- 4. chaining and chain filters (host) ----
+	std::vector<std::vector<HChain>> chains(n);
+	parallel_for(n_thr, n, 256, [&](int i) {
+		int ns = nseeds[i];
+		if (ns == 0) return;
+		std::vector<HSeed> hs(ns);
+		for (int k = 0; k < ns; ++k) {
+			int64_t o = seed_off[i] + k;
+			hs[k].rbeg = (int64_t)sa[o]; hs[k].qbeg = qbl[2 * o]; hs[k].len = hs[k].score = qbl[2 * o + 1];
+		}
+		chains_from_seeds(opt, bns, seqs[i].l_seq, hs.data(), ns, lrep[i], chains[i]);
+		chain_filter(opt, chains[i]);
+		filter_chained_seeds(opt, bns, pac, seqs[i].l_seq, (const uint8_t *)seqs[i].seq, chains[i]);
+	});
+	std::vector<int> chain_off(n + 1), reg_off(n + 1);
+	chain_off[0] = reg_off[0] = 0;
+	for (int i = 0; i < n; ++i) {
+		int ns = 0;
+		for (auto &c : chains[i]) ns += (int)c.seeds.size();
+		chain_off[i + 1] = chain_off[i] + (int)chains[i].size();
+		reg_off[i + 1] = reg_off[i] + ns;
+	}
+	const int NC = chain_off[n], NS = reg_off[n];
+	g_stats.n_chains = NC;
+	std::vector<DevChain> hchains(NC);
+	std::vector<DevSeed> hseeds(NS);
+	std::vector<unsigned int> hsrt(NS);
+	parallel_for(n_thr, n, 512, [&](int i) {
+		int so = reg_off[i];
+		for (size_t c = 0; c < chains[i].size(); ++c) {
+			const HChain &ch = chains[i][c];
+			DevChain &d = hchains[chain_off[i] + c];
+			int ns = (int)ch.seeds.size();
+			d.seed_beg = so; d.n_seeds = ns; d.rid = ch.rid; d.frac_rep = ch.frac_rep;
+			d.far_beg = d.far_end = 0;
+			if (ns) {
+				int is_rev;
+				bns_depos(bns, ch.seeds[0].rbeg, &is_rev);
+				int64_t fb = bns->anns[ch.rid].offset, fe = fb + bns->anns[ch.rid].len;
+				if (is_rev) { int64_t t = fb; fb = (bns->l_pac << 1) - fe; fe = (bns->l_pac << 1) - t; }
+				d.far_beg = fb; d.far_end = fe;
+			}
+			// seeds are visited by decreasing score, ties by decreasing index (src/bwamem.c:662-667)
+			std::vector<uint64_t> key(ns);
+			for (int k = 0; k < ns; ++k) {
+				hseeds[so + k].rbeg = ch.seeds[k].rbeg; hseeds[so + k].qbeg = ch.seeds[k].qbeg; hseeds[so + k].len = ch.seeds[k].len;
+				key[k] = (uint64_t)ch.seeds[k].score << 32 | (uint32_t)k;
+			}
+			std::sort(key.begin(), key.end());   // keys are distinct, any sort gives the reference's order
+			for (int k = 0; k < ns; ++k) hsrt[so + k] = (uint32_t)key[k];
+			so += ns;
+		}
+	});
+	double t4 = now_ms();
+
+	// ---- 5. chain -> regions on the GPU ----
+	std::vector<DevReg> hregs(NS);
+	std::vector<int> nregs(n, 0);
+	if (NS > 0) {
+		const int TS = max_len + 2;
+		std::vector<int> tab(5 * TS);
+		for (int l = 0; l < TS; ++l) {
+			tab[l] = cal_max_gap(opt, l);
+			tab[TS + l] = clamp_band(opt, l, 1 << 28, opt->pen_clip5);
+			tab[2 * TS + l] = clamp_band(opt, l, 1 << 28, opt->pen_clip3);
+			tab[3 * TS + l] = (int)ceil(l * .95);
+			tab[4 * TS + l] = (int)floor(.1 * l);
+		}
+		int *d_tab = (int *)W.tab.ensure(tab.size() * 4);
+		int *d_chain_off = (int *)W.chain_off.ensure((size_t)(n + 1) * 4), *d_reg_off = (int *)W.reg_off.ensure((size_t)(n + 1) * 4);
+		DevChain *d_chains = (DevChain *)W.chains.ensure((size_t)std::max(NC, 1) * sizeof(DevChain));
+		DevSeed *d_seeds = (DevSeed *)W.seeds.ensure((size_t)NS * sizeof(DevSeed));
+		unsigned int *d_srt = (unsigned int *)W.srt.ensure((size_t)NS * 4);
+		DevReg *d_regs = (DevReg *)W.regs.ensure((size_t)NS * sizeof(DevReg));
+		int *d_nregs = (int *)W.nregs.ensure((size_t)n * 4);
+		HIP_OK(hipMemcpyAsync(d_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, st));
+		HIP_OK(hipMemcpyAsync(d_chain_off, chain_off.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, st));
+		HIP_OK(hipMemcpyAsync(d_reg_off, reg_off.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, st));
+		HIP_OK(hipMemcpyAsync(d_chains, hchains.data(), (size_t)NC * sizeof(DevChain), hipMemcpyHostToDevice, st));
+		HIP_OK(hipMemcpyAsync(d_seeds, hseeds.data(), (size_t)NS * sizeof(DevSeed), hipMemcpyHostToDevice, st));
+		HIP_OK(hipMemcpyAsync(d_srt, hsrt.data(), (size_t)NS * 4, hipMemcpyHostToDevice, st));
+		HIP_OK(hipMemsetAsync(d_cnt, 0, 256, st));
+		C2aParams cp;
+		cp.l_pac = bns->l_pac; cp.a = opt->a; cp.w = opt->w; cp.pen_clip5 = opt->pen_clip5; cp.pen_clip3 = opt->pen_clip3;
+		ExtParams ep;
+		memcpy(ep.mat, opt->mat, 25);
+		ep.o_del = opt->o_del; ep.e_del = opt->e_del; ep.o_ins = opt->o_ins; ep.e_ins = opt->e_ins; ep.zdrop = opt->zdrop;
+		ev_ext.start(st);
+		launch_c2a(st, cp, ep, n, d_seq, d_off, d_chain_off, d_chains, d_seeds, d_srt, d_reg_off, d_regs, d_nregs, d_tab, TS,
+		           (const uint8_t *)ix.d_pac, d_cnt, max_len);
+		ev_ext.stop(st);
+		HIP_OK(hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, st));
+		HIP_OK(hipMemcpyAsync(hregs.data(), d_regs, (size_t)NS * sizeof(DevReg), hipMemcpyDeviceToHost, st));
+		HIP_OK(hipMemcpyAsync(nregs.data(), d_nregs, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+		HIP_OK(hipStreamSynchronize(st));
+		HIP_OK(hipGetLastError());
+		g_stats.k_ext_ms = ev_ext.ms();
+		g_stats.ext_cells = cnt[0]; g_stats.n_ext = cnt[1];
+	}
+	double t5 = now_ms();
+
+	// ---- 6. region post-processing (host) ----
+	std::vector<HRegV> regs(n);
+	parallel_for(n_thr, n, 256, [&](int i) {
+		HRegV &v = regs[i];
+		int m = nregs[i];
+		v.resize(m);
+		for (int k = 0; k < m; ++k) {
+			const DevReg &d = hregs[reg_off[i] + k];
+			HReg &r = v[k];
+			r.rb = d.rb; r.re = d.re; r.qb = d.qb; r.qe = d.qe; r.rid = d.rid; r.score = d.score; r.truesc = d.truesc;
+			r.w = d.w; r.seedcov = d.seedcov; r.seedlen0 = d.seedlen0; r.frac_rep = d.frac_rep;
+		}
+		sort_dedup_patch(opt, bns, pac, (uint8_t *)seqs[i].seq, v);
+		for (HReg &r : v)
+			if (r.rid >= 0 && bns->anns[r.rid].is_alt) r.is_alt = 1;
+	});
+	double t6 = now_ms();
+
+	// ---- 7. insert-size statistics over the whole batch ----
+	mem_pestat_t pes[4];
+	if (pe) {
+		if (pes0) memcpy(pes, pes0, 4 * sizeof(mem_pestat_t));
+		else pestat(opt, bns->l_pac, n, regs.data(), pes);
+	}
+	double t7 = now_ms();
+
+	// ---- 8. pairing / SAM ----
+	if (pe) {
+		parallel_for(n_thr, n >> 1, 128, [&](int i) {
+			sam_pe(opt, bns, pac, pes, (uint64_t)((n_processed >> 1) + i), &seqs[i << 1], &regs[i << 1]);
+		});
+	} else {
+		parallel_for(n_thr, n, 256, [&](int i) {
+			mark_primary_se(opt, regs[i], n_processed + i);
+			if (opt->flag & MEM_F_PRIMARY5) reorder_primary5(opt->T, regs[i]);
+			reg2sam(opt, bns, pac, &seqs[i], regs[i], 0, 0);
+		});
+	}
+	double t8 = now_ms();
+	g_stats.n_reads = n;
+	g_stats.h2d_ms = t1 - t_begin;
+	g_stats.smem_ms = t2 - t1; g_stats.sa_ms = t3 - t2; g_stats.chain_ms = t4 - t3; g_stats.ext_ms = t5 - t4;
+	g_stats.regs_ms = t6 - t5; g_stats.pestat_ms = t7 - t6; g_stats.sam_ms = t8 - t7; g_stats.total_ms = t8 - t_begin;
+	if (bwa_verbose >= 3)
+		fprintf(stderr, "[M::%s] Processed %d reads in %.3f CPU sec, %.3f real sec\n", "mem_process_seqs", n, cpu_sec() - c_begin,
+		        (t8 - t_begin) * 1e-3);
+}
