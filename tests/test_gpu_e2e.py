@@ -1,0 +1,150 @@
+"""End-to-end parity of mem_process_seqs() (through the C ABI, on the GPU) with
+ (a) the committed golden SAM produced by the compiled reference, and
+ (b) the compiled reference itself (oracle/_ref/libbwaref.so) on fresh seeded inputs and option variants."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from mpibwa_amd import abi, simulate
+from oracle import pyoracle as po
+from golden_util import golden_index, load_reads, load_sam, sam_cases, kernel_vectors, ragged
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gold_engine(tmp_path_factory, built):
+    from mpibwa_amd import api
+    prefix = golden_index(tmp_path_factory.mktemp("gold"))
+    return api.Engine(prefix, device=0)
+
+
+def test_golden_sam_all_cases(gold_engine):
+    pe, se = load_reads("reads_pe150.tsv.gz"), load_reads("reads_se_var.tsv.gz")
+    for case, kw in sam_cases().items():
+        reads = pe if case.startswith("pe") else se
+        got = b"".join(gold_engine.process(gold_engine.opt(**kw), reads))
+        assert got == load_sam(case), case
+
+
+def test_golden_kernel_vectors_on_gpu(gold_engine):
+    kv = kernel_vectors()
+    opt = gold_engine.opt()
+    reads, outs = ragged(kv, "intv_reads"), ragged(kv, "intv_out")
+    got, _, _ = gold_engine.smem(opt, reads, cap=512)
+    for g, o in zip(got, outs):
+        assert (g.reshape(-1) == o).all()
+    sa, _, _ = gold_engine.sa(kv["sa_k"])
+    assert (sa == kv["sa_v"]).all()
+    qs, ts, p = ragged(kv, "ext_q"), ragged(kv, "ext_t"), kv["ext_p"]
+    # zdrop is a batch-wide option: run one batch per distinct value
+    for zd in np.unique(p[:, 3]):
+        sel = np.nonzero(p[:, 3] == zd)[0]
+        o = gold_engine.opt(zdrop=int(zd))
+        out, _, _ = gold_engine.extend(o, [qs[i] for i in sel], [ts[i] for i in sel], p[sel, 0], p[sel, 1], p[sel, 2])
+        assert (out == kv["ext_o"][sel]).all()
+
+
+needs_ref = pytest.mark.skipif(not po.ref_available(), reason="oracle/_ref/libbwaref.so not present")
+
+
+@pytest.fixture(scope="module")
+def both(genome):
+    from mpibwa_amd import api
+    # the device index is a process-wide singleton: (re)upload this module's genome
+    api.load_library().mi355x_finalize()
+    return api.Engine(genome["prefix"], device=0), po.RefIndex(genome["prefix"])
+
+
+def _cmp(eng, ref, reads, kw, **pk):
+    want = ref.process(ref.opt(**kw), reads, **pk)
+    got = eng.process(eng.opt(**kw), reads, **pk)
+    assert len(got) == len(want)
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert a == b, (i, a[:300], b[:300])
+
+
+@needs_ref
+def test_pe_default_and_chunking(both, reads_pe):
+    eng, ref = both
+    ra = simulate.reads_to_ascii(reads_pe)
+    _cmp(eng, ref, ra, dict(flag=abi.MEM_F_PE))
+    # a different chunking changes mem_pestat and therefore the SAM: both sides must agree chunk by chunk
+    _cmp(eng, ref, ra[:217], dict(flag=abi.MEM_F_PE))
+    _cmp(eng, ref, ra[217:], dict(flag=abi.MEM_F_PE), n_processed=434)
+
+
+@needs_ref
+@pytest.mark.parametrize("kw", [
+    dict(flag=abi.MEM_F_PE | abi.MEM_F_NO_MULTI),
+    dict(flag=abi.MEM_F_PE | abi.MEM_F_SOFTCLIP),
+    dict(flag=abi.MEM_F_PE | abi.MEM_F_ALL),
+    dict(flag=abi.MEM_F_PE | abi.MEM_F_PRIMARY5),
+    dict(flag=abi.MEM_F_PE | abi.MEM_F_NO_RESCUE),
+    dict(flag=abi.MEM_F_PE | abi.MEM_F_NOPAIRING),
+    dict(flag=abi.MEM_F_PE | abi.MEM_F_REF_HDR, T=15, min_seed_len=15),
+    dict(flag=abi.MEM_F_PE, w=20, zdrop=30, max_occ=50, split_width=3),
+    dict(flag=abi.MEM_F_PE, pen_unpaired=5, pen_clip5=0, pen_clip3=9, max_mem_intv=0),
+    dict(flag=abi.MEM_F_PE, o_del=4, e_del=2, o_ins=8, e_ins=1, drop_ratio=0.3, mask_level=0.7),
+])
+def test_pe_option_variants(both, reads_pe, kw):
+    eng, ref = both
+    _cmp(eng, ref, simulate.reads_to_ascii(reads_pe[:250]), kw)
+
+
+@needs_ref
+def test_se_variable_length(both, reads_var):
+    eng, ref = both
+    ra = simulate.reads_to_ascii(reads_var)
+    _cmp(eng, ref, ra, dict(flag=0))
+    _cmp(eng, ref, ra, dict(flag=abi.MEM_F_ALL | abi.MEM_F_SOFTCLIP), n_processed=1000)
+
+
+@needs_ref
+def test_scoring_matrix_and_misc_inputs(both, reads_pe):
+    eng, ref = both
+    ra = simulate.reads_to_ascii(reads_pe[:200])
+
+    def scaled(e, a, b):
+        o = e.opt(flag=abi.MEM_F_PE, a=a, b=b)
+        e.lib.bwa_fill_scmat(a, b, o.contents.mat)
+        return o
+    want = ref.process(scaled(ref, 2, 5), ra)
+    got = eng.process(scaled(eng, 2, 5), ra)
+    assert got == want
+    # no qualities, with a comment column (-C), user-supplied insert size (-I)
+    _cmp(eng, ref, ra, dict(flag=abi.MEM_F_PE), with_qual=False, comment="BC:Z:ACGT")
+    pes = (abi.mem_pestat_t * 4)()
+    for d in range(4):
+        pes[d].failed = 1
+    pes[1].failed = 0
+    pes[1].avg, pes[1].std, pes[1].low, pes[1].high = 400.0, 50.0, 100, 700
+    _cmp(eng, ref, ra, dict(flag=abi.MEM_F_PE), pes0=pes)
+
+
+@needs_ref
+def test_edge_reads(both, genome):
+    eng, ref = both
+    g = genome["seqs"][0]
+    lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+
+    def asc(a):
+        return lut[np.minimum(a, 4)].tobytes()
+    reads = [
+        ("short", b"ACGTACGTAC", b"TTGACCA"),                       # shorter than a seed
+        ("allN", b"N" * 80, b"N" * 80),
+        ("homo", b"A" * 150, b"T" * 150),
+        ("edge", asc(g[:150]), asc(simulate._COMP[np.minimum(g[200:350], 3)][::-1])),   # at a contig start
+        ("one_unmappable", asc(g[5000:5150]), bytes(np.random.default_rng(4).choice(list(b"ACGT"), 150).tolist())),
+        ("tail", asc(g[-150:]), asc(simulate._COMP[np.minimum(g[-400:-250], 3)][::-1])),
+    ]
+    pes = (abi.mem_pestat_t * 4)()
+    for d in range(4):
+        pes[d].failed = 1
+    pes[1].failed = 0
+    pes[1].avg, pes[1].std, pes[1].low, pes[1].high = 300.0, 60.0, 50, 800
+    _cmp(eng, ref, reads, dict(flag=abi.MEM_F_PE), pes0=pes)
+    _cmp(eng, ref, [(n, a, None) for n, a, b in reads], dict(flag=0))
+    # empty batch: returns without touching anything
+    assert eng.process(eng.opt(flag=0), []) == []
