@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the mem_process_seqs() hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A step = one call of mem_process_seqs() (through the C ABI of libmpibwa_amd.so) on one chunk of
+synthetic 2x150 bp paired-end reads, i.e. exactly what mpiBWA's main loop does per chunk
+(src/mainParallel.c:1314).  One process per GPU; for N > 1 the driver launches this script under
+torch.distributed.run and the reads are sharded (independent chunks per rank, no data-path collective;
+the only collective is the one-off RCCL broadcast of the index from rank 0, as the north star asks).
+
+The JSON line carries, besides the contract fields,
+  roofline      — the SMEM seeding kernel: algorithmic bytes (64 B per occ block touched + read + output,
+                  SURVEY.md §8d, counted on the device) / its HIP-event time, against 8 TB/s HBM3E
+  cpu_baseline  — the reference's own mem_process_seqs (oracle/_ref/libbwaref.so, compiled from the
+                  reference sources) on a bounded sample of the same reads, on this box's host cores.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genome-mbp", type=float, default=float(os.environ.get("MPIBWA_BENCH_GENOME_MBP", "3100")))
+    ap.add_argument("--pairs", type=int, default=int(os.environ.get("MPIBWA_BENCH_PAIRS", "333334")),
+                    help="read pairs per step per GPU (mpiBWA -K 100000000 closes a chunk at 10^8 bases)")
+    ap.add_argument("--cpu-sample-pairs", type=int, default=int(os.environ.get("MPIBWA_BENCH_CPU_PAIRS", "60000")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workdir", default=os.environ.get("MPIBWA_BENCH_DIR", "/tmp/mpibwa_bench"))
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+
+    from mpibwa_amd import abi, api, bigindex, simulate
+    from mpibwa_amd.build import build
+    if rank == 0:
+        build()
+    if world > 1:
+        dist.barrier()
+    lib = api.load_library(build_if_missing=False)
+
+    # ---- reference genome + index: built once by rank 0 on its GPU, broadcast over RCCL/xGMI ----
+    os.makedirs(args.workdir, exist_ok=True)
+    t0 = time.time()
+    idx = bigindex.make_or_get(args.workdir, genome_mbp=args.genome_mbp, seed=38, rank=rank, world=world,
+                               local_rank=local_rank, dist=dist if world > 1 else None, log=log if rank == 0 else None)
+    eng = idx.engine
+    if rank == 0:
+        log("index ready in %.1f s: l_pac=%d, occ blocks %.2f GB, SA %.2f GB" %
+            (time.time() - t0, idx.l_pac, idx.blk_bytes / 1e9, idx.sa_bytes / 1e9))
+
+    # ---- reads: seeded per rank, same generator as the tests (2 % unmappable, 1 % subst., 0.1 % indel) ----
+    reads = idx.simulate_pairs(args.pairs, seed=1000 + rank)
+    batch = abi.SeqBatch(api.libc, reads)
+    opt = eng.opt(flag=abi.MEM_F_PE, n_threads=os.cpu_count() or 1)
+    lib_verbose = C.c_int.in_dll(eng.lib, "bwa_verbose")
+    lib_verbose.value = 1   # keep the per-chunk stderr chatter out of the timed region
+
+    def step():
+        eng.process_batch(opt, batch)
+        st = eng.stats()
+        batch.take_sam()      # the caller owns and frees seqs[i].sam (src/mainParallel.c:1390)
+        return st
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    acc = {}
+    for _ in range(args.steps):
+        st = step()
+        for k, v in st.items():
+            acc[k] = acc.get(k, 0) + v
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    n_reads_total = 2 * args.pairs * args.steps * world
+    value = n_reads_total / elapsed / 1e6
+
+    # ---- roofline of the dominant kernel (rank 0's launches; every rank runs the same kernel on its own shard) ----
+    ach = acc["smem_bytes"] / (acc["k_smem_ms"] * 1e-3) / 1e9 if acc.get("k_smem_ms") else 0.0
+    roofline = {"kernel": "smem_kernel", "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(ach / 8000.0, 4), "traffic": None,
+                "launch_ms": round(acc["k_smem_ms"] / args.steps, 3), "algo_bytes_per_launch": int(acc["smem_bytes"] / args.steps)}
+
+    out = {
+        "metric": "Mreads/s (whole node) 2x150 bp PE vs GRCh38-size reference; SAM bit-match",
+        "value": round(value, 4), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "config": {"workload": "2x150 bp PE reads vs seeded synthetic %.0f Mbp reference (GRCh38 absent on the box)" % (idx.l_pac / 1e6),
+                   "pairs_per_step_per_gpu": args.pairs, "reference_mbp": round(idx.l_pac / 1e6, 1),
+                   "chunking": "one mem_process_seqs chunk per step (mpiBWA -K 1e8 semantics)", "parallelism": "reads sharded, 1 rank/GPU"},
+        "roofline": roofline,
+        "stage_ms_per_step": {k: round(acc[k] / args.steps, 2) for k in
+                              ("h2d_ms", "smem_ms", "sa_ms", "chain_ms", "ext_ms", "regs_ms", "pestat_ms", "sam_ms", "k_smem_ms", "k_sa_ms", "k_ext_ms")},
+        "aux_kernels": {
+            "sa_kernel_GBps": round(acc["sa_bytes"] / (acc["k_sa_ms"] * 1e-3) / 1e9, 1) if acc.get("k_sa_ms") else None,
+            "c2a_kernel_GCUPS": round(acc["ext_cells"] / (acc["k_ext_ms"] * 1e-3) / 1e9, 2) if acc.get("k_ext_ms") else None},
+    }
+
+    # ---- CPU baseline: the reference itself on this box's host cores, bounded sample, rank 0 at N=1 only ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            from oracle import pyoracle as po
+            if po.ref_available():
+                cores = os.cpu_count() or 1
+                sample = reads[:min(args.cpu_sample_pairs, len(reads))]
+                ref = po.RefIndex(idx.prefix)
+                C.c_int.in_dll(ref.lib, "bwa_verbose").value = 1
+                ropt = ref.opt(flag=abi.MEM_F_PE, n_threads=cores)
+                rb = abi.SeqBatch(po.libc, sample)
+                t0 = time.perf_counter()
+                ref.lib.mem_process_seqs(ropt, ref.bwt, ref.bns, ref.pac, 0, rb.n, rb.arr, None)
+                dt = time.perf_counter() - t0
+                want = rb.take_sam()
+                got = eng.process(opt, sample)
+                out["cpu_baseline"] = {"value": round(rb.n / dt / 1e6, 5), "unit": "Mreads/s", "cores": cores, "kind": "reference",
+                                       "sample": "%d pairs of the same reads, one chunk, reference mem_process_seqs -t %d (%.1f s)" % (len(sample), cores, dt)}
+                out["parity_on_sample"] = bool(got == want)
+            else:
+                out["cpu_baseline"] = None
+        except Exception as e:  # the baseline must never take the bench line down
+            out["cpu_baseline"] = {"error": repr(e)}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -175,6 +175,9 @@ void mi355x_finalize(void);
 /* own bwa-compatible index builder (formats of src/bwt.c:385-462,
  * src/bntseq.c:66-96,275-328). Writes prefix.{pac,ann,amb,bwt,sa}. */
 int  mi355x_index_build(const char *fasta, const char *prefix);
+/* same .bwt/.sa, built in HBM (radix sort + prefix doubling on the device) from an N-free forward pac
+ * of l_pac bases; used for GRCh38-sized synthetic references.  *seconds = device build time. */
+int  mi355x_index_build_gpu(int device, const uint8_t *pac, int64_t l_pac, const char *prefix, double *seconds);
 
 /* ---- stage-level entry points (used by tests/bench for kernel parity and
  *      roofline measurement; each runs ONLY the named HIP kernel) ---- */

@@ -100,49 +100,63 @@ assert C.sizeof(bntseq_t) == 48
 
 class SeqBatch:
     """Owns the C buffers behind a bseq1_t[n] array, built the way mpiBWA's main does
-    (src/mainParallel.c:1257-1301): NUL-terminated name/seq/qual strings, mates interleaved."""
+    (src/mainParallel.c:1257-1301): one chunk buffer, NUL-terminated name/seq/qual strings pointing into it,
+    mates interleaved."""
+
+    _DT = None
 
     def __init__(self, libc, reads, with_qual=True, comment=None):
         # reads: list of (name:str, seq1:bytes, seq2:bytes|None)
+        import numpy as np
         self.libc = libc
-        flat = []
+        names, seqs = [], []
         for name, s1, s2 in reads:
-            flat.append((name, s1))
+            nb = name.encode() if isinstance(name, str) else name
+            names.append(nb); seqs.append(bytes(s1))
             if s2 is not None:
-                flat.append((name, s2))
-        self.n = len(flat)
-        self.arr = (bseq1_t * self.n)()
-        self._keep = []
-        for i, (name, s) in enumerate(flat):
-            nb = C.create_string_buffer(name.encode())
-            sb = C.create_string_buffer(bytes(s))
-            self._keep += [nb, sb]
-            self.arr[i].l_seq = len(s)
-            self.arr[i].id = 0
-            self.arr[i].name = C.addressof(nb)
-            self.arr[i].seq = C.addressof(sb)
-            self.arr[i].comment = None
-            if comment is not None:
-                cb = C.create_string_buffer(comment.encode())
-                self._keep.append(cb)
-                self.arr[i].comment = C.addressof(cb)
+                names.append(nb); seqs.append(bytes(s2))
+        n = self.n = len(seqs)
+        cb = comment.encode() if comment is not None else None
+        parts, lens = [], []
+        for nb, sq in zip(names, seqs):
+            parts += [nb, b"\0", sq, b"\0"]
+            lens += [len(nb) + 1, len(sq) + 1]
             if with_qual:
-                qb = C.create_string_buffer(b"I" * len(s))
-                self._keep.append(qb)
-                self.arr[i].qual = C.addressof(qb)
-            else:
-                self.arr[i].qual = None
-            self.arr[i].sam = None
+                parts += [b"I" * len(sq), b"\0"]
+            if cb is not None:
+                parts += [cb, b"\0"]
+        blob = b"".join(parts)
+        self._arena = C.create_string_buffer(blob, len(blob) + 1)
+        base = C.addressof(self._arena)
+        if SeqBatch._DT is None:
+            SeqBatch._DT = np.dtype([("l_seq", "<i4"), ("id", "<i4"), ("name", "<u8"), ("comment", "<u8"), ("seq", "<u8"),
+                                     ("qual", "<u8"), ("sam", "<u8")])
+        rec = np.zeros(max(n, 1), dtype=SeqBatch._DT)
+        if n:
+            ln = np.array([len(x) for x in names], dtype=np.int64) + 1
+            ls = np.array([len(x) for x in seqs], dtype=np.int64) + 1
+            per = ln + ls + (ls if with_qual else 0) + ((len(cb) + 1) if cb is not None else 0)
+            start = np.concatenate([[0], np.cumsum(per)[:-1]]) + base
+            rec["l_seq"][:n] = ls - 1
+            rec["name"][:n] = start
+            rec["seq"][:n] = start + ln
+            if with_qual:
+                rec["qual"][:n] = start + ln + ls
+            if cb is not None:
+                rec["comment"][:n] = start + ln + ls + (ls if with_qual else 0)
+        self._rec = rec
+        self.arr = C.cast(rec.ctypes.data, C.POINTER(bseq1_t))
 
     def take_sam(self):
         """Collect seqs[i].sam strings and free() them as the caller in mainParallel.c:1390 does."""
         out = []
+        sam = self._rec["sam"]
         for i in range(self.n):
-            p = self.arr[i].sam
+            p = int(sam[i])
             if p:
                 out.append(C.string_at(p))
                 self.libc.free(C.c_void_p(p))
-                self.arr[i].sam = None
+                sam[i] = 0
             else:
                 out.append(b"")
         return out

@@ -15,7 +15,7 @@ libc.free.argtypes = [C.c_void_p]
 
 EXPORTS = [
     "mem_process_seqs", "mem_opt_init", "bwa_fill_scmat", "bwa_idx_load_from_disk", "bwa_mem2idx", "bwa_idx_destroy",
-    "mi355x_index_upload", "mi355x_index_alloc", "mi355x_index_buffers", "mi355x_finalize", "mi355x_index_build",
+    "mi355x_index_upload", "mi355x_index_alloc", "mi355x_index_buffers", "mi355x_finalize", "mi355x_index_build", "mi355x_index_build_gpu",
     "mi355x_smem_batch", "mi355x_sa_batch", "mi355x_extend_batch", "mi355x_last_stats",
 ]
 
@@ -42,6 +42,7 @@ def load_library(build_if_missing=True):
     sig("mem_opt_init", P(abi.mem_opt_t), [])
     sig("bwa_idx_load_from_disk", P(abi.bwaidx_t), [C.c_char_p, C.c_int])
     sig("mi355x_index_build", C.c_int, [C.c_char_p, C.c_char_p])
+    sig("mi355x_index_build_gpu", C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_char_p, P(C.c_double)])
     sig("mem_process_seqs", None, [P(abi.mem_opt_t), P(abi.bwt_t), P(abi.bntseq_t), P(C.c_uint8), C.c_int64, C.c_int,
                                    P(abi.bseq1_t), P(abi.mem_pestat_t)])
     sig("mi355x_index_upload", C.c_int, [C.c_int, P(abi.bwt_t), P(abi.bntseq_t), P(C.c_uint8)])
