@@ -76,14 +76,18 @@ def main():
     # ---- reads: seeded per rank, same generator as the tests (2 % unmappable, 1 % subst., 0.1 % indel) ----
     reads = idx.simulate_pairs(args.pairs, seed=1000 + rank)
     batch = abi.SeqBatch(api.libc, reads)
-    opt = eng.opt(flag=abi.MEM_F_PE, n_threads=os.cpu_count() or 1)
+    cores = int(lib.mi355x_host_cpus())
+    opt = eng.opt(flag=abi.MEM_F_PE, n_threads=cores)
     lib_verbose = C.c_int.in_dll(eng.lib, "bwa_verbose")
     lib_verbose.value = 1   # keep the per-chunk stderr chatter out of the timed region
 
     def step():
         eng.process_batch(opt, batch)
         st = eng.stats()
-        batch.take_sam()      # the caller owns and frees seqs[i].sam (src/mainParallel.c:1390)
+        # the caller owns seqs[i].sam: concatenate + free, as mpiBWA's copy_buffer_thr does (src/mainParallel.c:103-127)
+        n = C.c_size_t(0)
+        p = lib.mi355x_collect_sam(batch.arr, batch.n, C.byref(n))
+        api.libc.free(C.c_void_p(p))
         return st
 
     for _ in range(args.warmup):
@@ -136,7 +140,6 @@ def main():
         try:
             from oracle import pyoracle as po
             if po.ref_available():
-                cores = os.cpu_count() or 1
                 sample = reads[:min(args.cpu_sample_pairs, len(reads))]
                 ref = po.RefIndex(idx.prefix)
                 C.c_int.in_dll(ref.lib, "bwa_verbose").value = 1

@@ -205,6 +205,13 @@ typedef struct {
 } mi355x_stats_t;
 void mi355x_last_stats(mi355x_stats_t *st);
 
+/* CPUs usable by this process (cgroup quota aware) — what the host stages are sized to. */
+int   mi355x_host_cpus(void);
+/* Caller-side convenience equal to mpiBWA's copy_buffer_thr (src/mainParallel.c:103-127): concatenates
+ * every seqs[i].sam into one malloc()ed buffer (returned, NUL-terminated, *total_len bytes) and free()s
+ * the per-read strings. */
+char *mi355x_collect_sam(bseq1_t *seqs, int n, size_t *total_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,7 +16,7 @@ libc.free.argtypes = [C.c_void_p]
 EXPORTS = [
     "mem_process_seqs", "mem_opt_init", "bwa_fill_scmat", "bwa_idx_load_from_disk", "bwa_mem2idx", "bwa_idx_destroy",
     "mi355x_index_upload", "mi355x_index_alloc", "mi355x_index_buffers", "mi355x_finalize", "mi355x_index_build", "mi355x_index_build_gpu",
-    "mi355x_smem_batch", "mi355x_sa_batch", "mi355x_extend_batch", "mi355x_last_stats",
+    "mi355x_smem_batch", "mi355x_sa_batch", "mi355x_extend_batch", "mi355x_last_stats", "mi355x_host_cpus", "mi355x_collect_sam",
 ]
 
 
@@ -52,6 +52,8 @@ def load_library(build_if_missing=True):
     sig("mi355x_extend_batch", C.c_int, [P(abi.mem_opt_t), C.c_int] + [C.c_void_p] * 8 + [P(C.c_double), P(C.c_uint64)])
     sig("mi355x_last_stats", None, [P(abi.mi355x_stats_t)])
     sig("mi355x_finalize", None, [])
+    sig("mi355x_host_cpus", C.c_int, [])
+    sig("mi355x_collect_sam", C.c_void_p, [P(abi.bseq1_t), C.c_int, P(C.c_size_t)])
     _LIB = lib
     return lib
 
@@ -90,6 +92,14 @@ class Engine:
 
     def process_batch(self, opt, batch, n_processed=0, pes0=None):
         self.lib.mem_process_seqs(opt, self.bwt, self.bns, self.pac, n_processed, batch.n, batch.arr, pes0)
+
+    def collect_sam(self, batch):
+        """All SAM text of the batch as one bytes object (frees the per-read strings like mpiBWA's writer does)."""
+        n = C.c_size_t(0)
+        p = self.lib.mi355x_collect_sam(batch.arr, batch.n, C.byref(n))
+        out = C.string_at(p, n.value)
+        libc.free(C.c_void_p(p))
+        return out
 
     def stats(self):
         st = abi.mi355x_stats_t()

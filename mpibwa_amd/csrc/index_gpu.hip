@@ -73,11 +73,10 @@ __device__ __forceinline__ u64 kmer_key(const u64 *T, u64 p, u64 N)
 // positions whose first `kb` symbols equal `bucket`
 __global__ void bucket_count_kernel(const u64 *__restrict__ T, u64 N, int kb, u64 *counts)
 {
-	u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
 	__shared__ u32 loc[256];
 	if (threadIdx.x < 256) loc[threadIdx.x] = 0;
 	__syncthreads();
-	if (p < N) {
+	for (u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x; p < N; p += (u64)gridDim.x * blockDim.x) {
 		u64 key = kmer_key(T, p, N);
 		u32 b = (u32)(key >> (64 - 2 * kb));
 		atomicAdd(&loc[b], 1u);
@@ -89,24 +88,27 @@ __global__ void bucket_count_kernel(const u64 *__restrict__ T, u64 N, int kb, u6
 __global__ void bucket_fill_kernel(const u64 *__restrict__ T, u64 N, int kb, u32 bucket, u64 *__restrict__ keys, u64 *__restrict__ pos,
                                    u64 *cursor)
 {
-	u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-	bool mine = false;
-	u64 key = 0;
-	if (p < N) {
-		key = kmer_key(T, p, N);
-		mine = (u32)(key >> (64 - 2 * kb)) == bucket;
-	}
-	// wave-aggregated append
-	u64 bal = __ballot(mine);
-	if (bal) {
-		int lane = threadIdx.x & 63;
-		int leader = __ffsll((long long)bal) - 1;
-		u64 base = 0;
-		if (lane == leader) base = atomicAdd(cursor, (u64)__popcll(bal));
-		base = __shfl(base, leader);
-		if (mine) {
-			u64 o = base + __popcll(bal & ((1ull << lane) - 1));
-			keys[o] = key; pos[o] = p;
+	// grid-stride with a block-uniform trip count (HIP caps one launch at 2^32 work-items)
+	for (u64 p0 = (u64)blockIdx.x * blockDim.x; p0 < N; p0 += (u64)gridDim.x * blockDim.x) {
+		u64 p = p0 + threadIdx.x;
+		bool mine = false;
+		u64 key = 0;
+		if (p < N) {
+			key = kmer_key(T, p, N);
+			mine = (u32)(key >> (64 - 2 * kb)) == bucket;
+		}
+		// wave-aggregated append
+		u64 bal = __ballot(mine);
+		if (bal) {
+			int lane = threadIdx.x & 63;
+			int leader = __ffsll((long long)bal) - 1;
+			u64 base = 0;
+			if (lane == leader) base = atomicAdd(cursor, (u64)__popcll(bal));
+			base = __shfl(base, leader);
+			if (mine) {
+				u64 o = base + __popcll(bal & ((1ull << lane) - 1));
+				keys[o] = key; pos[o] = p;
+			}
 		}
 	}
 }
@@ -261,7 +263,18 @@ struct Buf {
 	template <class T> T *as() { return (T *)p; }
 };
 
-static inline unsigned grid_for(u64 n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+static inline unsigned grid_for(u64 n, int bs)
+{
+	u64 g = (n + bs - 1) / bs;
+	if (g * bs >= (1ull << 32)) die("index builder: launch of %llu work-items exceeds the 2^32 limit", (unsigned long long)(g * bs));
+	return (unsigned)g;
+}
+static inline unsigned grid_strided(u64 n, int bs) { u64 g = (n + bs - 1) / bs; return (unsigned)(g < 262144 ? g : 262144); }
+static inline void check_launch(const char *what)
+{
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) die("index builder: %s: %s", what, hipGetErrorString(e));
+}
 
 } // namespace mbw
 
@@ -285,6 +298,7 @@ extern "C" int mi355x_index_build_gpu(int device, const uint8_t *pac, int64_t l_
 	Buf d_pac(l_pac / 4 + 1), d_T(n_words * 8);
 	HIP_OK(hipMemcpy(d_pac.p, pac, l_pac / 4 + 1, hipMemcpyHostToDevice));
 	hipLaunchKernelGGL(build_text_kernel, dim3(grid_for(n_words, BS)), dim3(BS), 0, 0, d_pac.as<uint8_t>(), l_pac, d_T.as<u64>(), n_words);
+	check_launch("build_text_kernel");
 	const u64 *T = d_T.as<u64>();
 
 	// bucket on the first kb symbols so that a bucket stays below ~384 M suffixes
@@ -293,7 +307,8 @@ extern "C" int mi355x_index_build_gpu(int device, const uint8_t *pac, int64_t l_
 	const u32 n_buckets = 1u << (2 * kb);
 	Buf d_counts(256 * 8);
 	HIP_OK(hipMemset(d_counts.p, 0, 256 * 8));
-	hipLaunchKernelGGL(bucket_count_kernel, dim3(grid_for(N, BS)), dim3(BS), 0, 0, T, N, kb, d_counts.as<u64>());
+	hipLaunchKernelGGL(bucket_count_kernel, dim3(grid_strided(N, BS)), dim3(BS), 0, 0, T, N, kb, d_counts.as<u64>());
+	check_launch("bucket_count_kernel");
 	std::vector<u64> counts(256);
 	HIP_OK(hipMemcpy(counts.data(), d_counts.p, 256 * 8, hipMemcpyDeviceToHost));
 	u64 max_bucket = 0;
@@ -321,7 +336,8 @@ extern "C" int mi355x_index_build_gpu(int device, const uint8_t *pac, int64_t l_
 			const u64 n = counts[b];
 			if (n == 0) continue;
 			HIP_OK(hipMemset(d_cursor.p, 0, 8));
-			hipLaunchKernelGGL(bucket_fill_kernel, dim3(grid_for(N, BS)), dim3(BS), 0, 0, T, N, kb, b, k_in.as<u64>(), v_in.as<u64>(), d_cursor.as<u64>());
+			hipLaunchKernelGGL(bucket_fill_kernel, dim3(grid_strided(N, BS)), dim3(BS), 0, 0, T, N, kb, b, k_in.as<u64>(), v_in.as<u64>(), d_cursor.as<u64>());
+			check_launch("bucket_fill_kernel");
 			size_t ts = tmp_sort;
 			HIP_OK(hipcub::DeviceRadixSort::SortPairs(tmp.p, ts, k_in.as<u64>(), k_out.as<u64>(), v_in.as<u64>(), v_out.as<u64>(), (int)n, 0, 64 - 2 * kb));
 			hipLaunchKernelGGL(flag_kernel, dim3(grid_for(n, BS)), dim3(BS), 0, 0, k_out.as<u64>(), n, head.as<u32>());
@@ -340,9 +356,11 @@ extern "C" int mi355x_index_build_gpu(int device, const uint8_t *pac, int64_t l_
 			}
 			hipLaunchKernelGGL(round0_post_kernel, dim3(grid_for(n, BS)), dim3(BS), 0, 0, E, v_out.as<u64>(), gst.as<u32>(), n, row_base,
 			                   d_rank.as<u64>(), u_pos->as<u64>(), u_row->as<u64>(), d_ucount.as<u64>());
+			check_launch("round0_post_kernel");
 			row_base += n;
 		}
 		HIP_OK(hipDeviceSynchronize());
+		if (row_base != N + 1) die("index builder: buckets cover %llu of %llu suffixes", (unsigned long long)(row_base - 1), (unsigned long long)N);
 	}
 
 	u64 m = 0;
@@ -388,6 +406,7 @@ extern "C" int mi355x_index_build_gpu(int device, const uint8_t *pac, int64_t l_
 			std::swap(cur_pos, alt_pos);
 			std::swap(cur_row, alt_row);
 			m = kept;
+			check_launch("doubling round");
 			if (h > N) die("index builder: doubling did not converge");
 		}
 	}
@@ -423,6 +442,7 @@ extern "C" int mi355x_index_build_gpu(int device, const uint8_t *pac, int64_t l_
 			HIP_OK(hipMemcpy(&lastp, cs[c] + n_blk - 1, 8, hipMemcpyDeviceToHost));
 			tot[c] = lastp + lastv;
 		}
+		check_launch("block_count_kernel");
 		hipLaunchKernelGGL(pack_kernel, dim3(grid_for(n_blk + 1, BS)), dim3(BS), 0, 0, d_B.as<uint8_t>(), N, primary, n_blk, c0.as<u64>(), c1.as<u64>(),
 		                   c2.as<u64>(), c3.as<u64>(), d_out.as<u32>());
 		// device image: one 64-B record per 128 symbols; the file closes with a 32-B count record right after the last packed word

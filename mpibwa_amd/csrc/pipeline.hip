@@ -39,12 +39,29 @@ namespace mbw {
 
 static mi355x_stats_t g_stats;
 
+// CPUs this process may actually use: the cgroup CPU quota when there is one, else the online CPU count
+static int usable_cpus()
+{
+	int hw = (int)std::thread::hardware_concurrency();
+	if (hw <= 0) hw = 1;
+	if (FILE *fp = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+		char q[64];
+		long long period = 0;
+		if (fscanf(fp, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+			long long quota = atoll(q);
+			int c = (int)((quota + period - 1) / period);
+			if (c >= 1 && c < hw) hw = c;
+		}
+		fclose(fp);
+	}
+	return hw;
+}
+
 static int host_threads(const mem_opt_t *opt)
 {
 	if (const char *e = getenv("MPIBWA_HOST_THREADS")) { int v = atoi(e); if (v > 0) return v; }
-	int hw = (int)std::thread::hardware_concurrency();
-	int t = std::max(opt->n_threads, hw > 0 ? hw : 1);
-	return std::min(t, 64);
+	(void)opt;   // the result does not depend on the thread count (as in the reference), so use what the box gives us
+	return std::min(usable_cpus(), 128);
 }
 
 template <class F>
@@ -100,6 +117,29 @@ static Workspace g_ws;
 using namespace mbw;
 
 extern "C" void mi355x_last_stats(mi355x_stats_t *st) { *st = g_stats; }
+extern "C" int mi355x_host_cpus(void) { return usable_cpus(); }
+
+// Caller-side helper mirroring mpiBWA's copy_buffer_thr (src/mainParallel.c:103-127): concatenate all
+// seqs[i].sam into one malloc'ed buffer and free the per-read strings.
+extern "C" char *mi355x_collect_sam(bseq1_t *seqs, int n, size_t *total_len)
+{
+	std::vector<size_t> len(n);
+	size_t tot = 0;
+	for (int i = 0; i < n; ++i) { len[i] = seqs[i].sam ? strlen(seqs[i].sam) : 0; tot += len[i]; }
+	char *buf = (char *)malloc(tot + 1);
+	if (!buf) die("out of memory collecting SAM");
+	size_t o = 0;
+	for (int i = 0; i < n; ++i) {
+		if (!seqs[i].sam) continue;
+		memcpy(buf + o, seqs[i].sam, len[i]);
+		o += len[i];
+		free(seqs[i].sam);
+		seqs[i].sam = 0;
+	}
+	buf[tot] = 0;
+	if (total_len) *total_len = tot;
+	return buf;
+}
 
 extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const bntseq_t *bns, const uint8_t *pac,
                                  int64_t n_processed, int n, bseq1_t *seqs, const mem_pestat_t *pes0)
