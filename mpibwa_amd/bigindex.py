@@ -13,6 +13,7 @@ import numpy as np
 from . import abi, api
 
 _REV_BYTE = None
+BUILDER_VERSION = 2   # bump whenever index_gpu.hip changes, so a cached index of an older build is never reused
 
 
 def _revcomp_bytes(a):
@@ -138,15 +139,16 @@ def make_or_get(workdir, genome_mbp=3100.0, seed=38, rank=0, world=1, local_rank
     lib = api.load_library()
     lib.mi355x_index_build_gpu.restype = C.c_int
     lib.mi355x_index_build_gpu.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_char_p, C.POINTER(C.c_double)]
-    prefix = os.path.join(workdir, "synth_%dM_s%d.fa" % (int(genome_mbp), seed))
+    prefix = os.path.join(workdir, "synth_%dM_s%d_b%d.fa" % (int(genome_mbp), seed, BUILDER_VERSION))
     t0 = time.time()
     pac, lens = synth_packed_genome(genome_mbp * 1e6, seed=seed)   # every rank regenerates the same packed genome (host stages need it)
     if log:
         log("synthetic genome: %.1f Mbp in %d contigs, generated in %.1f s" % (lens.sum() / 1e6, len(lens), time.time() - t0))
-    if rank == 0 and not os.path.exists(prefix + ".sa"):
+    if rank == 0 and not os.path.exists(prefix + ".ok"):
         write_meta_files(prefix, pac, lens)
         secs = C.c_double(0)
         lib.mi355x_index_build_gpu(local_rank, pac.ctypes.data, int(lens.sum()), prefix.encode(), C.byref(secs))
+        open(prefix + ".ok", "w").write("built in %.1f s\n" % secs.value)   # only a completed build is ever reused
         if log:
             log("FM-index built on the GPU in %.1f s" % secs.value)
     if dist is not None:
