@@ -205,6 +205,11 @@ typedef struct {
 } mi355x_stats_t;
 void mi355x_last_stats(mi355x_stats_t *st);
 
+/* host-logic test hook (no GPU involved): ksw_align2 (src/ksw.c:343-365) as used by mate rescue;
+ * out7 = score,te,qe,score2,te2,tb,qb; portable != 0 runs the lane-by-lane statement instead of SSE2 */
+void mi355x_host_ksw_align2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat, int o_del,
+                            int e_del, int o_ins, int e_ins, int xtra, int portable, int out7[7]);
+
 /* CPUs usable by this process (cgroup quota aware) — what the host stages are sized to. */
 int   mi355x_host_cpus(void);
 /* Caller-side convenience equal to mpiBWA's copy_buffer_thr (src/mainParallel.c:103-127): concatenates

@@ -16,7 +16,7 @@ libc.free.argtypes = [C.c_void_p]
 EXPORTS = [
     "mem_process_seqs", "mem_opt_init", "bwa_fill_scmat", "bwa_idx_load_from_disk", "bwa_mem2idx", "bwa_idx_destroy",
     "mi355x_index_upload", "mi355x_index_alloc", "mi355x_index_buffers", "mi355x_finalize", "mi355x_index_build", "mi355x_index_build_gpu",
-    "mi355x_smem_batch", "mi355x_sa_batch", "mi355x_extend_batch", "mi355x_last_stats", "mi355x_host_cpus", "mi355x_collect_sam",
+    "mi355x_smem_batch", "mi355x_sa_batch", "mi355x_extend_batch", "mi355x_last_stats", "mi355x_host_cpus", "mi355x_collect_sam", "mi355x_host_ksw_align2",
 ]
 
 
@@ -52,6 +52,7 @@ def load_library(build_if_missing=True):
     sig("mi355x_extend_batch", C.c_int, [P(abi.mem_opt_t), C.c_int] + [C.c_void_p] * 8 + [P(C.c_double), P(C.c_uint64)])
     sig("mi355x_last_stats", None, [P(abi.mi355x_stats_t)])
     sig("mi355x_finalize", None, [])
+    sig("mi355x_host_ksw_align2", None, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p])
     sig("mi355x_host_cpus", C.c_int, [])
     sig("mi355x_collect_sam", C.c_void_p, [P(abi.bseq1_t), C.c_int, P(C.c_size_t)])
     _LIB = lib

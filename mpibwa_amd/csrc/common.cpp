@@ -1,5 +1,7 @@
 // common.cpp — tables and option defaults shared by the host stages.
 #include "internal.h"
+#include "hprof.h"
+#include <cstdio>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -17,6 +19,18 @@ static struct Nt4Init {
 	}
 } nt4_init;
 const uint8_t *const nt4_table_ptr = nt4_init.t;
+
+std::atomic<long long> g_hprof[HP_N];
+std::atomic<long long> g_hcount[HP_N];
+bool g_hprof_on = getenv("MPIBWA_PROF") != nullptr;
+void hprof_report(const char *tag)
+{
+	if (!g_hprof_on) return;
+	static const char *nm[HP_N] = {"matesw", "ksw_align2", "reg2aln", "ksw_global2", "gen_alt", "aln2sam", "mark_primary", "pair", "dedup_patch"};
+	fprintf(stderr, "[hprof %s]", tag);
+	for (int i = 0; i < HP_N; ++i) { fprintf(stderr, " %s=%.1fms/%lld", nm[i], g_hprof[i].load() * 1e-6, g_hcount[i].load()); g_hprof[i] = 0; g_hcount[i] = 0; }
+	fprintf(stderr, "\n");
+}
 
 } // namespace mbw
 

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <emmintrin.h>
 
 namespace mbw {
 
@@ -235,16 +236,144 @@ KswResult striped_sw(const Prof &q, int tlen, const uint8_t *target, int o_del, 
 	return r;
 }
 
+
+// ---- the same striped kernel on 128-bit SSE2 registers (x86-64 hosts) ----
+// One template for both lane widths; V16 = 16 unsigned bytes, V8 = 8 signed words.  Operation order follows the
+// lane-by-lane version above exactly (that version is the readable statement of the semantics, this one is the fast one;
+// tests/test_host_ksw.py checks that they agree).
+struct LaneU8 {
+	static const int P = 16;
+	static __m128i set1(int v) { return _mm_set1_epi8((char)v); }
+	static __m128i add_score(__m128i h, __m128i s, __m128i shift) { return _mm_subs_epu8(_mm_adds_epu8(h, s), shift); }
+	static __m128i vmax(__m128i a, __m128i b) { return _mm_max_epu8(a, b); }
+	static __m128i subs(__m128i a, __m128i b) { return _mm_subs_epu8(a, b); }
+	static __m128i shl_lane(__m128i a) { return _mm_slli_si128(a, 1); }
+	static bool f_dead(__m128i f, __m128i h) { return _mm_movemask_epi8(_mm_cmpeq_epi8(_mm_subs_epu8(f, h), _mm_setzero_si128())) == 0xffff; }
+	static int hmax(__m128i x)
+	{
+		x = _mm_max_epu8(x, _mm_srli_si128(x, 8)); x = _mm_max_epu8(x, _mm_srli_si128(x, 4));
+		x = _mm_max_epu8(x, _mm_srli_si128(x, 2)); x = _mm_max_epu8(x, _mm_srli_si128(x, 1));
+		return _mm_extract_epi16(x, 0) & 0xff;
+	}
+};
+struct LaneI16 {
+	static const int P = 8;
+	static __m128i set1(int v) { return _mm_set1_epi16((short)v); }
+	static __m128i add_score(__m128i h, __m128i s, __m128i) { return _mm_adds_epi16(h, s); }
+	static __m128i vmax(__m128i a, __m128i b) { return _mm_max_epi16(a, b); }
+	static __m128i subs(__m128i a, __m128i b) { return _mm_subs_epu16(a, b); }
+	static __m128i shl_lane(__m128i a) { return _mm_slli_si128(a, 2); }
+	static bool f_dead(__m128i f, __m128i h) { return _mm_movemask_epi8(_mm_cmpgt_epi16(f, h)) == 0; }
+	static int hmax(__m128i x)
+	{
+		x = _mm_max_epi16(x, _mm_srli_si128(x, 8)); x = _mm_max_epi16(x, _mm_srli_si128(x, 4));
+		x = _mm_max_epi16(x, _mm_srli_si128(x, 2));
+		return _mm_extract_epi16(x, 0);
+	}
+};
+
+template <class L>
+KswResult striped_sw_sse2(const Prof &q, int tlen, const uint8_t *target, int o_del, int e_del_, int o_ins, int e_ins_, int xtra)
+{
+	const bool BYTE = L::P == 16;
+	const int P = L::P, slen = q.slen;
+	KswResult r = {0, -1, -1, -1, -1, -1, -1};
+	const int minsc = (xtra & KSW_XSUBO) ? xtra & 0xffff : 0x10000;
+	const int endsc = (xtra & KSW_XSTOP) ? xtra & 0xffff : 0x10000;
+	const __m128i zero = _mm_setzero_si128(), oe_del = L::set1(o_del + e_del_), e_del = L::set1(e_del_), oe_ins = L::set1(o_ins + e_ins_),
+	              e_ins = L::set1(e_ins_), shift = L::set1(q.shift);
+	// profile re-packed into vectors: [5][slen]
+	std::vector<__m128i> mem((size_t)slen * 9 + 1);
+	__m128i *qp = mem.data(), *H0 = qp + (size_t)slen * 5, *H1 = H0 + slen, *E = H1 + slen, *Hmax = E + slen;
+	for (size_t v = 0; v < (size_t)slen * 5; ++v) {
+		const int16_t *src = &q.qp[v * P];
+		if (BYTE) { alignas(16) uint8_t t[16]; for (int l = 0; l < 16; ++l) t[l] = (uint8_t)src[l]; qp[v] = _mm_load_si128((const __m128i *)t); }
+		else qp[v] = _mm_loadu_si128((const __m128i *)src);
+	}
+	for (int j = 0; j < slen; ++j) { H0[j] = zero; E[j] = zero; Hmax[j] = zero; H1[j] = zero; }
+	std::vector<uint64_t> b;
+	int te = -1, gmax = 0;
+	for (int i = 0; i < tlen; ++i) {
+		__m128i f = zero, mx = zero, h, e, t;
+		const __m128i *S = qp + (size_t)target[i] * slen;
+		h = slen > 0 ? L::shl_lane(H0[slen - 1]) : zero;
+		for (int j = 0; j < slen; ++j) {
+			h = L::add_score(h, S[j], shift);
+			e = E[j];
+			h = L::vmax(h, e); h = L::vmax(h, f);
+			mx = L::vmax(mx, h);
+			H1[j] = h;
+			e = L::subs(e, e_del); t = L::subs(h, oe_del); e = L::vmax(e, t);
+			E[j] = e;
+			f = L::subs(f, e_ins); t = L::subs(h, oe_ins); f = L::vmax(f, t);
+			h = H0[j];
+		}
+		bool done = false;
+		for (int k = 0; k < 16 && !done; ++k) {
+			f = L::shl_lane(f);
+			for (int j = 0; j < slen; ++j) {
+				h = L::vmax(H1[j], f);
+				H1[j] = h;
+				h = L::subs(h, oe_ins);
+				f = L::subs(f, e_ins);
+				if (L::f_dead(f, h)) { done = true; break; }
+			}
+		}
+		int imax = L::hmax(mx);
+		if (imax >= minsc) {
+			if (b.empty() || (int32_t)b.back() + 1 != i) b.push_back((uint64_t)imax << 32 | (uint32_t)i);
+			else if ((int)(b.back() >> 32) < imax) b.back() = (uint64_t)imax << 32 | (uint32_t)i;
+		}
+		if (imax > gmax) {
+			gmax = imax; te = i;
+			for (int j = 0; j < slen; ++j) Hmax[j] = H1[j];
+			if (BYTE) { if (gmax + q.shift >= 255 || gmax >= endsc) break; }
+			else if (gmax >= endsc) break;
+		}
+		std::swap(H0, H1);
+	}
+	if (BYTE) r.score = gmax + q.shift < 255 ? gmax : 255;
+	else r.score = gmax;
+	r.te = te;
+	if (!BYTE || r.score != 255) {
+		int mxv = -1, qlen = slen * P;
+		if (!BYTE) r.qe = -1;
+		const uint8_t *t8 = (const uint8_t *)Hmax;
+		const uint16_t *t16 = (const uint16_t *)Hmax;
+		for (int i = 0; i < qlen; ++i) {
+			int v = BYTE ? t8[i] : t16[i];
+			int pos = i / P + i % P * slen;
+			if (v > mxv) { mxv = v; r.qe = pos; }
+			else if (v == mxv && pos < r.qe) r.qe = pos;
+		}
+		if (!b.empty()) {
+			int i = (r.score + q.max - 1) / q.max;
+			int low = te - i, high = te + i;
+			for (uint64_t x : b) {
+				int e2 = (int32_t)x;
+				if ((e2 < low || e2 > high) && (int)(x >> 32) > r.score2) { r.score2 = (int)(x >> 32); r.te2 = e2; }
+			}
+		}
+	}
+	return r;
+}
+
 } // namespace
+
+static bool g_ksw_portable = getenv("MPIBWA_KSW_PORTABLE") != nullptr;
 
 KswResult ksw_align2(int qlen, uint8_t *query, int tlen, uint8_t *target, const int8_t *mat, int o_del, int e_del, int o_ins,
                      int e_ins, int xtra)
 {
 	const int size = (xtra & KSW_XBYTE) ? 1 : 2;
 	Prof q = make_profile(size, qlen, query, mat);
+	const bool portable = g_ksw_portable;   // lane-by-lane version, for cross-checking
 	auto run = [&](const Prof &p, int x) {
-		return size == 1 ? striped_sw<true>(p, tlen, target, o_del, e_del, o_ins, e_ins, x)
-		                 : striped_sw<false>(p, tlen, target, o_del, e_del, o_ins, e_ins, x);
+		if (portable)
+			return size == 1 ? striped_sw<true>(p, tlen, target, o_del, e_del, o_ins, e_ins, x)
+			                 : striped_sw<false>(p, tlen, target, o_del, e_del, o_ins, e_ins, x);
+		return size == 1 ? striped_sw_sse2<LaneU8>(p, tlen, target, o_del, e_del, o_ins, e_ins, x)
+		                 : striped_sw_sse2<LaneI16>(p, tlen, target, o_del, e_del, o_ins, e_ins, x);
 	};
 	KswResult r = run(q, xtra);
 	if ((xtra & KSW_XSTART) == 0 || ((xtra & KSW_XSUBO) && r.score < (xtra & 0xffff))) return r;
@@ -261,3 +390,15 @@ KswResult ksw_align2(int qlen, uint8_t *query, int tlen, uint8_t *target, const 
 }
 
 } // namespace mbw
+
+// test hook (host logic, no GPU): the local alignment used by mate rescue; portable != 0 selects the lane-by-lane version
+extern "C" void mi355x_host_ksw_align2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat, int o_del,
+                                       int e_del, int o_ins, int e_ins, int xtra, int portable, int out7[7])
+{
+	std::vector<uint8_t> q(query, query + qlen), t(target, target + tlen);
+	bool saved = mbw::g_ksw_portable;
+	mbw::g_ksw_portable = portable != 0;
+	mbw::KswResult r = mbw::ksw_align2(qlen, q.data(), tlen, t.data(), mat, o_del, e_del, o_ins, e_ins, xtra);
+	mbw::g_ksw_portable = saved;
+	out7[0] = r.score; out7[1] = r.te; out7[2] = r.qe; out7[3] = r.score2; out7[4] = r.te2; out7[5] = r.tb; out7[6] = r.qb;
+}

@@ -5,6 +5,7 @@
 //   mem_sam_pe   pairing decision, MAPQ and the two SAM records   src/bwamem_pair.c:250-393
 #include "host.h"
 #include "sortutil.h"
+#include "hprof.h"
 
 #include <algorithm>
 #include <cmath>
@@ -106,6 +107,7 @@ void pestat(const mem_opt_t *opt, int64_t l_pac, int n, const HRegV *regs, mem_p
 static int matesw(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, const mem_pestat_t pes[4], const HReg *a, int l_ms,
                   const uint8_t *ms, HRegV &ma)
 {
+	HProf hp_(HP_MATESW);
 	int64_t l_pac = bns->l_pac;
 	int skip[4], n = 0, rid = -1;
 	for (int r = 0; r < 4; ++r) skip[r] = pes[r].failed ? 1 : 0;
@@ -135,6 +137,7 @@ static int matesw(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac,
 		if (rb < re) ref = bns_fetch_seq(bns, pac, &rb, (rb + re) >> 1, &re, &rid);
 		if (a->rid == rid && re - rb >= opt->min_seed_len) {
 			int xtra = KSW_XSUBO | KSW_XSTART | (l_ms * opt->a < 250 ? KSW_XBYTE : 0) | (opt->min_seed_len * opt->a);
+			HProf hp2_(HP_ALIGN2);
 			KswResult aln = ksw_align2(l_ms, seq.data(), (int)(re - rb), ref.data(), opt->mat, opt->o_del, opt->e_del, opt->o_ins,
 			                           opt->e_ins, xtra);
 			if (aln.score >= opt->min_seed_len && aln.qb >= 0) {
@@ -167,6 +170,7 @@ static inline bool pair_lt(const Pair64 &a, const Pair64 &b) { return a.x < b.x 
 static int pair_hits(const mem_opt_t *opt, const bntseq_t *bns, const mem_pestat_t pes[4], HRegV a[2], int id, int *sub, int *n_sub,
                      int z[2], int n_pri[2])
 {
+	HProf hp_(HP_PAIR);
 	std::vector<Pair64> v, u;
 	int y[4], ret;
 	int64_t l_pac = bns->l_pac;

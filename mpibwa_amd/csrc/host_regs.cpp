@@ -9,6 +9,7 @@
 //   mem_gen_alt (XA tag)                           src/bwamem_extra.c:91-140
 #include "host.h"
 #include "sortutil.h"
+#include "hprof.h"
 
 #include <algorithm>
 #include <cassert>
@@ -52,6 +53,7 @@ int sort_dedup_patch(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *p
 {
 	int n = (int)v.size();
 	if (n <= 1) return n;
+	HProf hp_(HP_DEDUP);
 	HReg *a = v.data();
 	ks_introsort((size_t)n, a, [](const HReg &x, const HReg &y) { return x.re < y.re; });   // by END position
 	for (int i = 0; i < n; ++i) a[i].n_comp = 1;
@@ -131,6 +133,7 @@ int mark_primary_se(const mem_opt_t *opt, HRegV &v, int64_t id)
 {
 	int n = (int)v.size(), n_pri = 0;
 	if (n == 0) return 0;
+	HProf hp_(HP_MARK);
 	HReg *a = v.data();
 	std::vector<int> z;
 	for (int i = 0; i < n; ++i) {
@@ -258,6 +261,7 @@ bool gen_cigar2(const int8_t mat[25], int o_del, int e_del, int o_ins, int e_ins
 		w = w < w_ ? w : w_;
 		int min_w = abs((int)rlen - l_query) + 3;
 		w = w > min_w ? w : min_w;
+		HProf hp_(HP_GLOBAL2);
 		*score = ksw_global2(l_query, query, (int)rlen, rseq.data(), mat, o_del, e_del, o_ins, e_ins, w, cigar);
 	}
 	if (NM && cigar) {
@@ -302,6 +306,7 @@ static inline int infer_bw(int l1, int l2, int score, int a, int q, int r)
 
 HAln reg2aln(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, int l_query, const char *query_, const HReg *ar)
 {
+	HProf hp_(HP_REG2ALN);
 	HAln a;
 	if (ar == 0 || ar->rb < 0 || ar->re < 0) {   // unmapped record
 		a.rid = -1; a.pos = -1; a.flag |= 0x4;
@@ -374,6 +379,7 @@ static void add_cigar(const mem_opt_t *opt, const HAln *p, std::string &str, int
 static void aln2sam(const mem_opt_t *opt, const bntseq_t *bns, std::string &str, const bseq1_t *s, int n, const HAln *list, int which,
                     const HAln *m_)
 {
+	HProf hp_(HP_ALN2SAM);
 	HAln ptmp = list[which], *p = &ptmp, mtmp, *m = 0;
 	if (m_) { mtmp = *m_; m = &mtmp; }
 	p->flag |= m ? 0x1 : 0;
@@ -487,6 +493,7 @@ void aln2sam_pub(const mem_opt_t *opt, const bntseq_t *bns, std::string &str, co
 bool gen_alt(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, const HRegV &a, int l_query, const char *query,
              std::vector<std::string> &xa, std::vector<char> &has)
 {
+	HProf hp_(HP_GENALT);
 	int n = (int)a.size(), tot = 0;
 	std::vector<int> cnt(n, 0);
 	std::vector<char> has_alt(n, 0);

@@ -28,6 +28,7 @@
 
 #include "device.h"
 #include "host.h"
+#include "hprof.h"
 
 namespace mbw {
 
@@ -123,19 +124,20 @@ extern "C" int mi355x_host_cpus(void) { return usable_cpus(); }
 // seqs[i].sam into one malloc'ed buffer and free the per-read strings.
 extern "C" char *mi355x_collect_sam(bseq1_t *seqs, int n, size_t *total_len)
 {
-	std::vector<size_t> len(n);
-	size_t tot = 0;
-	for (int i = 0; i < n; ++i) { len[i] = seqs[i].sam ? strlen(seqs[i].sam) : 0; tot += len[i]; }
+	std::vector<size_t> off(n + 1);
+	const int n_thr = std::min(usable_cpus(), 32);
+	parallel_for(n_thr, n, 8192, [&](int i) { off[i + 1] = seqs[i].sam ? strlen(seqs[i].sam) : 0; });
+	off[0] = 0;
+	for (int i = 0; i < n; ++i) off[i + 1] += off[i];
+	const size_t tot = off[n];
 	char *buf = (char *)malloc(tot + 1);
 	if (!buf) die("out of memory collecting SAM");
-	size_t o = 0;
-	for (int i = 0; i < n; ++i) {
-		if (!seqs[i].sam) continue;
-		memcpy(buf + o, seqs[i].sam, len[i]);
-		o += len[i];
+	parallel_for(n_thr, n, 8192, [&](int i) {
+		if (!seqs[i].sam) return;
+		memcpy(buf + off[i], seqs[i].sam, off[i + 1] - off[i]);
 		free(seqs[i].sam);
 		seqs[i].sam = 0;
-	}
+	});
 	buf[tot] = 0;
 	if (total_len) *total_len = tot;
 	return buf;
@@ -388,6 +390,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		});
 	}
 	double t8 = now_ms();
+	hprof_report("sam stage");
 	g_stats.n_reads = n;
 	g_stats.h2d_ms = t1 - t_begin;
 	g_stats.smem_ms = t2 - t1; g_stats.sa_ms = t3 - t2; g_stats.chain_ms = t4 - t3; g_stats.ext_ms = t5 - t4;
