@@ -52,7 +52,7 @@ __device__ __forceinline__ int ref_base(const uint8_t *pac, i64 l_pac, i64 p)
 
 __global__ void __launch_bounds__(64 * C2A_WAVES)
 c2a_kernel(C2aParams P, WxParams X, int n_reads, const uint8_t *__restrict__ seq, const int64_t *__restrict__ off,
-           const int *__restrict__ chain_off, const DevChain *__restrict__ chains, const DevSeed *__restrict__ seeds,
+           const int *__restrict__ lens, const int *__restrict__ chain_off, const DevChain *__restrict__ chains, const DevSeed *__restrict__ seeds,
            unsigned int *srt, const int *__restrict__ reg_off, DevReg *regs, int *n_regs, const int *__restrict__ tab,
            int tab_stride, const uint8_t *__restrict__ pac, unsigned long long *counters, int max_len)
 {
@@ -65,7 +65,7 @@ c2a_kernel(C2aParams P, WxParams X, int n_reads, const uint8_t *__restrict__ seq
 	const int *gap = tab, *bound5 = tab + tab_stride, *bound3 = tab + 2 * tab_stride, *ceil95 = tab + 3 * tab_stride,
 	          *thr10 = tab + 4 * tab_stride;
 	const uint8_t *q = seq + off[rd];
-	const int lq = (int)(off[rd + 1] - off[rd]);
+	const int lq = lens[rd];
 	DevReg *av = regs + reg_off[rd];
 	int nav = 0;
 	unsigned long long cells = 0, n_ext = 0;
@@ -210,7 +210,7 @@ c2a_kernel(C2aParams P, WxParams X, int n_reads, const uint8_t *__restrict__ seq
 }
 
 void launch_c2a(void *stream, const C2aParams &P, const ExtParams &ep, int n_reads, const uint8_t *d_seq, const int64_t *d_off,
-                const int *d_chain_off, const DevChain *d_chains, const DevSeed *d_seeds, unsigned int *d_srt, const int *d_reg_off,
+                const int *d_len, const int *d_chain_off, const DevChain *d_chains, const DevSeed *d_seeds, unsigned int *d_srt, const int *d_reg_off,
                 DevReg *d_regs, int *d_nregs, const int *d_tab, int tab_stride, const uint8_t *d_pac, unsigned long long *d_counters,
                 int max_len)
 {
@@ -220,7 +220,7 @@ void launch_c2a(void *stream, const C2aParams &P, const ExtParams &ep, int n_rea
 	size_t shmem = (size_t)C2A_WAVES * 2 * (max_len + 2) * sizeof(int);
 	int n_blocks = (n_reads + C2A_WAVES - 1) / C2A_WAVES;
 	hipLaunchKernelGGL(c2a_kernel, dim3(n_blocks), dim3(64 * C2A_WAVES), shmem, (hipStream_t)stream, P, X, n_reads, d_seq, d_off,
-	                   d_chain_off, d_chains, d_seeds, d_srt, d_reg_off, d_regs, d_nregs, d_tab, tab_stride, d_pac, d_counters,
+	                   d_len, d_chain_off, d_chains, d_seeds, d_srt, d_reg_off, d_regs, d_nregs, d_tab, tab_stride, d_pac, d_counters,
 	                   max_len);
 }
 

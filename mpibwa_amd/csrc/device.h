@@ -42,8 +42,9 @@ struct DevBuf {
 };
 
 // Launchers (all asynchronous on `stream`; kernel time measured by the caller with HIP events)
+// d_off[r] must be a multiple of 16 (reads padded to 16-byte slots); d_len[r] is the true length
 void launch_smem(void *stream, const FmDev &fm, const SmemParams &sp, int n_reads, const uint8_t *d_seq,
-                 const int64_t *d_off, int cap, uint64_t *d_out, int *d_nout, int max_len,
+                 const int64_t *d_off, const int *d_len, int cap, uint64_t *d_out, int *d_nout, int max_len,
                  unsigned long long *d_counters /* [0]=next read, [1]=blocks, [2]=overflow */,
                  void *d_scratch, size_t scratch_bytes_per_quad, int n_quads);
 int  smem_grid_quads(int max_len, size_t *scratch_per_quad);
@@ -78,7 +79,7 @@ struct C2aParams {
 	int a, w, pen_clip5, pen_clip3;
 };
 void launch_c2a(void *stream, const C2aParams &P, const ExtParams &ep, int n_reads, const uint8_t *d_seq, const int64_t *d_off,
-                const int *d_chain_off, const DevChain *d_chains, const DevSeed *d_seeds, unsigned int *d_srt, const int *d_reg_off,
+                const int *d_len, const int *d_chain_off, const DevChain *d_chains, const DevSeed *d_seeds, unsigned int *d_srt, const int *d_reg_off,
                 DevReg *d_regs, int *d_nregs, const int *d_tab, int tab_stride, const uint8_t *d_pac, unsigned long long *d_counters,
                 int max_len);
 

@@ -68,6 +68,8 @@ static void alloc_index(const bwt_t *bwt, const bntseq_t *bns)
 	if ((1 << sh) != bwt->sa_intv) die("SA sampling interval %d is not a power of two", bwt->sa_intv);
 	fm.sa_shift = sh;
 	g_idx.l_pac = bns->l_pac;
+	if (bwt->seq_len >= (1ull << 34))
+		die("reference of %llu symbols: this build packs SA-interval bounds into 34 bits (references up to 8.5 Gbp)", (unsigned long long)bwt->seq_len);
 }
 
 } // namespace mbw
@@ -162,10 +164,20 @@ extern "C" int mi355x_smem_batch(const mem_opt_t *opt, int n, const uint8_t *seq
 	if (n <= 0) return 0;
 	hipStream_t st = 0;
 	int max_len = 0;
-	for (int i = 0; i < n; ++i) max_len = std::max(max_len, (int)(off[i + 1] - off[i]));
+	std::vector<int64_t> poff(n + 1);   // 16-byte aligned slots, as the kernel expects
+	std::vector<int> lens(n);
+	poff[0] = 0;
+	for (int i = 0; i < n; ++i) {
+		lens[i] = (int)(off[i + 1] - off[i]);
+		max_len = std::max(max_len, lens[i]);
+		poff[i + 1] = poff[i] + ((lens[i] + 15) & ~15);
+	}
 	size_t total = off[n];
-	uint8_t *d_seq; int64_t *d_off; uint64_t *d_out; int *d_nout; unsigned long long *d_cnt; void *d_scr;
-	HIP_OK(hipMalloc(&d_seq, total + 16));
+	std::vector<uint8_t> packed(poff[n] + 16, 0);
+	for (int i = 0; i < n; ++i) memcpy(packed.data() + poff[i], seqs + off[i], lens[i]);
+	uint8_t *d_seq; int64_t *d_off; uint64_t *d_out; int *d_nout, *d_len; unsigned long long *d_cnt; void *d_scr;
+	HIP_OK(hipMalloc(&d_seq, packed.size()));
+	HIP_OK(hipMalloc(&d_len, (size_t)n * 4));
 	HIP_OK(hipMalloc(&d_off, (size_t)(n + 1) * 8));
 	HIP_OK(hipMalloc(&d_out, (size_t)n * cap * 32));
 	HIP_OK(hipMalloc(&d_nout, (size_t)n * 4));
@@ -173,13 +185,14 @@ extern "C" int mi355x_smem_batch(const mem_opt_t *opt, int n, const uint8_t *seq
 	size_t per_quad = 0;
 	int n_quads = smem_grid_quads(max_len, &per_quad);
 	HIP_OK(hipMalloc(&d_scr, per_quad * n_quads));
-	HIP_OK(hipMemcpy(d_seq, seqs, total, hipMemcpyHostToDevice));
-	HIP_OK(hipMemcpy(d_off, off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
+	HIP_OK(hipMemcpy(d_seq, packed.data(), packed.size(), hipMemcpyHostToDevice));
+	HIP_OK(hipMemcpy(d_off, poff.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
+	HIP_OK(hipMemcpy(d_len, lens.data(), (size_t)n * 4, hipMemcpyHostToDevice));
 	HIP_OK(hipMemset(d_cnt, 0, 64));
 	HIP_OK(hipMemset(d_nout, 0, (size_t)n * 4));
 	Timer tm;
 	tm.start(st);
-	launch_smem(st, g_idx.fm, smem_params(opt), n, d_seq, d_off, cap, d_out, d_nout, max_len, d_cnt, d_scr, per_quad,
+	launch_smem(st, g_idx.fm, smem_params(opt), n, d_seq, d_off, d_len, cap, d_out, d_nout, max_len, d_cnt, d_scr, per_quad,
 	            n_quads);
 	double ms = tm.stop(st);
 	HIP_OK(hipGetLastError());
@@ -188,7 +201,7 @@ extern "C" int mi355x_smem_batch(const mem_opt_t *opt, int n, const uint8_t *seq
 	HIP_OK(hipMemcpy(n_out, d_nout, (size_t)n * 4, hipMemcpyDeviceToHost));
 	HIP_OK(hipMemcpy(intv_out, d_out, (size_t)n * cap * 32, hipMemcpyDeviceToHost));
 	(void)hipFree(d_seq); (void)hipFree(d_off); (void)hipFree(d_out); (void)hipFree(d_nout); (void)hipFree(d_cnt);
-	(void)hipFree(d_scr);
+	(void)hipFree(d_scr); (void)hipFree(d_len);
 	// order by info (the reference sorts with an unstable introsort keyed on info only, src/bwamem.c:161;
 	// equal keys are identical records, so any order of ties is the same byte sequence)
 	uint64_t n_intv = 0;

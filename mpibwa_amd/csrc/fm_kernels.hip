@@ -33,7 +33,8 @@ namespace mbw {
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
-#define LCAP 32            // interval-list entries kept in LDS per quad
+#define LCAP 24            // interval-list entries kept in LDS per quad (16 B each)
+#define QSLOT 256          // bytes of LDS per quad for the read itself (longer reads are read from HBM)
 #define SMEM_BLOCK 256     // 4 waves = 64 quads per workgroup
 
 template <int CTRL>
@@ -104,42 +105,55 @@ __device__ __forceinline__ int quad_extend(const FmDev &fm, u64 x0, u64 x1, u64 
 	return (ka >> 7) == (la >> 7) ? 1 : 2;
 }
 
+// One interval-list entry = 16 bytes: x0,x1,x2 (34 bits each: references up to 2^34 symbols = 8.5 Gbp) and the
+// end coordinate (16 bits).  Lane c of the quad stores dword c; every lane reads the whole entry back (one
+// ds_read_b128, broadcast inside the quad).
 struct QuadList {
-	u64 *lds;      // LCAP x 4 u64 of this quad
-	u64 *spill;    // per-quad HBM scratch for entries >= LCAP
+	uint4 *lds;      // LCAP entries of this quad
+	uint4 *spill;    // per-quad HBM scratch for entries >= LCAP
 };
 
 __device__ __forceinline__ void list_store(const QuadList &L, int e, int c, u64 x0, u64 x1, u64 x2, u64 end)
 {
-	u64 v = c == 0 ? x0 : c == 1 ? x1 : c == 2 ? x2 : end;
-	if (e < LCAP) L.lds[e * 4 + c] = v;
-	else L.spill[(size_t)(e - LCAP) * 4 + c] = v;
+	u32 hi = (u32)(x0 >> 32) | (u32)(x1 >> 32) << 2 | (u32)(x2 >> 32) << 4 | (u32)end << 16;
+	u32 v = c == 0 ? (u32)x0 : c == 1 ? (u32)x1 : c == 2 ? (u32)x2 : hi;
+	u32 *p = (u32 *)(e < LCAP ? L.lds + e : L.spill + (e - LCAP));
+	p[c] = v;
 }
 __device__ __forceinline__ void list_load(const QuadList &L, int e, u64 &x0, u64 &x1, u64 &x2, u64 &end)
 {
-	const u64 *p = e < LCAP ? L.lds + e * 4 : L.spill + (size_t)(e - LCAP) * 4;
-	x0 = p[0]; x1 = p[1]; x2 = p[2]; end = p[3];
+	uint4 v = e < LCAP ? L.lds[e] : L.spill[e - LCAP];
+	x0 = (u64)(v.w & 3) << 32 | v.x;
+	x1 = (u64)(v.w >> 2 & 3) << 32 | v.y;
+	x2 = (u64)(v.w >> 4 & 3) << 32 | v.z;
+	end = v.w >> 16;
 }
 
 enum { ST_PICK = 0, ST_FWD = 1, ST_BWD = 2, ST_P3 = 3, ST_DONE = 4 };
 
 __global__ void __launch_bounds__(SMEM_BLOCK)
 smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ seq, const int64_t *__restrict__ off,
-            int cap, u64 *__restrict__ out, int *__restrict__ nout_arr, u64 *counters, u64 *scratch,
-            size_t scratch_u64_per_quad)
+            const int *__restrict__ lens, int cap, u64 *__restrict__ out, int *__restrict__ nout_arr, u64 *counters, uint4 *scratch,
+            size_t scratch_ent_per_quad)
 {
-	__shared__ u64 lds_list[(SMEM_BLOCK / 4) * LCAP * 4];
+	__shared__ uint4 lds_list[(SMEM_BLOCK / 4) * LCAP];
+	__shared__ uint4 lds_read[(SMEM_BLOCK / 4) * (QSLOT / 16)];
 	const int lane = threadIdx.x & 63, c = lane & 3, qlead = lane & ~3;
 	const int quad_in_blk = threadIdx.x >> 2;
 	const size_t quad_gid = (size_t)blockIdx.x * (SMEM_BLOCK / 4) + quad_in_blk;
 	QuadList L;
-	L.lds = lds_list + quad_in_blk * LCAP * 4;
-	L.spill = scratch + quad_gid * scratch_u64_per_quad;
+	L.lds = lds_list + quad_in_blk * LCAP;
+	L.spill = scratch + quad_gid * scratch_ent_per_quad;
+	uint4 *myread = lds_read + quad_in_blk * (QSLOT / 16);
+	const uint8_t *lq = (const uint8_t *)myread;
 
 	int st = ST_PICK, pass = 0;
 	int rd = 0, len = 0, x = 0, i = 0, j = 0, np = 0, nc = 0, top = 0, min_intv = 1, ret = 0, last_start = -1;
 	int nout = 0, k2 = 0, old_n = 0, cb = -1, last_push_end = 0;
-	const uint8_t *q = seq;
+	const uint8_t *gq = seq;
+	bool q_lds = false;
+	// read base i: from the quad's LDS copy when the read fits, else from HBM
+	auto Q = [&](int i_) -> int { return q_lds ? lq[i_] : gq[i_]; };
 	u64 ik0 = 0, ik1 = 0, ik2 = 0, ik_end = 0, lastc_x2 = 0;
 	u64 p0 = 0, p1 = 0, p2 = 0, p_end = 0;   // backward: the list entry being extended
 	u64 *myout = out;
@@ -149,7 +163,7 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 	// start the forward sweep of bwt_smem1a at position x
 	auto begin_smem = [&](int xs, int mi) {
 		x = xs; min_intv = mi < 1 ? 1 : mi;
-		int b = q[xs];
+		int b = Q(xs);
 		ik0 = fm.L2[b] + 1; ik2 = fm.L2[b + 1] - fm.L2[b]; ik1 = fm.L2[3 - b] + 1; ik_end = xs + 1;
 		i = xs + 1; top = 0; st = ST_FWD;
 	};
@@ -158,7 +172,7 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 		last_push_end = (int)ik_end;
 		++top;
 	};
-	auto set_cb = [&]() { cb = (i < 0 || q[i] > 3) ? -1 : (int)q[i]; };
+	auto set_cb = [&]() { cb = (i < 0 || Q(i) > 3) ? -1 : (int)Q(i); };
 	auto fwd_done = [&]() {   // the list holds `top` entries, longest match last pushed
 		ret = last_push_end; np = top; i = x - 1; j = 0; nc = 0; last_start = -1; st = ST_BWD;
 		set_cb();
@@ -187,13 +201,18 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 					if (c == 0) r = (int)atomicAdd(&counters[0], 1ull);
 					r = __shfl(r, qlead);
 					if (r >= n_reads) { st = ST_DONE; break; }
-					rd = r; q = seq + off[r]; len = (int)(off[r + 1] - off[r]);
+					rd = r; gq = seq + off[r]; len = lens[r];
+					q_lds = len <= QSLOT;
+					if (q_lds) {   // off[] is 16-byte aligned: the quad copies the read with 16-B loads
+						const uint4 *src = (const uint4 *)gq;
+						for (int k = c; k * 16 < len; k += 4) myread[k] = src[k];
+					}
 					myout = out + (size_t)r * cap * 4;
 					nout = 0; x = 0; overflow = false; nblk = 0;
 					pass = len < sp.min_seed_len ? 4 : 1;   // src/bwamem.c:260: shorter than a seed => no intervals
 				}
 				if (pass == 1) {
-					while (x < len && q[x] > 3) ++x;
+					while (x < len && Q(x) > 3) ++x;
 					if (x >= len) { pass = 2; k2 = 0; old_n = nout < cap ? nout : cap; }
 					else begin_smem(x, 1);
 				} else if (pass == 2) {
@@ -211,10 +230,10 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 				} else if (pass == 3) {
 					if (sp.max_mem_intv <= 0) pass = 4;
 					else {
-						while (x < len && q[x] > 3) ++x;
+						while (x < len && Q(x) > 3) ++x;
 						if (x >= len) pass = 4;
 						else {
-							int b = q[x];
+							int b = Q(x);
 							ik0 = fm.L2[b] + 1; ik2 = fm.L2[b + 1] - fm.L2[b]; ik1 = fm.L2[3 - b] + 1;
 							i = x + 1; st = ST_P3;
 						}
@@ -228,7 +247,7 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 					pass = 0;
 				}
 			} else if (st == ST_FWD) {
-				if (i == len || q[i] > 3) { push_fwd(); fwd_done(); }
+				if (i == len || Q(i) > 3) { push_fwd(); fwd_done(); }
 				else { need = true; back = false; e0 = ik0; e1 = ik1; e2 = ik2; }
 			} else if (st == ST_BWD) {
 				if (cb < 0) {
@@ -245,7 +264,7 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 				}
 			} else { // ST_P3
 				if (i == len) { x = len; st = ST_PICK; }
-				else if (q[i] > 3) { x = i + 1; st = ST_PICK; }
+				else if (Q(i) > 3) { x = i + 1; st = ST_PICK; }
 				else { need = true; back = false; e0 = ik0; e1 = ik1; e2 = ik2; }
 			}
 		}
@@ -253,7 +272,7 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 		if (need) {
 			u64 o0, o1, o2;
 			nblk += quad_extend(fm, e0, e1, e2, back, c, o0, o1, o2);
-			int csel = back ? cb : 3 - (int)q[i];
+			int csel = back ? cb : 3 - (int)Q(i);
 			u64 s0 = __shfl(o0, qlead | csel), s1 = __shfl(o1, qlead | csel), s2 = __shfl(o2, qlead | csel);
 			if (st == ST_FWD) {
 				bool stop = false;
@@ -285,14 +304,14 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 
 int smem_grid_quads(int max_len, size_t *scratch_per_quad)
 {
-	int n_blocks = 256 * 2;    // 2 workgroups (64 KB LDS each) per CU
+	int n_blocks = 256 * 4;    // 4 workgroups (40 KB LDS, 4 waves each) per CU
 	size_t ent = max_len + 1 > LCAP ? (size_t)(max_len + 1 - LCAP) : 0;
-	*scratch_per_quad = (ent * 4 + 4) * sizeof(u64);
+	*scratch_per_quad = (ent + 1) * sizeof(uint4);
 	return n_blocks * (SMEM_BLOCK / 4);
 }
 
 void launch_smem(void *stream, const FmDev &fm, const SmemParams &sp, int n_reads, const uint8_t *d_seq,
-                 const int64_t *d_off, int cap, uint64_t *d_out, int *d_nout, int max_len,
+                 const int64_t *d_off, const int *d_len, int cap, uint64_t *d_out, int *d_nout, int max_len,
                  unsigned long long *d_counters, void *d_scratch, size_t scratch_bytes_per_quad, int n_quads)
 {
 	(void)max_len;
@@ -301,8 +320,8 @@ void launch_smem(void *stream, const FmDev &fm, const SmemParams &sp, int n_read
 	if (want < 1) want = 1;
 	if (n_blocks > want) n_blocks = want;
 	hipLaunchKernelGGL(smem_kernel, dim3(n_blocks), dim3(SMEM_BLOCK), 0, (hipStream_t)stream, fm, sp, n_reads, d_seq,
-	                   d_off, cap, (u64 *)d_out, d_nout, (u64 *)d_counters, (u64 *)d_scratch,
-	                   scratch_bytes_per_quad / sizeof(u64));
+	                   d_off, d_len, cap, (u64 *)d_out, d_nout, (u64 *)d_counters, (uint4 *)d_scratch,
+	                   scratch_bytes_per_quad / sizeof(uint4));
 }
 
 // ---------------------------------------------------------------------------

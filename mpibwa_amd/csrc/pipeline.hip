@@ -107,7 +107,7 @@ struct EvTimer {
 
 // device work buffers, grown on demand and kept across calls
 struct Workspace {
-	DevBuf seq, off, intv, nintv, cnt, scratch, nseeds, lrep, seed_off, rows, qbl, sa;
+	DevBuf seq, off, len, intv, nintv, cnt, scratch, nseeds, lrep, seed_off, rows, qbl, sa;
 	DevBuf chain_off, chains, seeds, srt, reg_off, regs, nregs, tab;
 	const void *host_bwt = nullptr;
 };
@@ -167,10 +167,17 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	EvTimer ev_smem, ev_sa, ev_ext;
 
 	// ---- 1. encode + pack ----
-	std::vector<int64_t> off(n + 1);
+	std::vector<int64_t> off(n + 1);   // 16-byte aligned slot of every read in the packed buffer
+	std::vector<int> lens(n);
 	off[0] = 0;
 	int max_len = 0;
-	for (int i = 0; i < n; ++i) { off[i + 1] = off[i] + seqs[i].l_seq; max_len = std::max(max_len, seqs[i].l_seq); }
+	int64_t total_bases = 0;
+	for (int i = 0; i < n; ++i) {
+		lens[i] = seqs[i].l_seq;
+		off[i + 1] = off[i] + ((seqs[i].l_seq + 15) & ~15);
+		max_len = std::max(max_len, seqs[i].l_seq);
+		total_bases += seqs[i].l_seq;
+	}
 	std::vector<uint8_t> flat(off[n] + 16);
 	parallel_for(n_thr, n, 4096, [&](int i) {
 		char *s = seqs[i].seq;
@@ -184,8 +191,10 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	double t1 = now_ms();
 	uint8_t *d_seq = (uint8_t *)W.seq.ensure(flat.size());
 	int64_t *d_off = (int64_t *)W.off.ensure((size_t)(n + 1) * 8);
+	int *d_len = (int *)W.len.ensure((size_t)n * 4);
 	HIP_OK(hipMemcpyAsync(d_seq, flat.data(), flat.size(), hipMemcpyHostToDevice, st));
 	HIP_OK(hipMemcpyAsync(d_off, off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+	HIP_OK(hipMemcpyAsync(d_len, lens.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
 	unsigned long long *d_cnt = (unsigned long long *)W.cnt.ensure(256);
 
 	// ---- 2. SMEM seeding (retry with a larger per-read capacity in the rare overflow case) ----
@@ -200,7 +209,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		d_nintv = (int *)W.nintv.ensure((size_t)n * 4);
 		HIP_OK(hipMemsetAsync(d_cnt, 0, 256, st));
 		ev_smem.start(st);
-		launch_smem(st, ix.fm, smem_params(opt), n, d_seq, d_off, cap, d_intv, d_nintv, max_len, d_cnt, d_scr, per_quad, n_quads);
+		launch_smem(st, ix.fm, smem_params(opt), n, d_seq, d_off, d_len, cap, d_intv, d_nintv, max_len, d_cnt, d_scr, per_quad, n_quads);
 		ev_smem.stop(st);
 		HIP_OK(hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, st));
 		HIP_OK(hipStreamSynchronize(st));
@@ -209,7 +218,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		if (cnt[2] == 0) break;
 		cap *= 4;
 	}
-	g_stats.smem_bytes = cnt[1] * 64 + (uint64_t)off[n];
+	g_stats.smem_bytes = cnt[1] * 64 + (uint64_t)total_bases;
 	double t2 = now_ms();
 
 	// ---- 3. seed enumeration + SA lookup ----
@@ -338,7 +347,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		memcpy(ep.mat, opt->mat, 25);
 		ep.o_del = opt->o_del; ep.e_del = opt->e_del; ep.o_ins = opt->o_ins; ep.e_ins = opt->e_ins; ep.zdrop = opt->zdrop;
 		ev_ext.start(st);
-		launch_c2a(st, cp, ep, n, d_seq, d_off, d_chain_off, d_chains, d_seeds, d_srt, d_reg_off, d_regs, d_nregs, d_tab, TS,
+		launch_c2a(st, cp, ep, n, d_seq, d_off, d_len, d_chain_off, d_chains, d_seeds, d_srt, d_reg_off, d_regs, d_nregs, d_tab, TS,
 		           (const uint8_t *)ix.d_pac, d_cnt, max_len);
 		ev_ext.stop(st);
 		HIP_OK(hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, st));
