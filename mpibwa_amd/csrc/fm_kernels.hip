@@ -50,32 +50,39 @@ __device__ __forceinline__ u64 dpp64(u64 v)
 // quad_perm selectors
 #define QP(a, b, c, d) ((a) | (b) << 2 | (c) << 4 | (d) << 6)
 
-// Occ(c, k) for the lane's own base c; k is already shifted for the '$' row.
-// `v` is this lane's 16 B of the 64-B block: lanes 0,1 hold the four 64-bit
-// running counts, lanes 2,3 the eight packed words.
-__device__ __forceinline__ u64 quad_occ(uint4 v, u64 k, int c)
+// A quad's view of one occ block: lane j holds the running count of base j (8 B) and packed words 2j, 2j+1 (8 B);
+// the four lanes together touch exactly the 64 bytes of the block.
+struct BlkPart { u64 cnt; uint2 w; };
+
+__device__ __forceinline__ BlkPart load_part(const FmDev &fm, u64 k, int c)
 {
-	// running count of base c: u64 #c lives in lane c>>1, half c&1
-	u32 a0 = dpp<QP(0, 0, 1, 1)>(v.x), a1 = dpp<QP(0, 0, 1, 1)>(v.y);
-	u32 a2 = dpp<QP(0, 0, 1, 1)>(v.z), a3 = dpp<QP(0, 0, 1, 1)>(v.w);
-	u64 cnt = (c & 1) ? ((u64)a3 << 32 | a2) : ((u64)a1 << 32 | a0);
-	u32 w[8];
-	w[0] = dpp<QP(2, 2, 2, 2)>(v.x); w[1] = dpp<QP(2, 2, 2, 2)>(v.y);
-	w[2] = dpp<QP(2, 2, 2, 2)>(v.z); w[3] = dpp<QP(2, 2, 2, 2)>(v.w);
-	w[4] = dpp<QP(3, 3, 3, 3)>(v.x); w[5] = dpp<QP(3, 3, 3, 3)>(v.y);
-	w[6] = dpp<QP(3, 3, 3, 3)>(v.z); w[7] = dpp<QP(3, 3, 3, 3)>(v.w);
-	const u32 pat = 0x55555555u * (u32)c;
-	const int kk = (int)(k & 127) + 1;      // number of symbols of this block that are counted (1..128)
-	u32 n = 0;
+	const char *base = (const char *)fm.blk + (k >> 7) * 64;
+	BlkPart p;
+	p.cnt = *(const u64 *)(base + 8 * c);
+	p.w = *(const uint2 *)(base + 32 + 8 * c);
+	return p;
+}
+
+// Occ(c, k) for the lane's own base c; k is already shifted for the '$' row.  Every lane counts all four bases in
+// its two words (bit planes + popcount), the per-base partial counts travel packed in one dword (<= 128 per byte),
+// two DPP adds give every lane the block totals, and lane c keeps byte c.
+__device__ __forceinline__ u64 quad_occ(BlkPart p, u64 k, int c)
+{
+	const int kk = (int)(k & 127) + 1 - 32 * c;   // symbols of this lane's two words that are counted
+	u32 a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
-	for (int i = 0; i < 8; ++i) {
-		int m = kk - 16 * i;                // symbols of word i that are counted
+	for (int t = 0; t < 2; ++t) {
+		int m = kk - 16 * t;
 		m = m < 0 ? 0 : (m > 16 ? 16 : m);
-		u32 mask = (u32)(0xFFFFFFFF00000000ull >> (2 * m));
-		u32 y = ~(w[i] ^ pat);
-		n += __popc(y & (y >> 1) & 0x55555555u & mask);
+		const u32 msk = (u32)(0xFFFFFFFF00000000ull >> (2 * m)) & 0x55555555u;
+		const u32 w = t ? p.w.y : p.w.x;
+		const u32 lo = w & msk, hi = (w >> 1) & msk, nlo = lo ^ msk, nhi = hi ^ msk;
+		a0 += __popc(nhi & nlo); a1 += __popc(nhi & lo); a2 += __popc(hi & nlo); a3 += __popc(hi & lo);
 	}
-	return cnt + n;
+	u32 pk = a0 | a1 << 8 | a2 << 16 | a3 << 24;
+	pk += dpp<QP(1, 0, 3, 2)>(pk);
+	pk += dpp<QP(2, 3, 0, 1)>(pk);
+	return p.cnt + ((pk >> (8 * c)) & 0xffu);
 }
 
 // bwt_extend for one quad: lane c receives child interval c.
@@ -83,12 +90,10 @@ __device__ __forceinline__ u64 quad_occ(uint4 v, u64 k, int c)
 __device__ __forceinline__ int quad_extend(const FmDev &fm, u64 x0, u64 x1, u64 x2, bool back, int c,
                                            u64 &o0, u64 &o1, u64 &o2)
 {
-	const uint4 *blk = (const uint4 *)fm.blk;
 	u64 p = back ? x0 : x1;                  // the side searched in the BWT (always >= 1)
 	u64 k = p - 1, l = k + x2;
 	u64 ka = k - (k >= fm.primary), la = l - (l >= fm.primary);
-	uint4 vk = blk[(ka >> 7) * 4 + c];
-	uint4 vl = blk[(la >> 7) * 4 + c];
+	BlkPart vk = load_part(fm, ka, c), vl = load_part(fm, la, c);
 	u64 tk = quad_occ(vk, ka, c), tl = quad_occ(vl, la, c);
 	u64 a = fm.L2[c] + 1 + tk, s = tl - tk;
 	// mirrored side: children are laid out T,G,C,A behind the (possible) sentinel
@@ -190,90 +195,16 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 		++nout;
 	};
 
+	// One pass per iteration, no inner re-dispatch: [consume the previous extend] -> [backward bookkeeping] ->
+	// [pick the next call / read] -> [forward bookkeeping] -> one bwt_extend for every quad that has a request.
+	bool need = false, back = false;
+	u64 o0 = 0, o1 = 0, o2 = 0;
+	int qi = 0;    // base at position i (forward / LAST-like sweeps)
 	for (;;) {
-		bool need = false, back = false;
-		u64 e0 = 0, e1 = 0, e2 = 0;
-		// ---- bookkeeping until this quad needs one bwt_extend (or is out of work) ----
-		while (!need && st != ST_DONE) {
-			if (st == ST_PICK) {
-				if (pass == 0) {
-					int r = 0;
-					if (c == 0) r = (int)atomicAdd(&counters[0], 1ull);
-					r = __shfl(r, qlead);
-					if (r >= n_reads) { st = ST_DONE; break; }
-					rd = r; gq = seq + off[r]; len = lens[r];
-					q_lds = len <= QSLOT;
-					if (q_lds) {   // off[] is 16-byte aligned: the quad copies the read with 16-B loads
-						const uint4 *src = (const uint4 *)gq;
-						for (int k = c; k * 16 < len; k += 4) myread[k] = src[k];
-					}
-					myout = out + (size_t)r * cap * 4;
-					nout = 0; x = 0; overflow = false; nblk = 0;
-					pass = len < sp.min_seed_len ? 4 : 1;   // src/bwamem.c:260: shorter than a seed => no intervals
-				}
-				if (pass == 1) {
-					while (x < len && Q(x) > 3) ++x;
-					if (x >= len) { pass = 2; k2 = 0; old_n = nout < cap ? nout : cap; }
-					else begin_smem(x, 1);
-				} else if (pass == 2) {
-					bool found = false;
-					while (k2 < old_n) {
-						u64 info = myout[(size_t)k2 * 4 + 3], xx2 = myout[(size_t)k2 * 4 + 2];
-						++k2;
-						int s = (int)(info >> 32), e = (int)(u32)info;
-						if (e - s < sp.split_len || xx2 > (u64)sp.split_width) continue;
-						begin_smem((s + e) >> 1, (int)xx2 + 1);
-						found = true;
-						break;
-					}
-					if (!found) { pass = 3; x = 0; }
-				} else if (pass == 3) {
-					if (sp.max_mem_intv <= 0) pass = 4;
-					else {
-						while (x < len && Q(x) > 3) ++x;
-						if (x >= len) pass = 4;
-						else {
-							int b = Q(x);
-							ik0 = fm.L2[b] + 1; ik2 = fm.L2[b + 1] - fm.L2[b]; ik1 = fm.L2[3 - b] + 1;
-							i = x + 1; st = ST_P3;
-						}
-					}
-				} else if (pass == 4) {   // read finished
-					if (c == 0) {
-						nout_arr[rd] = nout;
-						atomicAdd(&counters[1], (u64)nblk);
-						if (overflow) atomicAdd(&counters[2], 1ull);
-					}
-					pass = 0;
-				}
-			} else if (st == ST_FWD) {
-				if (i == len || Q(i) > 3) { push_fwd(); fwd_done(); }
-				else { need = true; back = false; e0 = ik0; e1 = ik1; e2 = ik2; }
-			} else if (st == ST_BWD) {
-				if (cb < 0) {
-					// start of the read or an ambiguous base: only the longest live match can be maximal
-					list_load(L, top - 1, p0, p1, p2, p_end);
-					if (last_start < 0 || i + 1 < last_start) emit(p0, p1, p2, i + 1, (int)p_end);
-					call_done();
-				} else if (j == np) {
-					if (nc == 0) call_done();
-					else { np = nc; --i; j = 0; nc = 0; set_cb(); }
-				} else {
-					list_load(L, top - 1 - j, p0, p1, p2, p_end);
-					need = true; back = true; e0 = p0; e1 = p1; e2 = p2;
-				}
-			} else { // ST_P3
-				if (i == len) { x = len; st = ST_PICK; }
-				else if (Q(i) > 3) { x = i + 1; st = ST_PICK; }
-				else { need = true; back = false; e0 = ik0; e1 = ik1; e2 = ik2; }
-			}
-		}
-		if (__ballot(st != ST_DONE) == 0) break;
+		// ---- consume ----
 		if (need) {
-			u64 o0, o1, o2;
-			nblk += quad_extend(fm, e0, e1, e2, back, c, o0, o1, o2);
-			int csel = back ? cb : 3 - (int)Q(i);
-			u64 s0 = __shfl(o0, qlead | csel), s1 = __shfl(o1, qlead | csel), s2 = __shfl(o2, qlead | csel);
+			const int csel = back ? cb : 3 - qi;
+			const u64 s0 = __shfl(o0, qlead | csel), s1 = __shfl(o1, qlead | csel), s2 = __shfl(o2, qlead | csel);
 			if (st == ST_FWD) {
 				bool stop = false;
 				if (s2 != ik2) {
@@ -299,6 +230,90 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 				} else { ik0 = s0; ik1 = s1; ik2 = s2; ++i; }
 			}
 		}
+		need = false;
+		// ---- backward sweep: end of a row, end of the call, or the next list entry ----
+		if (st == ST_BWD) {
+			if (cb >= 0 && j == np) {
+				if (nc == 0) call_done();
+				else { np = nc; --i; j = 0; nc = 0; set_cb(); }
+			}
+			if (st == ST_BWD) {
+				if (cb < 0) {   // start of the read or an ambiguous base: only the longest live match can be maximal
+					list_load(L, top - 1, p0, p1, p2, p_end);
+					if (last_start < 0 || i + 1 < last_start) emit(p0, p1, p2, i + 1, (int)p_end);
+					call_done();
+				} else {
+					list_load(L, top - 1 - j, p0, p1, p2, p_end);
+					need = true; back = true;
+				}
+			}
+		}
+		// ---- between calls: next call of this pass, next pass, next read ----
+		while (st == ST_PICK) {
+			if (pass == 0) {
+				int r = 0;
+				if (c == 0) r = (int)atomicAdd(&counters[0], 1ull);
+				r = __shfl(r, qlead);
+				if (r >= n_reads) { st = ST_DONE; break; }
+				rd = r; gq = seq + off[r]; len = lens[r];
+				q_lds = len <= QSLOT;
+				if (q_lds) {   // off[] is 16-byte aligned: the quad copies the read with 16-B loads
+					const uint4 *src = (const uint4 *)gq;
+					for (int k = c; k * 16 < len; k += 4) myread[k] = src[k];
+				}
+				myout = out + (size_t)r * cap * 4;
+				nout = 0; x = 0; overflow = false; nblk = 0;
+				pass = len < sp.min_seed_len ? 4 : 1;   // src/bwamem.c:260: shorter than a seed => no intervals
+			}
+			if (pass == 1) {
+				while (x < len && Q(x) > 3) ++x;
+				if (x >= len) { pass = 2; k2 = 0; old_n = nout < cap ? nout : cap; }
+				else begin_smem(x, 1);
+			} else if (pass == 2) {
+				bool found = false;
+				while (k2 < old_n) {
+					u64 info = myout[(size_t)k2 * 4 + 3], xx2 = myout[(size_t)k2 * 4 + 2];
+					++k2;
+					int s = (int)(info >> 32), e = (int)(u32)info;
+					if (e - s < sp.split_len || xx2 > (u64)sp.split_width) continue;
+					begin_smem((s + e) >> 1, (int)xx2 + 1);
+					found = true;
+					break;
+				}
+				if (!found) { pass = 3; x = 0; }
+			} else if (pass == 3) {
+				if (sp.max_mem_intv <= 0) pass = 4;
+				else {
+					while (x < len && Q(x) > 3) ++x;
+					if (x >= len) pass = 4;
+					else {
+						int b = Q(x);
+						ik0 = fm.L2[b] + 1; ik2 = fm.L2[b + 1] - fm.L2[b]; ik1 = fm.L2[3 - b] + 1;
+						i = x + 1; st = ST_P3;
+					}
+				}
+			} else if (pass == 4) {   // read finished
+				if (c == 0) {
+					nout_arr[rd] = nout;
+					atomicAdd(&counters[1], (u64)nblk);
+					if (overflow) atomicAdd(&counters[2], 1ull);
+				}
+				pass = 0;
+			}
+		}
+		// ---- forward sweeps ----
+		if (st == ST_FWD) {
+			if (i < len) qi = Q(i);
+			if (i == len || qi > 3) { push_fwd(); fwd_done(); }   // the backward sweep starts in the next iteration
+			else { need = true; back = false; }
+		} else if (st == ST_P3) {
+			if (i < len) qi = Q(i);
+			if (i == len) { x = len; st = ST_PICK; }
+			else if (qi > 3) { x = i + 1; st = ST_PICK; }
+			else { need = true; back = false; }
+		}
+		if (__ballot(st != ST_DONE) == 0) break;
+		if (need) nblk += quad_extend(fm, back ? p0 : ik0, back ? p1 : ik1, back ? p2 : ik2, back, c, o0, o1, o2);
 	}
 }
 
