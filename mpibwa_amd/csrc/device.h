@@ -48,6 +48,12 @@ void launch_smem(void *stream, const FmDev &fm, const SmemParams &sp, int n_read
                  unsigned long long *d_counters /* [0]=next read, [1]=blocks, [2]=overflow */,
                  void *d_scratch, size_t scratch_bytes_per_quad, int n_quads);
 int  smem_grid_quads(int max_len, size_t *scratch_per_quad);
+// lane-per-read variant (smem_lane.hip); same contract
+void launch_smem_lane(void *stream, const FmDev &fm, const SmemParams &sp, int n_reads, const uint8_t *d_seq,
+                      const int64_t *d_off, const int *d_len, int cap, uint64_t *d_out, int *d_nout,
+                      unsigned long long *d_counters, void *d_scratch, size_t scratch_bytes_per_lane, int n_lanes);
+int  smem_lane_grid(int max_len, size_t *scratch_per_lane);
+bool smem_use_lane();
 
 void launch_sa(void *stream, const FmDev &fm, int n, const uint64_t *d_k, uint64_t *d_out,
                unsigned long long *d_counters /* [0]=next task, [1]=steps */);

@@ -202,14 +202,16 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	uint64_t *d_intv; int *d_nintv;
 	unsigned long long cnt[8];
 	size_t per_quad = 0;
-	int n_quads = smem_grid_quads(max_len, &per_quad);
+	const bool lane_k = smem_use_lane();
+	int n_quads = lane_k ? smem_lane_grid(max_len, &per_quad) : smem_grid_quads(max_len, &per_quad);
 	void *d_scr = W.scratch.ensure(per_quad * n_quads);
 	for (;;) {
 		d_intv = (uint64_t *)W.intv.ensure((size_t)n * cap * 32);
 		d_nintv = (int *)W.nintv.ensure((size_t)n * 4);
 		HIP_OK(hipMemsetAsync(d_cnt, 0, 256, st));
 		ev_smem.start(st);
-		launch_smem(st, ix.fm, smem_params(opt), n, d_seq, d_off, d_len, cap, d_intv, d_nintv, max_len, d_cnt, d_scr, per_quad, n_quads);
+		if (lane_k) launch_smem_lane(st, ix.fm, smem_params(opt), n, d_seq, d_off, d_len, cap, d_intv, d_nintv, d_cnt, d_scr, per_quad, n_quads);
+		else launch_smem(st, ix.fm, smem_params(opt), n, d_seq, d_off, d_len, cap, d_intv, d_nintv, max_len, d_cnt, d_scr, per_quad, n_quads);
 		ev_smem.stop(st);
 		HIP_OK(hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, st));
 		HIP_OK(hipStreamSynchronize(st));
