@@ -190,6 +190,11 @@ int mi355x_smem_batch(const mem_opt_t *opt, int n, const uint8_t *seqs, const in
                       int cap, uint64_t *intv_out, int *n_out, double *kernel_ms, uint64_t *algo_bytes);
 /* Suffix-array lookup (bwt_sa, src/bwt.c:86-96) for n BWT rows. */
 int mi355x_sa_batch(int n, const uint64_t *k, uint64_t *sa_out, double *kernel_ms, uint64_t *algo_bytes);
+/* Same lookups answered from the dense SA that mi355x_index_upload() expands in HBM when memory allows
+ * (dense != 0; returns -1 if the table is absent), or by the LF walk (dense == 0). */
+int mi355x_sa_batch2(int n, const uint64_t *k, uint64_t *sa_out, double *kernel_ms, int dense);
+/* expansion time in ms (0 if not expanded) and, through *bytes, the size of the dense table */
+double mi355x_sa_dense_info(size_t *bytes);
 /* Banded extension (ksw_extend2, src/ksw.c:380-479) for n independent jobs.
  * q/t: concatenated nt4 bytes; per job 5 ints in out: score,qle,tle,gtle,gscore,max_off (6). */
 int mi355x_extend_batch(const mem_opt_t *opt, int n, const uint8_t *q, const int64_t *qoff,

@@ -16,7 +16,7 @@ libc.free.argtypes = [C.c_void_p]
 EXPORTS = [
     "mem_process_seqs", "mem_opt_init", "bwa_fill_scmat", "bwa_idx_load_from_disk", "bwa_mem2idx", "bwa_idx_destroy",
     "mi355x_index_upload", "mi355x_index_alloc", "mi355x_index_buffers", "mi355x_finalize", "mi355x_index_build", "mi355x_index_build_gpu",
-    "mi355x_smem_batch", "mi355x_sa_batch", "mi355x_extend_batch", "mi355x_last_stats", "mi355x_host_cpus", "mi355x_collect_sam", "mi355x_host_ksw_align2",
+    "mi355x_smem_batch", "mi355x_sa_batch", "mi355x_sa_batch2", "mi355x_sa_dense_info", "mi355x_extend_batch", "mi355x_last_stats", "mi355x_host_cpus", "mi355x_collect_sam", "mi355x_host_ksw_align2",
 ]
 
 
@@ -49,6 +49,8 @@ def load_library(build_if_missing=True):
     sig("mi355x_smem_batch", C.c_int, [P(abi.mem_opt_t), C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                        C.c_void_p, P(C.c_double), P(C.c_uint64)])
     sig("mi355x_sa_batch", C.c_int, [C.c_int, C.c_void_p, C.c_void_p, P(C.c_double), P(C.c_uint64)])
+    sig("mi355x_sa_batch2", C.c_int, [C.c_int, C.c_void_p, C.c_void_p, P(C.c_double), C.c_int])
+    sig("mi355x_sa_dense_info", C.c_double, [P(C.c_size_t)])
     sig("mi355x_extend_batch", C.c_int, [P(abi.mem_opt_t), C.c_int] + [C.c_void_p] * 8 + [P(C.c_double), P(C.c_uint64)])
     sig("mi355x_last_stats", None, [P(abi.mi355x_stats_t)])
     sig("mi355x_finalize", None, [])
@@ -130,6 +132,14 @@ class Engine:
         nbytes = C.c_uint64(0)
         self.lib.mi355x_sa_batch(len(ks), ks.ctypes.data, out.ctypes.data, C.byref(ms), C.byref(nbytes))
         return out, ms.value, nbytes.value
+
+    def sa_dense(self, ks):
+        """Lookups through the dense SA table (None if the table was not expanded)."""
+        ks = np.ascontiguousarray(ks, dtype=np.uint64)
+        out = np.zeros(len(ks), dtype=np.uint64)
+        ms = C.c_double(0)
+        rc = self.lib.mi355x_sa_batch2(len(ks), ks.ctypes.data, out.ctypes.data, C.byref(ms), 1)
+        return (out, ms.value) if rc == 0 else None
 
     def extend(self, opt, qs, ts, w, h0, end_bonus):
         n = len(qs)

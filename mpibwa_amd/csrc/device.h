@@ -13,6 +13,7 @@ namespace mbw {
 struct FmDev {
 	const void *blk;        // n_blk x 64 B
 	const uint64_t *sa;     // sampled SA, sa[0] = -1
+	const uint64_t *sa_full; // optional: SA value of EVERY row (seq_len+1 entries), expanded in HBM at upload; null if absent
 	uint64_t primary, seq_len;
 	uint64_t L2[5];
 	int sa_shift;           // log2(sa_intv)
@@ -25,6 +26,7 @@ struct DevIndex {
 	void *d_blk = nullptr; size_t blk_bytes = 0;
 	void *d_sa = nullptr;  size_t sa_bytes = 0;
 	void *d_pac = nullptr; size_t pac_bytes = 0;
+	void *d_sa_full = nullptr; size_t sa_full_bytes = 0; double sa_expand_ms = 0;
 	int64_t l_pac = 0;
 };
 DevIndex &dev_index();
@@ -57,6 +59,10 @@ bool smem_use_lane();
 
 void launch_sa(void *stream, const FmDev &fm, int n, const uint64_t *d_k, uint64_t *d_out,
                unsigned long long *d_counters /* [0]=next task, [1]=steps */);
+// dense-SA path: one 8-byte load per lookup from FmDev::sa_full
+void launch_sa_dense(void *stream, const FmDev &fm, int n, const uint64_t *d_k, uint64_t *d_out);
+// fill `full` (seq_len+1 entries) from the sampled SA by walking LF once over the whole text (seq_len steps in total)
+void launch_sa_expand(void *stream, const FmDev &fm, uint64_t *full, unsigned long long *d_counters);
 
 struct ExtParams {
 	int8_t mat[25];

@@ -67,7 +67,8 @@ static void alloc_index(const bwt_t *bwt, const bntseq_t *bns)
 	HIP_OK(hipMemset(g_idx.d_blk, 0, g_idx.blk_bytes));
 	HIP_OK(hipMemset(g_idx.d_pac, 0, g_idx.pac_bytes));
 	FmDev &fm = g_idx.fm;
-	fm.blk = g_idx.d_blk; fm.sa = (const uint64_t *)g_idx.d_sa;
+	fm.blk = g_idx.d_blk; fm.sa = (const uint64_t *)g_idx.d_sa; fm.sa_full = nullptr;
+	if (g_idx.d_sa_full) { (void)hipFree(g_idx.d_sa_full); g_idx.d_sa_full = nullptr; g_idx.sa_full_bytes = 0; }
 	fm.primary = bwt->primary; fm.seq_len = bwt->seq_len;
 	for (int i = 0; i < 5; ++i) fm.L2[i] = bwt->L2[i];
 	int sh = 0;
@@ -82,6 +83,32 @@ static void alloc_index(const bwt_t *bwt, const bntseq_t *bns)
 } // namespace mbw
 
 using namespace mbw;
+
+// Expand the sampled SA into a dense one when HBM allows it (MPIBWA_SA_DENSE=0 disables it).
+static void maybe_expand_sa()
+{
+	const char *e = getenv("MPIBWA_SA_DENSE");
+	if (e && atoi(e) == 0) return;
+	size_t need = (size_t)(g_idx.fm.seq_len + 1) * 8, free_b = 0, total_b = 0;
+	if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + (need >> 1) + ((size_t)8 << 30)) return;   // keep room for the batches
+	HIP_OK(hipMalloc(&g_idx.d_sa_full, need));
+	unsigned long long *d_cnt;
+	HIP_OK(hipMalloc(&d_cnt, 64));
+	HIP_OK(hipMemset(d_cnt, 0, 64));
+	hipEvent_t a, b;
+	HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b));
+	HIP_OK(hipEventRecord(a, 0));
+	launch_sa_expand(0, g_idx.fm, (uint64_t *)g_idx.d_sa_full, d_cnt);
+	HIP_OK(hipEventRecord(b, 0));
+	HIP_OK(hipEventSynchronize(b));
+	HIP_OK(hipGetLastError());
+	float ms = 0;
+	HIP_OK(hipEventElapsedTime(&ms, a, b));
+	g_idx.sa_expand_ms = ms;
+	g_idx.sa_full_bytes = need;
+	g_idx.fm.sa_full = (const uint64_t *)g_idx.d_sa_full;
+	(void)hipFree(d_cnt); (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+}
 
 extern "C" int mi355x_index_alloc(int local_rank, const bwt_t *bwt, const bntseq_t *bns)
 {
@@ -98,10 +125,12 @@ extern "C" int mi355x_index_upload(int local_rank, const bwt_t *bwt, const bntse
 	HIP_OK(hipMemcpy(g_idx.d_blk, bwt->bwt, (size_t)bwt->bwt_size * 4, hipMemcpyHostToDevice));
 	HIP_OK(hipMemcpy(g_idx.d_sa, bwt->sa, g_idx.sa_bytes, hipMemcpyHostToDevice));
 	HIP_OK(hipMemcpy(g_idx.d_pac, pac, (size_t)bns->l_pac / 4 + 1, hipMemcpyHostToDevice));
+	maybe_expand_sa();
 	g_idx.ready = true;
 	return 0;
 }
 
+extern "C" int mi355x_sa_batch(int n, const uint64_t *k, uint64_t *sa_out, double *kernel_ms, uint64_t *algo_bytes);
 extern "C" int mi355x_index_buffers(void **d_bwt, size_t *bwt_bytes, void **d_sa, size_t *sa_bytes, void **d_pac,
                                     size_t *pac_bytes)
 {
@@ -115,6 +144,7 @@ extern "C" int mi355x_index_buffers(void **d_bwt, size_t *bwt_bytes, void **d_sa
 extern "C" void mi355x_finalize(void)
 {
 	if (g_idx.d_blk) { (void)hipFree(g_idx.d_blk); (void)hipFree(g_idx.d_sa); (void)hipFree(g_idx.d_pac); }
+	if (g_idx.d_sa_full) (void)hipFree(g_idx.d_sa_full);
 	g_idx = DevIndex();
 }
 
@@ -223,6 +253,28 @@ extern "C" int mi355x_smem_batch(const mem_opt_t *opt, int n, const uint8_t *seq
 	if (algo_bytes) *algo_bytes = cnt[1] * 64 + total + n_intv * 32;   // 64 B per occ block + read + output
 	return cnt[2] ? -1 : 0;
 }
+
+// dense != 0: answer from the expanded table (fails if it is absent); dense == 0: LF walk on the sampled SA
+extern "C" int mi355x_sa_batch2(int n, const uint64_t *k, uint64_t *sa_out, double *kernel_ms, int dense)
+{
+	need_index();
+	if (!dense) return mi355x_sa_batch(n, k, sa_out, kernel_ms, nullptr);
+	if (!g_idx.fm.sa_full) return -1;
+	if (n <= 0) return 0;
+	uint64_t *d_k, *d_o;
+	HIP_OK(hipMalloc(&d_k, (size_t)n * 8)); HIP_OK(hipMalloc(&d_o, (size_t)n * 8));
+	HIP_OK(hipMemcpy(d_k, k, (size_t)n * 8, hipMemcpyHostToDevice));
+	Timer tm;
+	tm.start(0);
+	launch_sa_dense(0, g_idx.fm, n, d_k, d_o);
+	double ms = tm.stop(0);
+	HIP_OK(hipGetLastError());
+	HIP_OK(hipMemcpy(sa_out, d_o, (size_t)n * 8, hipMemcpyDeviceToHost));
+	(void)hipFree(d_k); (void)hipFree(d_o);
+	if (kernel_ms) *kernel_ms = ms;
+	return 0;
+}
+extern "C" double mi355x_sa_dense_info(size_t *bytes) { if (bytes) *bytes = g_idx.sa_full_bytes; return g_idx.sa_expand_ms; }
 
 extern "C" int mi355x_sa_batch(int n, const uint64_t *k, uint64_t *sa_out, double *kernel_ms, uint64_t *algo_bytes)
 {

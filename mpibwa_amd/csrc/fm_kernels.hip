@@ -420,6 +420,89 @@ void launch_sa(void *stream, const FmDev &fm, int n, const uint64_t *d_k, uint64
 }
 
 // ---------------------------------------------------------------------------
+// Dense suffix array.  288 GB of HBM hold the SA value of every row (50 GB for GRCh38), so a lookup becomes one
+// 8-byte load instead of a ~31-step LF walk.  The table is expanded on the device from the sampled SA: LF maps the
+// row of suffix i to the row of suffix i-1, so walking LF from every sampled row until the next sampled row visits
+// each row exactly once (seq_len steps in total) and assigns SA = start value - steps.  Values are what bwt_sa()
+// returns (src/bwt.c:86-96), including its sa[0] = -1 convention, so results are bit-identical to the walk.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(SA_BLOCK)
+sa_expand_kernel(FmDev fm, u64 n_samples, u64 *__restrict__ full, u64 *counters)
+{
+	const int lane = threadIdx.x & 63, c = lane & 3, qlead = lane & ~3;
+	const uint4 *blk = (const uint4 *)fm.blk;
+	const u64 mask = ((u64)1 << fm.sa_shift) - 1;
+	bool done = false, have = false;
+	u64 k = 0, v = 0;
+	for (;;) {
+		while (!done && !have) {
+			u64 t = 0;
+			if (c == 0) t = atomicAdd(&counters[0], 1ull);
+			t = __shfl(t, qlead);
+			if (t >= n_samples) { done = true; break; }
+			k = t << fm.sa_shift;
+			v = t == 0 ? fm.seq_len : fm.sa[t];          // row 0 is the '$' suffix: true value seq_len (stored as -1)
+			if (c == 0) full[k] = t == 0 ? ~0ull : v;
+			have = true;
+		}
+		if (__ballot(!done) == 0) break;
+		if (!done) {
+			// one LF step (same arithmetic as sa_kernel)
+			if (k == fm.primary) k = 0;
+			else {
+				u64 x = k - (k > fm.primary);
+				uint4 vv = blk[(x >> 7) * 4 + c];
+				int wi = (int)(x & 127) >> 4;
+				u32 mine = (wi & 3) == 0 ? vv.x : (wi & 3) == 1 ? vv.y : (wi & 3) == 2 ? vv.z : vv.w;
+				u32 word = __shfl(mine, qlead | (2 + (wi >> 2)));
+				int sym = (word >> ((~(u32)x & 15) << 1)) & 3;
+				u64 part = 0;
+				if (c >= 2) {
+					const u32 pat = 0x55555555u * (u32)sym;
+					const int kk = (int)(x & 127) + 1 - (c == 3 ? 64 : 0);
+					u32 w4[4] = {vv.x, vv.y, vv.z, vv.w};
+					u32 cnt = 0;
+#pragma unroll
+					for (int i2 = 0; i2 < 4; ++i2) {
+						int m = kk - 16 * i2;
+						m = m < 0 ? 0 : (m > 16 ? 16 : m);
+						u32 msk = (u32)(0xFFFFFFFF00000000ull >> (2 * m));
+						u32 y = ~(w4[i2] ^ pat);
+						cnt += __popc(y & (y >> 1) & 0x55555555u & msk);
+					}
+					part = cnt;
+				} else if (c == (sym >> 1)) {
+					part = (sym & 1) ? ((u64)vv.w << 32 | vv.z) : ((u64)vv.y << 32 | vv.x);
+				}
+				part += dpp64<QP(1, 0, 3, 2)>(part);
+				part += dpp64<QP(2, 3, 0, 1)>(part);
+				k = fm.L2[sym] + part;
+			}
+			--v;
+			if ((k & mask) == 0) have = false;           // reached the next sampled row: its own walk covers the rest
+			else if (c == 0) full[k] = v;
+		}
+	}
+}
+
+__global__ void sa_dense_kernel(const u64 *__restrict__ full, int n, const u64 *__restrict__ ks, u64 *__restrict__ out)
+{
+	int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t < n) out[t] = full[ks[t]];
+}
+
+void launch_sa_expand(void *stream, const FmDev &fm, uint64_t *full, unsigned long long *d_counters)
+{
+	u64 n_samples = (fm.seq_len + ((u64)1 << fm.sa_shift)) >> fm.sa_shift;
+	hipLaunchKernelGGL(sa_expand_kernel, dim3(256 * 8), dim3(SA_BLOCK), 0, (hipStream_t)stream, fm, n_samples, (u64 *)full, (u64 *)d_counters);
+}
+void launch_sa_dense(void *stream, const FmDev &fm, int n, const uint64_t *d_k, uint64_t *d_out)
+{
+	hipLaunchKernelGGL(sa_dense_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const u64 *)fm.sa_full, n, (const u64 *)d_k,
+	                   (u64 *)d_out);
+}
+
+// ---------------------------------------------------------------------------
 // Seed enumeration: one thread per read (tiny integer work, L2-resident data).
 // ---------------------------------------------------------------------------
 __global__ void seed_prep_kernel(int n_reads, int cap, u64 *intv, const int *__restrict__ nintv, int max_occ,

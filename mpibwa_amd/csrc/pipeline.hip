@@ -249,7 +249,8 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		if (S > 0x7fffffff) die("too many seeds in one batch");
 		HIP_OK(hipMemsetAsync(d_cnt, 0, 256, st));
 		ev_sa.start(st);
-		launch_sa(st, ix.fm, (int)S, d_rows, d_sa, d_cnt);
+		if (ix.fm.sa_full) launch_sa_dense(st, ix.fm, (int)S, d_rows, d_sa);   // one 8-byte load per row
+		else launch_sa(st, ix.fm, (int)S, d_rows, d_sa, d_cnt);                // LF walk on the sampled SA
 		ev_sa.stop(st);
 		HIP_OK(hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, st));
 		HIP_OK(hipMemcpyAsync(sa.data(), d_sa, (size_t)S * 8, hipMemcpyDeviceToHost, st));
@@ -257,7 +258,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		HIP_OK(hipStreamSynchronize(st));
 		HIP_OK(hipGetLastError());
 		g_stats.k_sa_ms = ev_sa.ms();
-		g_stats.sa_bytes = cnt[1] * 64 + (uint64_t)S * 8;
+		g_stats.sa_bytes = ix.fm.sa_full ? (uint64_t)S * 16 : cnt[1] * 64 + (uint64_t)S * 8;
 	}
 	double t3 = now_ms();
 

@@ -65,6 +65,27 @@ def test_sa_kernel_matches_oracle(engine, genome):
     assert nbytes == fm.fm.n_sa_steps * 64 + 8 * len(ks)
 
 
+def test_dense_sa_matches_walk_and_oracle(engine, genome):
+    """The SA table expanded in HBM must return exactly what the LF walk (and the oracle) returns, for every row class."""
+    fm = po.OracleFM(genome["prefix"])
+    n = int(fm.fm.seq_len)
+    rng = np.random.default_rng(10)
+    ks = np.concatenate([rng.integers(1, n + 1, size=30000).astype(np.uint64),
+                         np.array([1, fm.fm.primary, fm.fm.primary + 1, n, 32, 64, n - 1], dtype=np.uint64)])
+    res = engine.sa_dense(ks)
+    assert res is not None, "dense SA was not expanded at upload"
+    dense, _ = res
+    walk, _, _ = engine.sa(ks)
+    assert (dense == walk).all()
+    want = np.array([fm.sa_lookup(int(k)) for k in ks[:3000]], dtype=np.uint64)
+    assert (dense[:3000] == want).all()
+    # exhaustive on a slice of rows: every row, not a sample
+    rows = np.arange(1, 70000, dtype=np.uint64)
+    d2, _ = engine.sa_dense(rows)
+    w2, _, _ = engine.sa(rows)
+    assert (d2 == w2).all()
+
+
 def _rand_pair(rng, qlen, div):
     q = rng.integers(0, 4, size=qlen, dtype=np.uint8)
     out = []
