@@ -88,8 +88,10 @@ __device__ __forceinline__ WxResult wave_extend(int qlen, QF qf, int tlen, TF tf
 		if (end > qlen) end = qlen;
 		int hleft0 = 0;
 		if (beg == 0) { hleft0 = h0 - (P.o_del + e_del * (i + 1)); if (hleft0 < 0) hleft0 = 0; }
-		int rowmax = 0, rowmax_j = -1;
+		int rowkey = -1;                           // (row maximum) << 13 | its largest column
 		int A = beg * e_ins;                       // F(i,beg) = 0
+		int h_carry = 0, h_last = hleft0;          // h of column 64*s-1; H[end] after the row
+		int first_nz = end, last_nz = -1;          // first / last cell of [beg,end] with H or E non-zero after the row
 		if (beg < end) {
 			const int s0 = beg >> 6, s1 = (end - 1) >> 6;
 			int diag0 = H[s0 << 6];                // pre-read of the strip's first cell (see below)
@@ -115,25 +117,37 @@ __device__ __forceinline__ WxResult wave_extend(int qlen, QF qf, int tlen, TF tf
 				if (j == beg) H[j] = hleft0;
 				if (act) { H[j + 1] = h; E[j] = en; }
 				A = max(A, __builtin_amdgcn_readlane(incl, 63) + e_ins);
-				// row maximum, largest column wins ties
-				int hv = act ? h : -1;
-				int red = wx_scan_max(hv);
-				int smax = __builtin_amdgcn_readlane(red, 63);
-				if (smax >= rowmax) {
-					unsigned long long bal = __ballot(act && h == smax);
-					if (bal) { rowmax = smax; rowmax_j = (s << 6) + 63 - __clzll(bal); }
+				// row maximum; the largest column wins ties: one max-scan over (h << 13 | column)
+				const int kmax = __builtin_amdgcn_readlane(wx_scan_max(act ? (h << 13 | j) : -1), 63);
+				rowkey = kmax > rowkey ? kmax : rowkey;
+				// cells of this strip that are non-zero after the row: H[c] = h of column c-1, E[c] = en of column c
+				const unsigned long long bh = __ballot(act && h != 0), be = __ballot(act && en != 0);
+				unsigned long long nz = (bh << 1) | be;
+				if (h_carry != 0 && (s << 6) > beg) nz |= 1ull;
+				if ((beg >> 6) == s && hleft0 != 0) nz |= 1ull << (beg & 63);
+				if (nz) {
+					const int lo = (s << 6) + __ffsll((long long)nz) - 1, hi = (s << 6) + 63 - __clzll(nz);
+					if (lo < end && lo < first_nz) first_nz = lo;
+					if (hi > last_nz) last_nz = hi;
 				}
+				h_carry = __builtin_amdgcn_readlane(h, 63);
+				if (s == s1) h_last = __builtin_amdgcn_readlane(h, (end - 1) & 63);
 			}
+			if ((end & 63) == 0 && h_carry != 0 && end > last_nz) last_nz = end;   // cell `end` opens the next strip
 			cells += (unsigned long long)(end - beg);
-		} else if (lane == 0) H[end] = hleft0;     // empty range: eh[end].h = h1 (src/ksw.c:447)
+		} else {
+			if (lane == 0) H[end] = hleft0;        // empty range: eh[end].h = h1 (src/ksw.c:447)
+			if (hleft0 != 0) last_nz = end;
+		}
 		if (lane == 0) E[end] = 0;
 		__builtin_amdgcn_wave_barrier();
-		const int h1 = H[end];
+		const int h1 = h_last;
 		const int jfin = beg < end ? end : beg;    // value of the reference's column counter after its loop
 		if (jfin == qlen) {
 			if (h1 >= gscore) best_ie = i;
 			if (h1 > gscore) gscore = h1;
 		}
+		const int rowmax = rowkey < 0 ? 0 : rowkey >> 13, rowmax_j = rowkey < 0 ? -1 : rowkey & 8191;
 		if (rowmax == 0) break;
 		if (rowmax > best) {
 			best = rowmax; best_i = i; best_j = rowmax_j;
@@ -144,22 +158,10 @@ __device__ __forceinline__ WxResult wave_extend(int qlen, QF qf, int tlen, TF tf
 			if (di > dj) { if (best - rowmax - (di - dj) * e_del > P.zdrop) break; }
 			else { if (best - rowmax - (dj - di) * e_ins > P.zdrop) break; }
 		}
-		// live range of the next row: first / last cell of [beg,end] with H or E non-zero
-		if (beg > end) beg = end;                  // (unreachable in practice; keeps the scans in bounds)
-		int nb = end;
-		for (int s = beg >> 6; s <= (end - 1) >> 6 && nb == end && beg < end; ++s) {
-			const int j = (s << 6) + lane;
-			bool nz = j >= beg && j < end && (H[j] != 0 || E[j] != 0);
-			unsigned long long bal = __ballot(nz);
-			if (bal) nb = (s << 6) + __ffsll((long long)bal) - 1;
-		}
-		int ne = nb - 1;                           // value of j when the downward scan finds nothing
-		for (int s = end >> 6; s >= nb >> 6; --s) {
-			const int j = (s << 6) + lane;
-			bool nz = j >= nb && j <= end && (H[j] != 0 || E[j] != 0);
-			unsigned long long bal = __ballot(nz);
-			if (bal) { ne = (s << 6) + 63 - __clzll(bal); break; }
-		}
+		// live range of the next row (src/ksw.c:466-469): first non-zero cell of [beg,end) (else end), then the last
+		// non-zero cell of [that,end] (else one before it)
+		const int nb = first_nz;
+		const int ne = last_nz >= nb ? last_nz : nb - 1;
 		beg = nb;
 		end = ne + 2 < qlen ? ne + 2 : qlen;
 	}

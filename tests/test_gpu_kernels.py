@@ -112,7 +112,8 @@ def test_extend_kernel_matches_oracle(engine):
     rng = np.random.default_rng(21)
     qs, ts, ws, h0s, ebs = [], [], [], [], []
     for it in range(3000):
-        qlen = int(rng.choice([1, 2, 17, 63, 64, 65, 127, 128, 129, 131, 150, 231, 300, int(rng.integers(1, 320))]))
+        qlen = int(rng.choice([1, 2, 17, 63, 64, 65, 126, 127, 128, 129, 131, 150, 190, 191, 192, 193, 231, 300, 319, 320, 321, 400, 640,
+                                   int(rng.integers(1, 330))]))
         q, t = _rand_pair(rng, qlen, float(rng.choice([0.0, 0.01, 0.05, 0.15, 0.4])))
         if rng.random() < 0.1:
             q[rng.integers(0, qlen)] = 4
