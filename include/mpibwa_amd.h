@@ -207,6 +207,8 @@ typedef struct {
 	double k_smem_ms, k_sa_ms, k_ext_ms;        /* HIP-event kernel times */
 	uint64_t smem_bytes, sa_bytes, ext_cells;    /* algorithmic work counted on device */
 	uint64_t n_reads, n_intv, n_seeds, n_chains, n_ext;
+	double plan_ms, aln_ms, k_aln_ms;            /* SAM stage: decisions+collect, CIGAR kernel round trip, its HIP-event time */
+	uint64_t n_aln;
 } mi355x_stats_t;
 void mi355x_last_stats(mi355x_stats_t *st);
 

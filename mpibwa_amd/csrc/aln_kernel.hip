@@ -1,0 +1,286 @@
+// aln_kernel.hip — final global re-alignment (CIGAR + NM + MD) of alignment regions on the device.
+//
+// Device counterpart of the DP part of mem_reg2aln (src/bwamem.c:1106-1122): bwa_gen_cigar2 (src/bwa.c:121-207)
+// = fetch of the reference window (src/bntseq.c:398-419), banded global alignment with traceback
+// (ksw_global2, src/ksw.c:504-606) under mem_reg2aln's band-doubling loop, and the NM / MD walk.
+// One wavefront per region.  Rows are sequential, lanes run across the band columns; the F recurrence
+// F(i,j+1) = max(F(i,j), M(i,j) - o_ins) - e_ins depends on M only, so it is the same max-plus prefix scan as in
+// wave_ext.cuh.  The direction bytes live in LDS; the traceback and the MD walk are wave-uniform scalar loops over
+// LDS (cheap because thousands of wavefronts do theirs concurrently).  Regions whose band matrix does not fit the
+// LDS budget are flagged and re-done by the host (rare: long gaps).
+#include <hip/hip_runtime.h>
+#include "device.h"
+#include "wave_ext.cuh"
+
+namespace mbw {
+
+#define ALN_WAVES 4
+#define ALN_ZCAP 12288       // direction bytes per wavefront
+#define ALN_MDCAP 768
+#define ALN_CIGCAP 96
+#define ALN_NEG (-0x40000000)
+
+__device__ __forceinline__ int wave_sum_int(int v)
+{
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+	return v;
+}
+
+struct AlnLds {
+	int *H, *E;
+	uint8_t *q, *t, *z, *md;
+	uint32_t *cig;
+};
+
+// decimal digits of v (v >= 0) appended at md[len...]; every lane runs it, lane 0 stores
+__device__ __forceinline__ int put_num(uint8_t *md, int len, int v, int lane)
+{
+	char buf[12];
+	int n = 0;
+	if (v == 0) buf[n++] = '0';
+	while (v > 0) { buf[n++] = '0' + v % 10; v /= 10; }
+	if (lane == 0)
+		for (int k = 0; k < n; ++k)
+			if (len + k < ALN_MDCAP) md[len + k] = buf[n - 1 - k];
+	return len + n;
+}
+
+__global__ void __launch_bounds__(64 * ALN_WAVES)
+aln_kernel(AlnParams P, WxParams X, int n_req, const AlnReq *__restrict__ reqs, const uint8_t *__restrict__ seq,
+           const int64_t *__restrict__ off, const uint8_t *__restrict__ pac, const int *__restrict__ gaptab, AlnHdr *__restrict__ hdr,
+           uint8_t *__restrict__ pool, unsigned long long *counters, unsigned long long pool_bytes, int max_len, int tcap)
+{
+	extern __shared__ int lds_raw[];
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int rq = blockIdx.x * ALN_WAVES + wave;
+	if (rq >= n_req) return;
+	// carve this wavefront's LDS
+	const size_t per_wave = (size_t)2 * (max_len + 2) * 4 + ((max_len + 3) & ~3) + ((tcap + 3) & ~3) + ALN_ZCAP + ALN_MDCAP + ALN_CIGCAP * 4;
+	uint8_t *base = (uint8_t *)lds_raw + (size_t)wave * per_wave;
+	AlnLds L;
+	L.H = (int *)base; L.E = L.H + (max_len + 2);
+	L.cig = (uint32_t *)(L.E + (max_len + 2));
+	L.q = (uint8_t *)(L.cig + ALN_CIGCAP);
+	L.t = L.q + ((max_len + 3) & ~3);
+	L.z = L.t + ((tcap + 3) & ~3);
+	L.md = L.z + ALN_ZCAP;
+
+	const AlnReq R = reqs[rq];
+	const int lq = R.qe - R.qb;
+	const long long rlen64 = R.re - R.rb;
+	AlnHdr out;
+	out.score = 0; out.NM = -1; out.n_cigar = 0; out.md_len = 0; out.pool_off = 0; out.flags = 0;
+	const bool bridging = R.rb < P.l_pac && R.re > P.l_pac;
+	if (lq <= 0 || rlen64 <= 0 || bridging || lq > max_len || rlen64 > tcap) {
+		out.flags = 1;   // host fallback (also reproduces the reference's rejection cases)
+		if (lane == 0) hdr[rq] = out;
+		return;
+	}
+	const int rlen = (int)rlen64;
+	const bool rev = R.rb >= P.l_pac;
+	const uint8_t *rd = seq + off[R.read];
+	// stage the (possibly reversed) query and the reference window: on the reverse strand both are flipped so that
+	// gaps end up left-aligned on the forward strand (src/bwa.c:136-141)
+	for (int j = lane; j < lq; j += 64) L.q[j] = rev ? rd[R.qe - 1 - j] : rd[R.qb + j];
+	{
+		const long long f0 = rev ? (P.l_pac << 1) - R.re : R.rb;   // forward-strand start of the window
+		for (int i = lane; i < rlen; i += 64) {
+			long long f = f0 + i;
+			int b = (pac[f >> 2] >> ((~f & 3) << 1)) & 3;
+			L.t[i] = rev ? 3 - b : b;
+		}
+	}
+	__builtin_amdgcn_wave_barrier();
+
+	const int oe_del = X.o_del + X.e_del, oe_ins = X.o_ins + X.e_ins, e_del = X.e_del, e_ins = X.e_ins;
+	const int wmax4 = P.w << 2;
+	int w2 = R.w2, last_sc = -(1 << 30), score = 0, n_cig = 0;
+	bool fallback = false;
+	for (int it = 0;; ) {
+		w2 = w2 < wmax4 ? w2 : wmax4;
+		if (lq == rlen && w2 == 0) {   // ungapped: no DP (src/bwa.c:143-151)
+			int s = 0;
+			for (int i = lane; i < lq; i += 64) s += X.mat[L.t[i] * 5 + L.q[i]];
+			score = wave_sum_int(s);
+			n_cig = 1;
+			if (lane == 0) L.cig[0] = (uint32_t)lq << 4;
+		} else {
+			int d_len = rlen - lq; d_len = d_len < 0 ? -d_len : d_len;
+			int w = (gaptab[lq] + d_len + 1) >> 1;
+			w = w < w2 ? w : w2;
+			const int min_w = d_len + 3;
+			w = w > min_w ? w : min_w;
+			const int n_col = lq < 2 * w + 1 ? lq : 2 * w + 1;
+			if ((long long)n_col * rlen > ALN_ZCAP) { fallback = true; break; }
+			// ---- banded global DP (src/ksw.c:523-589) ----
+			for (int j = lane; j <= lq; j += 64) {
+				L.H[j] = j == 0 ? 0 : (j <= w ? -(X.o_ins + e_ins * j) : ALN_NEG);
+				L.E[j] = ALN_NEG;
+			}
+			__builtin_amdgcn_wave_barrier();
+			for (int i = 0; i < rlen; ++i) {
+				const int tb = L.t[i];
+				const int m0 = X.mat[tb * 5 + 0], m1 = X.mat[tb * 5 + 1], m2 = X.mat[tb * 5 + 2], m3 = X.mat[tb * 5 + 3], m4 = X.mat[tb * 5 + 4];
+				const int beg = i > w ? i - w : 0, end = i + w + 1 < lq ? i + w + 1 : lq;
+				const int hleft0 = beg == 0 ? -(X.o_del + e_del * (i + 1)) : ALN_NEG;
+				int A = ALN_NEG;   // running max of g_k + e_ins over the columns already done (F(i,beg) = -inf)
+				uint8_t *zi = L.z + (size_t)i * n_col;
+				if (beg < end) {
+					const int s0 = beg >> 6, s1 = (end - 1) >> 6;
+					int diag0 = L.H[s0 << 6];
+					for (int s = s0; s <= s1; ++s) {
+						const int j = (s << 6) + lane;
+						const bool act = j >= beg && j < end;
+						int diag = lane == 0 ? diag0 : (j <= lq ? L.H[j] : 0);
+						int e = j <= lq ? L.E[j] : 0;
+						const int nxt = (s + 1) << 6;
+						if (nxt <= lq) diag0 = L.H[nxt];
+						const int qb = act ? (int)L.q[j] : 4;
+						const int sc = qb == 0 ? m0 : qb == 1 ? m1 : qb == 2 ? m2 : qb == 3 ? m3 : m4;
+						const int m = diag + sc;
+						const int g = act ? m - oe_ins + j * e_ins : ALN_NEG - (1 << 28);
+						const int incl = wx_scan_max_id(g, ALN_NEG - (1 << 28));
+						const int excl = wx_dpp<0x138, 0xf>(ALN_NEG - (1 << 28), incl);
+						int f = max(A, excl + e_ins) - j * e_ins;     // F(i,j)
+						uint8_t d = m >= e ? 0 : 1;
+						int h = m >= e ? m : e;
+						if (h < f) { d = 2; h = f; }
+						int t = m - oe_del;
+						int e2 = e - e_del;
+						if (e2 > t) d |= 1 << 2; else e2 = t;
+						t = m - oe_ins;
+						if (f - e_ins > t) d |= 2 << 4;
+						if (j == beg) L.H[j] = hleft0;
+						if (act) { L.H[j + 1] = h; L.E[j] = e2; zi[j - beg] = d; }
+						A = max(A, __builtin_amdgcn_readlane(incl, 63) + e_ins);
+					}
+				} else if (lane == 0) L.H[end] = hleft0;
+				if (lane == 0) L.E[end] = ALN_NEG;
+				__builtin_amdgcn_wave_barrier();
+			}
+			score = L.H[lq];
+			// ---- traceback (src/ksw.c:590-603): wave-uniform walk, lane 0 stores ----
+			{
+				int which = 0, i = rlen - 1, k = (i + w + 1 < lq ? i + w + 1 : lq) - 1, n = 0;
+				uint32_t cur = 0;   // current run: len << 4 | op, built from the end of the alignment
+				bool ovf = false;
+				auto push = [&](uint32_t op, uint32_t len) {
+					if (cur && (cur & 0xf) == op) cur += len << 4;
+					else {
+						if (cur) { if (n < ALN_CIGCAP) { if (lane == 0) L.cig[n] = cur; } else ovf = true; ++n; }
+						cur = len << 4 | op;
+					}
+				};
+				while (i >= 0 && k >= 0) {
+					which = L.z[(size_t)i * n_col + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
+					if (which == 0) { push(0, 1); --i; --k; }
+					else if (which == 1) { push(2, 1); --i; }
+					else { push(1, 1); --k; }
+				}
+				if (i >= 0) push(2, i + 1);
+				if (k >= 0) push(1, k + 1);
+				if (cur) { if (n < ALN_CIGCAP) { if (lane == 0) L.cig[n] = cur; } else ovf = true; ++n; }
+				if (ovf) { fallback = true; break; }
+				__builtin_amdgcn_wave_barrier();
+				// reverse into alignment order
+				for (int a = lane; a < n / 2; a += 64) { uint32_t x = L.cig[a]; L.cig[a] = L.cig[n - 1 - a]; L.cig[n - 1 - a] = x; }
+				__builtin_amdgcn_wave_barrier();
+				n_cig = n;
+			}
+		}
+		if (score == last_sc || w2 == wmax4) break;   // src/bwamem.c:1118
+		last_sc = score;
+		w2 <<= 1;
+		if (!(++it < 3 && score < R.truesc - P.a)) break;
+	}
+	if (fallback) {
+		out.flags = 1;
+		if (lane == 0) hdr[rq] = out;
+		return;
+	}
+	// ---- NM and MD (src/bwa.c:168-199) ----
+	int md_len = 0, n_mm = 0, n_gap = 0;
+	{
+		const char *int2base = rev ? "TGCAN" : "ACGTN";
+		int x = 0, y = 0, u = 0;
+		for (int k = 0; k < n_cig; ++k) {
+			const uint32_t c = L.cig[k];
+			const int op = c & 0xf, len = (int)(c >> 4);
+			if (op == 0) {
+				for (int i0 = 0; i0 < len; i0 += 64) {
+					const int i = i0 + lane;
+					unsigned long long mm = __ballot(i < len && L.q[x + i] != L.t[y + i]);
+					int cur = 0;                      // positions of this chunk already accounted for
+					const int chunk = len - i0 < 64 ? len - i0 : 64;
+					while (mm) {
+						const int p = __ffsll((long long)mm) - 1;
+						mm &= mm - 1;
+						u += p - cur;
+						md_len = put_num(L.md, md_len, u, lane);
+						if (lane == 0 && md_len < ALN_MDCAP) L.md[md_len] = int2base[L.t[y + i0 + p]];
+						++md_len; ++n_mm; u = 0; cur = p + 1;
+					}
+					u += chunk - cur;
+				}
+				x += len; y += len;
+			} else if (op == 2) {
+				if (k > 0 && k < n_cig - 1) {
+					md_len = put_num(L.md, md_len, u, lane);
+					if (lane == 0 && md_len < ALN_MDCAP) L.md[md_len] = '^';
+					++md_len;
+					for (int i = lane; i < len; i += 64)
+						if (md_len + i < ALN_MDCAP) L.md[md_len + i] = int2base[L.t[y + i]];
+					md_len += len;
+					u = 0; n_gap += len;
+				}
+				y += len;
+			} else { x += len; n_gap += len; }
+		}
+		md_len = put_num(L.md, md_len, u, lane);
+	}
+	if (md_len > ALN_MDCAP) {
+		out.flags = 1;
+		if (lane == 0) hdr[rq] = out;
+		return;
+	}
+	__builtin_amdgcn_wave_barrier();
+	// ---- hand the record over: [cigar u32 x n][md bytes] in the pool ----
+	const unsigned need = (unsigned)n_cig * 4 + (((unsigned)md_len + 3) & ~3u);
+	unsigned long long at = 0;
+	if (lane == 0) at = atomicAdd(&counters[0], (unsigned long long)need);
+	at = __shfl(at, 0);
+	if (at + need > pool_bytes) {
+		out.flags = 1;
+		if (lane == 0) hdr[rq] = out;
+		return;
+	}
+	uint32_t *pc = (uint32_t *)(pool + at);
+	for (int k = lane; k < n_cig; k += 64) pc[k] = L.cig[k];
+	uint8_t *pm = pool + at + (size_t)n_cig * 4;
+	for (int k = lane; k < md_len; k += 64) pm[k] = L.md[k];
+	out.score = score; out.NM = n_mm + n_gap; out.n_cigar = n_cig; out.md_len = md_len; out.pool_off = (uint32_t)(at >> 2); out.flags = 0;
+	if (lane == 0) hdr[rq] = out;
+}
+
+size_t aln_lds_per_block(int max_len, int tcap)
+{
+	size_t per_wave = (size_t)2 * (max_len + 2) * 4 + ((max_len + 3) & ~3) + ((tcap + 3) & ~3) + ALN_ZCAP + ALN_MDCAP + ALN_CIGCAP * 4;
+	return per_wave * ALN_WAVES;
+}
+
+void launch_aln(void *stream, const AlnParams &P, const ExtParams &ep, int n_req, const AlnReq *d_req, const uint8_t *d_seq,
+                const int64_t *d_off, const uint8_t *d_pac, const int *d_gaptab, AlnHdr *d_hdr, uint8_t *d_pool,
+                unsigned long long *d_counters, size_t pool_bytes, int max_len, int tcap)
+{
+	WxParams X;
+	for (int i = 0; i < 25; ++i) X.mat[i] = ep.mat[i];
+	X.o_del = ep.o_del; X.e_del = ep.e_del; X.o_ins = ep.o_ins; X.e_ins = ep.e_ins; X.zdrop = ep.zdrop;
+	size_t shmem = aln_lds_per_block(max_len, tcap);
+	int n_blocks = (n_req + ALN_WAVES - 1) / ALN_WAVES;
+	if (shmem > 64 * 1024 && hipFuncSetAttribute((const void *)aln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)
+		die("aln_kernel: cannot reserve %zu bytes of LDS", shmem);
+	hipLaunchKernelGGL(aln_kernel, dim3(n_blocks), dim3(64 * ALN_WAVES), shmem, (hipStream_t)stream, P, X, n_req, d_req, d_seq, d_off, d_pac,
+	                   d_gaptab, d_hdr, d_pool, d_counters, (unsigned long long)pool_bytes, max_len, tcap);
+}
+
+} // namespace mbw

@@ -95,6 +95,21 @@ void launch_c2a(void *stream, const C2aParams &P, const ExtParams &ep, int n_rea
                 DevReg *d_regs, int *d_nregs, const int *d_tab, int tab_stride, const uint8_t *d_pac, unsigned long long *d_counters,
                 int max_len);
 
+// ---- final global re-alignment on the device (aln_kernel.hip) ----
+struct AlnReq {                  // one call of mem_reg2aln's DP loop (src/bwamem.c:1106-1122)
+	int64_t rb, re;
+	int32_t read, qb, qe, w2, truesc, pad;
+};
+struct AlnHdr {                  // result header; cigar (n_cigar x u32) and MD (md_len bytes) sit at pool[4 * pool_off]
+	int32_t score, NM, n_cigar, md_len;
+	uint32_t pool_off;
+	int32_t flags;               // 1 = not done on the device (band matrix too large / caps): the host recomputes it
+};
+struct AlnParams { int64_t l_pac; int a, w; };
+void launch_aln(void *stream, const AlnParams &P, const ExtParams &ep, int n_req, const AlnReq *d_req, const uint8_t *d_seq,
+                const int64_t *d_off, const uint8_t *d_pac, const int *d_gaptab, AlnHdr *d_hdr, uint8_t *d_pool,
+                unsigned long long *d_counters, size_t pool_bytes, int max_len, int tcap);
+
 // ---- seed enumeration between SMEM and SA lookup (fm_kernels.hip) ----
 // per read: sort intervals by info, l_rep (src/bwamem.c:265-272) and the number of SA rows to look up
 void launch_seed_prep(void *stream, int n_reads, int cap, uint64_t *d_intv, const int *d_nintv, int max_occ, int *d_nseeds, int *d_lrep);

@@ -48,6 +48,30 @@ struct HAln {            // mem_aln_t, src/bwamem.h:87-98 (cigar + MD kept as se
 
 struct KswResult { int score, te, qe, score2, te2, tb, qb; };   // kswr_t, src/ksw.h:14-20
 
+// ---- where mem_reg2aln's global re-alignment is computed ----
+// The SAM stage runs twice around one GPU launch: a COLLECT pass that takes every pairing / marking decision and only
+// records which regions need a CIGAR (no text is produced), the device kernel (aln_kernel.hip), and a REPLAY pass that
+// repeats the same (deterministic) emission with the device results plugged in.  Without a context the host computes
+// the alignment itself (mode HOST) — used for regions the device flags, and by the unit tests of the host logic.
+struct AlnReqH { int64_t rb, re; int32_t read, qb, qe, w2, truesc, pad; };   // same layout as the device's AlnReq
+struct AlnHdrH { int32_t score, NM, n_cigar, md_len; uint32_t pool_off; int32_t flags; };
+struct AlnCtx {
+	enum { HOST = 0, COLLECT = 1, REPLAY = 2 };
+	int mode = HOST;
+	std::vector<AlnReqH> *reqs = nullptr;   // COLLECT: appended in call order
+	const AlnHdrH *hdr = nullptr;           // REPLAY: results in the same order, starting at `cursor`
+	const uint8_t *pool = nullptr;
+	size_t cursor = 0;
+	bool text() const { return mode != COLLECT; }
+};
+
+struct PairPlan {        // every decision mem_sam_pe takes before it formats anything (src/bwamem_pair.c:264-345)
+	int n_pri[2] = {0, 0}, z[2] = {0, 0}, q_se[2] = {0, 0};
+	int extra_flag = 1;
+	bool paired = false;
+	int n_rescue = 0;
+};
+
 // ---- reference geometry helpers (src/bntseq.c) ----
 int  bns_pos2rid(const bntseq_t *bns, int64_t pos_f);
 int  bns_intv2rid(const bntseq_t *bns, int64_t rb, int64_t re);
@@ -81,13 +105,20 @@ void reorder_primary5(int T, HRegV &a);
 int  approx_mapq_se(const mem_opt_t *opt, const HReg *a);
 bool gen_cigar2(const int8_t mat[25], int o_del, int e_del, int o_ins, int e_ins, int w_, int64_t l_pac, const uint8_t *pac,
                 int l_query, uint8_t *query, int64_t rb, int64_t re, int *score, std::vector<uint32_t> *cigar, std::string *md, int *NM);
-HAln reg2aln(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, int l_query, const char *query, const HReg *ar);
-void reg2sam(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, bseq1_t *s, HRegV &a, int extra_flag, const HAln *m);
+HAln reg2aln(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, int l_query, const char *query, const HReg *ar,
+             AlnCtx *ctx = nullptr, int read_idx = 0);
+void reg2sam(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, bseq1_t *s, HRegV &a, int extra_flag, const HAln *m,
+             AlnCtx *ctx = nullptr, int read_idx = 0);
 
 // ---- per-batch / per-pair stages (src/bwamem_pair.c) ----
 void pestat(const mem_opt_t *opt, int64_t l_pac, int n, const HRegV *regs, mem_pestat_t pes[4]);
 int  sam_pe(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, const mem_pestat_t pes[4], uint64_t id, bseq1_t s[2],
             HRegV a[2]);
+// the same in two halves: decisions (mutates a[]), then emission (pure; honours ctx, read0 = index of s[0] in the batch)
+void sam_pe_plan(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, const mem_pestat_t pes[4], uint64_t id, bseq1_t s[2],
+                 HRegV a[2], PairPlan &plan);
+void sam_pe_emit(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, const mem_pestat_t pes[4], bseq1_t s[2], HRegV a[2],
+                 const PairPlan &plan, AlnCtx *ctx, int read0);
 
 inline uint64_t hash_64(uint64_t key)   // Thomas Wang's 64-bit mix, as in src/utils.h:98-109
 {

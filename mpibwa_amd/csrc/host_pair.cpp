@@ -18,7 +18,7 @@ namespace mbw {
 void aln2sam_pub(const mem_opt_t *opt, const bntseq_t *bns, std::string &str, const bseq1_t *s, int n, const HAln *list, int which,
                  const HAln *m);
 bool gen_alt(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, const HRegV &a, int l_query, const char *query,
-             std::vector<std::string> &xa, std::vector<char> &has);
+             std::vector<std::string> &xa, std::vector<char> &has, AlnCtx *ctx, int read_idx);
 char *sam_to_c(const std::string &s);
 
 // orientation (0 FF, 1 FR, 2 RF, 3 RR) and distance of two hits given in the doubled coordinate
@@ -226,12 +226,12 @@ static int pair_hits(const mem_opt_t *opt, const bntseq_t *bns, const mem_pestat
 
 #define RAW_MAPQ(diff, a) ((int)(6.02 * (diff) / (a) + .499))
 
-int sam_pe(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, const mem_pestat_t pes[4], uint64_t id, bseq1_t s[2], HRegV a[2])
+// ---- decisions: mate rescue, primary marking, pairing, MAPQ (everything that mutates a[]) ----
+void sam_pe_plan(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, const mem_pestat_t pes[4], uint64_t id, bseq1_t s[2],
+                 HRegV a[2], PairPlan &P)
 {
-	int n = 0, z[2] = {0, 0}, o, subo = 0, n_sub = 0, extra_flag = 1, n_pri[2];
-	HAln h[2];
-	bool paired_path = false;
-
+	int n = 0, o, subo = 0, n_sub = 0;
+	P = PairPlan();
 	if (!(opt->flag & MEM_F_NO_RESCUE)) {   // mate rescue from the best hits of each end
 		HRegV b[2];
 		for (int i = 0; i < 2; ++i)
@@ -241,106 +241,125 @@ int sam_pe(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, const 
 			for (size_t j = 0; j < b[i].size() && (int)j < opt->max_matesw; ++j)
 				n += matesw(opt, bns, pac, pes, &b[i][j], s[!i].l_seq, (uint8_t *)s[!i].seq, a[!i]);
 	}
-	n_pri[0] = mark_primary_se(opt, a[0], id << 1 | 0);
-	n_pri[1] = mark_primary_se(opt, a[1], id << 1 | 1);
+	P.n_rescue = n;
+	P.n_pri[0] = mark_primary_se(opt, a[0], id << 1 | 0);
+	P.n_pri[1] = mark_primary_se(opt, a[1], id << 1 | 1);
 	if (opt->flag & MEM_F_PRIMARY5) {
 		reorder_primary5(opt->T, a[0]);
 		reorder_primary5(opt->T, a[1]);
 	}
-	if (!(opt->flag & MEM_F_NOPAIRING) && n_pri[0] && n_pri[1] &&
-	    (o = pair_hits(opt, bns, pes, a, (int)id, &subo, &n_sub, z, n_pri)) > 0) {
-		int is_multi[2], q_pe, score_un, q_se[2];
-		for (int i = 0; i < 2; ++i) {   // an end with several good primary hits is left to the single-end logic
-			int j;
-			for (j = 1; j < n_pri[i]; ++j)
-				if (a[i][j].secondary < 0 && a[i][j].score >= opt->T) break;
-			is_multi[i] = j < n_pri[i] ? 1 : 0;
+	if ((opt->flag & MEM_F_NOPAIRING) || !P.n_pri[0] || !P.n_pri[1]) return;
+	int *z = P.z;
+	if ((o = pair_hits(opt, bns, pes, a, (int)id, &subo, &n_sub, z, P.n_pri)) <= 0) return;
+	int is_multi[2], q_pe, score_un, *q_se = P.q_se;
+	for (int i = 0; i < 2; ++i) {   // an end with several good primary hits is left to the single-end logic
+		int j;
+		for (j = 1; j < P.n_pri[i]; ++j)
+			if (a[i][j].secondary < 0 && a[i][j].score >= opt->T) break;
+		is_multi[i] = j < P.n_pri[i] ? 1 : 0;
+	}
+	if (is_multi[0] || is_multi[1]) return;
+	P.paired = true;
+	score_un = a[0][0].score + a[1][0].score - opt->pen_unpaired;
+	subo = subo > score_un ? subo : score_un;
+	q_pe = RAW_MAPQ(o - subo, opt->a);
+	if (n_sub > 0) q_pe -= (int)(4.343 * log(n_sub + 1) + .499);
+	if (q_pe < 0) q_pe = 0;
+	if (q_pe > 60) q_pe = 60;
+	q_pe = (int)(q_pe * (1. - .5 * (a[0][0].frac_rep + a[1][0].frac_rep)) + .499);
+	if (o > score_un) {   // the pair beats the two best single-end hits
+		HReg *c[2] = {&a[0][z[0]], &a[1][z[1]]};
+		for (int i = 0; i < 2; ++i) {
+			if (c[i]->secondary >= 0) { c[i]->sub = a[i][c[i]->secondary].score; c[i]->secondary = -2; }
+			q_se[i] = approx_mapq_se(opt, c[i]);
 		}
-		if (!is_multi[0] && !is_multi[1]) {
-			paired_path = true;
-			score_un = a[0][0].score + a[1][0].score - opt->pen_unpaired;
-			subo = subo > score_un ? subo : score_un;
-			q_pe = RAW_MAPQ(o - subo, opt->a);
-			if (n_sub > 0) q_pe -= (int)(4.343 * log(n_sub + 1) + .499);
-			if (q_pe < 0) q_pe = 0;
-			if (q_pe > 60) q_pe = 60;
-			q_pe = (int)(q_pe * (1. - .5 * (a[0][0].frac_rep + a[1][0].frac_rep)) + .499);
-			if (o > score_un) {   // the pair beats the two best single-end hits
-				HReg *c[2] = {&a[0][z[0]], &a[1][z[1]]};
-				for (int i = 0; i < 2; ++i) {
-					if (c[i]->secondary >= 0) { c[i]->sub = a[i][c[i]->secondary].score; c[i]->secondary = -2; }
-					q_se[i] = approx_mapq_se(opt, c[i]);
-				}
-				q_se[0] = q_se[0] > q_pe ? q_se[0] : q_pe < q_se[0] + 40 ? q_pe : q_se[0] + 40;
-				q_se[1] = q_se[1] > q_pe ? q_se[1] : q_pe < q_se[1] + 40 ? q_pe : q_se[1] + 40;
-				extra_flag |= 2;
-				// cap by the tandem-repeat score
-				q_se[0] = q_se[0] < RAW_MAPQ(c[0]->score - c[0]->csub, opt->a) ? q_se[0] : RAW_MAPQ(c[0]->score - c[0]->csub, opt->a);
-				q_se[1] = q_se[1] < RAW_MAPQ(c[1]->score - c[1]->csub, opt->a) ? q_se[1] : RAW_MAPQ(c[1]->score - c[1]->csub, opt->a);
-			} else {
-				z[0] = z[1] = 0;
-				q_se[0] = approx_mapq_se(opt, &a[0][0]);
-				q_se[1] = approx_mapq_se(opt, &a[1][0]);
-			}
-			for (int i = 0; i < 2; ++i) {
-				int k = a[i][z[i]].secondary_all;
-				if (k >= 0 && k < n_pri[i]) {   // the chosen hit was secondary: swap roles with its parent
-					for (size_t j = 0; j < a[i].size(); ++j)
-						if (a[i][j].secondary_all == k || (int)j == k) a[i][j].secondary_all = z[i];
-					a[i][z[i]].secondary_all = -1;
-				}
-			}
-			std::vector<std::string> xa[2];
-			std::vector<char> has[2];
-			bool have_xa[2] = {false, false};
-			if (!(opt->flag & MEM_F_ALL))
-				for (int i = 0; i < 2; ++i) have_xa[i] = gen_alt(opt, bns, pac, a[i], s[i].l_seq, s[i].seq, xa[i], has[i]);
-			std::vector<HAln> aa[2];
-			HAln g[2];
-			for (int i = 0; i < 2; ++i) {
-				h[i] = reg2aln(opt, bns, pac, s[i].l_seq, s[i].seq, &a[i][z[i]]);
-				h[i].mapq = q_se[i] & 0xff;
-				h[i].flag |= 0x40 << i | extra_flag;
-				if (have_xa[i] && has[i][z[i]]) { h[i].has_xa = true; h[i].xa = xa[i][z[i]]; }
-				aa[i].push_back(h[i]);
-				if (n_pri[i] < (int)a[i].size()) {   // the read also has ALT hits
-					HReg *p = &a[i][n_pri[i]];
-					if (p->score < opt->T || p->secondary >= 0 || !p->is_alt) continue;
-					g[i] = reg2aln(opt, bns, pac, s[i].l_seq, s[i].seq, p);
-					g[i].flag |= 0x800 | 0x40 << i | extra_flag;
-					if (have_xa[i] && has[i][n_pri[i]]) { g[i].has_xa = true; g[i].xa = xa[i][n_pri[i]]; }
-					aa[i].push_back(g[i]);
-				}
-			}
-			std::string str;
-			for (size_t i = 0; i < aa[0].size(); ++i) aln2sam_pub(opt, bns, str, &s[0], (int)aa[0].size(), aa[0].data(), (int)i, &h[1]);
-			s[0].sam = sam_to_c(str);
-			str.clear();
-			for (size_t i = 0; i < aa[1].size(); ++i) aln2sam_pub(opt, bns, str, &s[1], (int)aa[1].size(), aa[1].data(), (int)i, &h[0]);
-			s[1].sam = sam_to_c(str);
-			if (strcmp(s[0].name, s[1].name) != 0) die("paired reads have different names: \"%s\", \"%s\"", s[0].name, s[1].name);
+		q_se[0] = q_se[0] > q_pe ? q_se[0] : q_pe < q_se[0] + 40 ? q_pe : q_se[0] + 40;
+		q_se[1] = q_se[1] > q_pe ? q_se[1] : q_pe < q_se[1] + 40 ? q_pe : q_se[1] + 40;
+		P.extra_flag |= 2;
+		// cap by the tandem-repeat score
+		q_se[0] = q_se[0] < RAW_MAPQ(c[0]->score - c[0]->csub, opt->a) ? q_se[0] : RAW_MAPQ(c[0]->score - c[0]->csub, opt->a);
+		q_se[1] = q_se[1] < RAW_MAPQ(c[1]->score - c[1]->csub, opt->a) ? q_se[1] : RAW_MAPQ(c[1]->score - c[1]->csub, opt->a);
+	} else {
+		z[0] = z[1] = 0;
+		q_se[0] = approx_mapq_se(opt, &a[0][0]);
+		q_se[1] = approx_mapq_se(opt, &a[1][0]);
+	}
+	for (int i = 0; i < 2; ++i) {
+		int k = a[i][z[i]].secondary_all;
+		if (k >= 0 && k < P.n_pri[i]) {   // the chosen hit was secondary: swap roles with its parent
+			for (size_t j = 0; j < a[i].size(); ++j)
+				if (a[i][j].secondary_all == k || (int)j == k) a[i][j].secondary_all = z[i];
+			a[i][z[i]].secondary_all = -1;
 		}
 	}
-	if (paired_path) return n;
+}
 
+// ---- emission: CIGARs (through ctx) and SAM text; a[] and the plan are only read ----
+void sam_pe_emit(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, const mem_pestat_t pes[4], bseq1_t s[2], HRegV a[2],
+                 const PairPlan &P, AlnCtx *ctx, int read0)
+{
+	const bool text = !ctx || ctx->text();
+	const int *z = P.z, *n_pri = P.n_pri;
+	HAln h[2];
+	if (P.paired) {
+		std::vector<std::string> xa[2];
+		std::vector<char> has[2];
+		bool have_xa[2] = {false, false};
+		if (!(opt->flag & MEM_F_ALL))
+			for (int i = 0; i < 2; ++i) have_xa[i] = gen_alt(opt, bns, pac, a[i], s[i].l_seq, s[i].seq, xa[i], has[i], ctx, read0 + i);
+		std::vector<HAln> aa[2];
+		HAln g[2];
+		for (int i = 0; i < 2; ++i) {
+			h[i] = reg2aln(opt, bns, pac, s[i].l_seq, s[i].seq, &a[i][z[i]], ctx, read0 + i);
+			h[i].mapq = P.q_se[i] & 0xff;
+			h[i].flag |= 0x40 << i | P.extra_flag;
+			if (text && have_xa[i] && has[i][z[i]]) { h[i].has_xa = true; h[i].xa = xa[i][z[i]]; }
+			aa[i].push_back(h[i]);
+			if (n_pri[i] < (int)a[i].size()) {   // the read also has ALT hits
+				HReg *p = &a[i][n_pri[i]];
+				if (p->score < opt->T || p->secondary >= 0 || !p->is_alt) continue;
+				g[i] = reg2aln(opt, bns, pac, s[i].l_seq, s[i].seq, p, ctx, read0 + i);
+				g[i].flag |= 0x800 | 0x40 << i | P.extra_flag;
+				if (text && have_xa[i] && has[i][n_pri[i]]) { g[i].has_xa = true; g[i].xa = xa[i][n_pri[i]]; }
+				aa[i].push_back(g[i]);
+			}
+		}
+		if (!text) return;
+		std::string str;
+		for (size_t i = 0; i < aa[0].size(); ++i) aln2sam_pub(opt, bns, str, &s[0], (int)aa[0].size(), aa[0].data(), (int)i, &h[1]);
+		s[0].sam = sam_to_c(str);
+		str.clear();
+		for (size_t i = 0; i < aa[1].size(); ++i) aln2sam_pub(opt, bns, str, &s[1], (int)aa[1].size(), aa[1].data(), (int)i, &h[0]);
+		s[1].sam = sam_to_c(str);
+		if (strcmp(s[0].name, s[1].name) != 0) die("paired reads have different names: \"%s\", \"%s\"", s[0].name, s[1].name);
+		return;
+	}
 	// no usable pair: report the ends independently
+	int extra_flag = 1;
 	for (int i = 0; i < 2; ++i) {
 		int which = -1;
 		if (!a[i].empty()) {
 			if (a[i][0].score >= opt->T) which = 0;
 			else if (n_pri[i] < (int)a[i].size() && a[i][n_pri[i]].score >= opt->T) which = n_pri[i];
 		}
-		h[i] = reg2aln(opt, bns, pac, s[i].l_seq, s[i].seq, which >= 0 ? &a[i][which] : 0);
+		h[i] = reg2aln(opt, bns, pac, s[i].l_seq, s[i].seq, which >= 0 ? &a[i][which] : 0, ctx, read0 + i);
 	}
 	if (!(opt->flag & MEM_F_NOPAIRING) && h[0].rid == h[1].rid && h[0].rid >= 0) {   // still flag a proper pair if the top hits form one
 		int64_t dist;
 		int d = infer_dir(bns->l_pac, a[0][0].rb, a[1][0].rb, &dist);
 		if (!pes[d].failed && dist >= pes[d].low && dist <= pes[d].high) extra_flag |= 2;
 	}
-	reg2sam(opt, bns, pac, &s[0], a[0], 0x41 | extra_flag, &h[1]);
-	reg2sam(opt, bns, pac, &s[1], a[1], 0x81 | extra_flag, &h[0]);
-	if (strcmp(s[0].name, s[1].name) != 0) die("paired reads have different names: \"%s\", \"%s\"", s[0].name, s[1].name);
-	return n;
+	reg2sam(opt, bns, pac, &s[0], a[0], 0x41 | extra_flag, &h[1], ctx, read0);
+	reg2sam(opt, bns, pac, &s[1], a[1], 0x81 | extra_flag, &h[0], ctx, read0 + 1);
+	if (text && strcmp(s[0].name, s[1].name) != 0) die("paired reads have different names: \"%s\", \"%s\"", s[0].name, s[1].name);
+}
+
+int sam_pe(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, const mem_pestat_t pes[4], uint64_t id, bseq1_t s[2], HRegV a[2])
+{
+	PairPlan P;
+	sam_pe_plan(opt, bns, pac, pes, id, s, a, P);
+	sam_pe_emit(opt, bns, pac, pes, s, a, P, nullptr, 0);
+	return P.n_rescue;
 }
 
 } // namespace mbw

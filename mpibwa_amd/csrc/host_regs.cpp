@@ -304,7 +304,8 @@ static inline int infer_bw(int l1, int l2, int score, int a, int q, int r)
 	return w;
 }
 
-HAln reg2aln(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, int l_query, const char *query_, const HReg *ar)
+HAln reg2aln(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, int l_query, const char *query_, const HReg *ar,
+             AlnCtx *ctx, int read_idx)
 {
 	HProf hp_(HP_REG2ALN);
 	HAln a;
@@ -314,23 +315,45 @@ HAln reg2aln(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, int 
 	}
 	int qb = ar->qb, qe = ar->qe, is_rev, NM = -1, score = 0, last_sc = -(1 << 30);
 	int64_t rb = ar->rb, re = ar->re;
-	std::vector<uint8_t> query(l_query);
-	for (int i = 0; i < l_query; ++i) query[i] = query_[i] < 5 ? query_[i] : nt4_table[(uint8_t)query_[i]];
 	a.mapq = (ar->secondary < 0 ? approx_mapq_se(opt, ar) : 0) & 0xff;
 	if (ar->secondary >= 0) a.flag |= 0x100;
 	int tmp = infer_bw(qe - qb, (int)(re - rb), ar->truesc, opt->a, opt->o_del, opt->e_del);
 	int w2 = infer_bw(qe - qb, (int)(re - rb), ar->truesc, opt->a, opt->o_ins, opt->e_ins);
 	w2 = w2 > tmp ? w2 : tmp;
 	if (w2 > opt->w) w2 = w2 < ar->w ? w2 : ar->w;
-	int i = 0;
-	do {
-		w2 = w2 < opt->w << 2 ? w2 : opt->w << 2;
-		gen_cigar2(opt->mat, opt->o_del, opt->e_del, opt->o_ins, opt->e_ins, w2, bns->l_pac, pac, qe - qb, &query[qb], rb, re, &score,
-		           &a.cigar, &a.md, &NM);
-		if (score == last_sc || w2 == opt->w << 2) break;   // global and local scores may legitimately differ
-		last_sc = score;
-		w2 <<= 1;
-	} while (++i < 3 && score < ar->truesc - opt->a);
+	if (ctx && ctx->mode == AlnCtx::COLLECT) {   // only note that this region needs its CIGAR; decisions do not depend on it
+		AlnReqH rq;
+		rq.rb = rb; rq.re = re; rq.read = read_idx; rq.qb = qb; rq.qe = qe; rq.w2 = w2; rq.truesc = ar->truesc; rq.pad = 0;
+		ctx->reqs->push_back(rq);
+		a.rid = ar->rid;
+		a.score = ar->score; a.sub = ar->sub > ar->csub ? ar->sub : ar->csub;
+		a.is_alt = ar->is_alt; a.alt_sc = ar->alt_sc;
+		return a;
+	}
+	bool have = false;
+	if (ctx && ctx->mode == AlnCtx::REPLAY) {
+		const AlnHdrH &h = ctx->hdr[ctx->cursor++];
+		if (h.flags == 0) {
+			const uint32_t *cg = (const uint32_t *)(ctx->pool + (size_t)h.pool_off * 4);
+			a.cigar.assign(cg, cg + h.n_cigar);
+			a.md.assign((const char *)(cg + h.n_cigar), h.md_len);
+			NM = h.NM; score = h.score;
+			have = true;
+		}
+	}
+	if (!have) {
+		std::vector<uint8_t> query(l_query);
+		for (int i = 0; i < l_query; ++i) query[i] = query_[i] < 5 ? query_[i] : nt4_table[(uint8_t)query_[i]];
+		int i = 0;
+		do {
+			w2 = w2 < opt->w << 2 ? w2 : opt->w << 2;
+			gen_cigar2(opt->mat, opt->o_del, opt->e_del, opt->o_ins, opt->e_ins, w2, bns->l_pac, pac, qe - qb, &query[qb], rb, re, &score,
+			           &a.cigar, &a.md, &NM);
+			if (score == last_sc || w2 == opt->w << 2) break;   // global and local scores may legitimately differ
+			last_sc = score;
+			w2 <<= 1;
+		} while (++i < 3 && score < ar->truesc - opt->a);
+	}
 	a.NM = (uint32_t)NM & 0x3fffff;
 	int64_t pos = bns_depos(bns, rb < bns->l_pac ? rb : re - 1, &is_rev);
 	a.is_rev = is_rev;
@@ -491,7 +514,7 @@ void aln2sam_pub(const mem_opt_t *opt, const bntseq_t *bns, std::string &str, co
 
 // XA strings per region (only valid after mark_primary_se); returns false when no region has alternatives
 bool gen_alt(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, const HRegV &a, int l_query, const char *query,
-             std::vector<std::string> &xa, std::vector<char> &has)
+             std::vector<std::string> &xa, std::vector<char> &has, AlnCtx *ctx, int read_idx)
 {
 	HProf hp_(HP_GENALT);
 	int n = (int)a.size(), tot = 0;
@@ -517,7 +540,9 @@ bool gen_alt(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, cons
 		int r = pri_idx(i);
 		if (r < 0) continue;
 		if (cnt[r] > opt->max_XA_hits_alt || (!has_alt[r] && cnt[r] > opt->max_XA_hits)) continue;
-		HAln t = reg2aln(opt, bns, pac, l_query, query, &a[i]);
+		HAln t = reg2aln(opt, bns, pac, l_query, query, &a[i], ctx, read_idx);
+		has[r] = 1;
+		if (ctx && !ctx->text()) continue;
 		std::string &s = xa[r];
 		s += bns->anns[t.rid].name;
 		s.push_back(','); s.push_back("+-"[t.is_rev]); put_int(s, t.pos + 1);
@@ -525,7 +550,6 @@ bool gen_alt(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, cons
 		for (uint32_t cg : t.cigar) { put_int(s, cg >> 4); s.push_back("MIDSHN"[cg & 0xf]); }
 		s.push_back(','); put_int(s, t.NM);
 		s.push_back(';');
-		has[r] = 1;
 	}
 	return true;
 }
@@ -540,12 +564,14 @@ static char *to_c(const std::string &s)
 }
 char *sam_to_c(const std::string &s) { return to_c(s); }
 
-void reg2sam(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, bseq1_t *s, HRegV &a, int extra_flag, const HAln *m)
+void reg2sam(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, bseq1_t *s, HRegV &a, int extra_flag, const HAln *m,
+             AlnCtx *ctx, int read_idx)
 {
+	const bool text = !ctx || ctx->text();
 	std::vector<std::string> xa;
 	std::vector<char> has;
 	bool have_xa = false;
-	if (!(opt->flag & MEM_F_ALL)) have_xa = gen_alt(opt, bns, pac, a, s->l_seq, s->seq, xa, has);
+	if (!(opt->flag & MEM_F_ALL)) have_xa = gen_alt(opt, bns, pac, a, s->l_seq, s->seq, xa, has, ctx, read_idx);
 	std::vector<HAln> aa;
 	std::string str;
 	int l = 0;
@@ -554,7 +580,7 @@ void reg2sam(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, bseq
 		if (p->score < opt->T) continue;
 		if (p->secondary >= 0 && (p->is_alt || !(opt->flag & MEM_F_ALL))) continue;
 		if (p->secondary >= 0 && p->secondary < INT_MAX && p->score < a[p->secondary].score * opt->drop_ratio) continue;
-		aa.push_back(reg2aln(opt, bns, pac, s->l_seq, s->seq, p));
+		aa.push_back(reg2aln(opt, bns, pac, s->l_seq, s->seq, p, ctx, read_idx));
 		HAln *q = &aa.back();
 		if (have_xa && has[k]) { q->has_xa = true; q->xa = xa[k]; }
 		q->flag |= extra_flag;
@@ -563,6 +589,7 @@ void reg2sam(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, bseq
 		if (!(opt->flag & MEM_F_KEEP_SUPP_MAPQ) && l && !p->is_alt && q->mapq > aa[0].mapq) q->mapq = aa[0].mapq;
 		++l;
 	}
+	if (!text) return;
 	if (aa.empty()) {
 		HAln t = reg2aln(opt, bns, pac, s->l_seq, s->seq, 0);
 		t.flag |= extra_flag;

@@ -108,7 +108,7 @@ struct EvTimer {
 // device work buffers, grown on demand and kept across calls
 struct Workspace {
 	DevBuf seq, off, len, intv, nintv, cnt, scratch, nseeds, lrep, seed_off, rows, qbl, sa;
-	DevBuf chain_off, chains, seeds, srt, reg_off, regs, nregs, tab;
+	DevBuf chain_off, chains, seeds, srt, reg_off, regs, nregs, tab, areq, ahdr, apool, agap;
 	const void *host_bwt = nullptr;
 };
 static Workspace g_ws;
@@ -389,18 +389,100 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	}
 	double t7 = now_ms();
 
-	// ---- 8. pairing / SAM ----
-	if (pe) {
-		parallel_for(n_thr, n >> 1, 128, [&](int i) {
-			sam_pe(opt, bns, pac, pes, (uint64_t)((n_processed >> 1) + i), &seqs[i << 1], &regs[i << 1]);
+	// ---- 8. pairing decisions, then CIGAR/MD/NM on the GPU, then SAM text ----
+	// A: decisions + a COLLECT pass that records which regions need a global re-alignment (mem_reg2aln's DP);
+	// B: aln_kernel does them all at once;  C: the same emission again (REPLAY) with the results plugged in.
+	const int n_units = pe ? n >> 1 : n;
+	std::vector<PairPlan> plans(pe ? n_units : 0);
+	const bool gpu_aln = getenv("MPIBWA_HOST_CIGAR") == nullptr;
+	std::vector<AlnReqH> all_req;
+	std::vector<uint32_t> unit_base(n_units + 1, 0);
+	{
+		// one request list per block of 256 units (a block is handled by exactly one thread); each unit remembers (first, count)
+		const int n_blk = (n_units + 255) / 256;
+		std::vector<std::vector<AlnReqH>> blk_req(n_blk);
+		std::vector<uint32_t> u_first(n_units), u_cnt(n_units);
+		parallel_for(n_thr, n_blk, 1, [&](int blk) {
+			std::vector<AlnReqH> &rq = blk_req[blk];
+			rq.reserve(256 * 3);
+			AlnCtx ctx;
+			ctx.mode = AlnCtx::COLLECT; ctx.reqs = &rq;
+			const int lo = blk * 256, hi = std::min(n_units, lo + 256);
+			for (int i = lo; i < hi; ++i) {
+				const size_t before = rq.size();
+				if (pe) {
+					sam_pe_plan(opt, bns, pac, pes, (uint64_t)((n_processed >> 1) + i), &seqs[i << 1], &regs[i << 1], plans[i]);
+					if (gpu_aln) sam_pe_emit(opt, bns, pac, pes, &seqs[i << 1], &regs[i << 1], plans[i], &ctx, i << 1);
+				} else {
+					mark_primary_se(opt, regs[i], n_processed + i);
+					if (opt->flag & MEM_F_PRIMARY5) reorder_primary5(opt->T, regs[i]);
+					if (gpu_aln) reg2sam(opt, bns, pac, &seqs[i], regs[i], 0, 0, &ctx, i);
+				}
+				u_first[i] = (uint32_t)before; u_cnt[i] = (uint32_t)(rq.size() - before);
+			}
 		});
-	} else {
-		parallel_for(n_thr, n, 256, [&](int i) {
-			mark_primary_se(opt, regs[i], n_processed + i);
-			if (opt->flag & MEM_F_PRIMARY5) reorder_primary5(opt->T, regs[i]);
-			reg2sam(opt, bns, pac, &seqs[i], regs[i], 0, 0);
+		for (int i = 0; i < n_units; ++i) unit_base[i + 1] = unit_base[i] + u_cnt[i];
+		all_req.resize(unit_base[n_units]);
+		parallel_for(n_thr, n_units, 4096, [&](int i) {
+			if (u_cnt[i]) memcpy(&all_req[unit_base[i]], &blk_req[i >> 8][u_first[i]], (size_t)u_cnt[i] * sizeof(AlnReqH));
 		});
 	}
+	double t8a = now_ms();
+	const size_t n_req = all_req.size();
+	std::vector<AlnHdrH> hdr(n_req);
+	std::vector<uint8_t> pool;
+	if (gpu_aln && n_req) {
+		const int tcap = max_len + 256;
+		std::vector<int> gaptab(max_len + 2);
+		for (int l = 0; l <= max_len + 1; ++l) {   // max_gap of bwa_gen_cigar2 (src/bwa.c:155-158), a function of l_query only
+			int max_ins = (int)((double)(((l + 1) >> 1) * opt->mat[0] - opt->o_ins) / opt->e_ins + 1.);
+			int max_del = (int)((double)(((l + 1) >> 1) * opt->mat[0] - opt->o_del) / opt->e_del + 1.);
+			int g = max_ins > max_del ? max_ins : max_del;
+			gaptab[l] = g > 1 ? g : 1;
+		}
+		const size_t pool_bytes = n_req * 96 + (1 << 20);
+		AlnReq *d_req = (AlnReq *)W.areq.ensure(n_req * sizeof(AlnReq));
+		AlnHdr *d_hdr = (AlnHdr *)W.ahdr.ensure(n_req * sizeof(AlnHdr));
+		uint8_t *d_pool = (uint8_t *)W.apool.ensure(pool_bytes);
+		int *d_gap = (int *)W.agap.ensure(gaptab.size() * 4);
+		static_assert(sizeof(AlnReq) == sizeof(AlnReqH) && sizeof(AlnHdr) == sizeof(AlnHdrH), "host/device record layouts differ");
+		HIP_OK(hipMemcpyAsync(d_req, all_req.data(), n_req * sizeof(AlnReq), hipMemcpyHostToDevice, st));
+		HIP_OK(hipMemcpyAsync(d_gap, gaptab.data(), gaptab.size() * 4, hipMemcpyHostToDevice, st));
+		HIP_OK(hipMemsetAsync(d_cnt, 0, 256, st));
+		AlnParams ap;
+		ap.l_pac = bns->l_pac; ap.a = opt->a; ap.w = opt->w;
+		ExtParams ep;
+		memcpy(ep.mat, opt->mat, 25);
+		ep.o_del = opt->o_del; ep.e_del = opt->e_del; ep.o_ins = opt->o_ins; ep.e_ins = opt->e_ins; ep.zdrop = opt->zdrop;
+		EvTimer ev_aln;
+		ev_aln.start(st);
+		launch_aln(st, ap, ep, (int)n_req, d_req, d_seq, d_off, (const uint8_t *)ix.d_pac, d_gap, d_hdr, d_pool, d_cnt, pool_bytes, max_len, tcap);
+		ev_aln.stop(st);
+		HIP_OK(hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, st));
+		HIP_OK(hipMemcpyAsync(hdr.data(), d_hdr, n_req * sizeof(AlnHdr), hipMemcpyDeviceToHost, st));
+		HIP_OK(hipStreamSynchronize(st));
+		HIP_OK(hipGetLastError());
+		g_stats.k_aln_ms = ev_aln.ms();
+		size_t used = std::min<size_t>(cnt[0], pool_bytes);
+		pool.resize(used + 16);
+		if (used) HIP_OK(hipMemcpy(pool.data(), d_pool, used, hipMemcpyDeviceToHost));
+		g_stats.n_aln = n_req;
+	}
+	double t8b = now_ms();
+	if (pe) {
+		parallel_for(n_thr, n_units, 128, [&](int i) {
+			AlnCtx ctx;
+			if (gpu_aln) { ctx.mode = AlnCtx::REPLAY; ctx.hdr = hdr.data(); ctx.pool = pool.data(); ctx.cursor = unit_base[i]; }
+			sam_pe_emit(opt, bns, pac, pes, &seqs[i << 1], &regs[i << 1], plans[i], gpu_aln ? &ctx : nullptr, i << 1);
+		});
+	} else {
+		parallel_for(n_thr, n_units, 256, [&](int i) {
+			AlnCtx ctx;
+			if (gpu_aln) { ctx.mode = AlnCtx::REPLAY; ctx.hdr = hdr.data(); ctx.pool = pool.data(); ctx.cursor = unit_base[i]; }
+			reg2sam(opt, bns, pac, &seqs[i], regs[i], 0, 0, gpu_aln ? &ctx : nullptr, i);
+		});
+	}
+	g_stats.plan_ms = t8a - t7; g_stats.aln_ms = t8b - t8a;
 	double t8 = now_ms();
 	hprof_report("sam stage");
 	// release the per-read containers in parallel (millions of small blocks: serial destruction costs ~0.2 s per chunk)

@@ -38,6 +38,17 @@ __device__ __forceinline__ int wx_scan_max(int v)
 	v = max(v, wx_dpp<0x143, 0xc>(WX_NEG, v));   // row_bcast:31 -> rows 2,3
 	return v;
 }
+// the same scan with a caller-chosen identity (for value ranges that go below WX_NEG)
+__device__ __forceinline__ int wx_scan_max_id(int v, int id)
+{
+	v = max(v, wx_dpp<0x111, 0xf>(id, v));
+	v = max(v, wx_dpp<0x112, 0xf>(id, v));
+	v = max(v, wx_dpp<0x114, 0xf>(id, v));
+	v = max(v, wx_dpp<0x118, 0xf>(id, v));
+	v = max(v, wx_dpp<0x142, 0xa>(id, v));
+	v = max(v, wx_dpp<0x143, 0xc>(id, v));
+	return v;
+}
 // value of the previous lane (lane 0 gets `first`)
 __device__ __forceinline__ int wx_prev_lane(int v, int first)
 {
