@@ -50,10 +50,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     import torch.distributed as dist
+    backend = os.environ.get("MPIBWA_BENCH_BACKEND", "nccl")   # "gloo" only for dry runs of the multi-rank path on one GPU
+    n_dev = torch.cuda.device_count()
+    dev = local_rank % max(n_dev, 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    torch.cuda.set_device(dev)
 
     from mpibwa_amd import abi, api, bigindex, simulate
     from mpibwa_amd.build import build
@@ -67,7 +73,7 @@ def main():
     os.makedirs(args.workdir, exist_ok=True)
     t0 = time.time()
     idx = bigindex.make_or_get(args.workdir, genome_mbp=args.genome_mbp, seed=38, rank=rank, world=world,
-                               local_rank=local_rank, dist=dist if world > 1 else None, log=log if rank == 0 else None)
+                               local_rank=dev, dist=dist if world > 1 else None, log=log if rank == 0 else None)
     eng = idx.engine
     if rank == 0:
         log("index ready in %.1f s: l_pac=%d, occ blocks %.2f GB, SA %.2f GB" %

@@ -170,6 +170,10 @@ int  mi355x_index_upload(int local_rank, const bwt_t *bwt, const bntseq_t *bns, 
  * then receive into these buffers). */
 int  mi355x_index_alloc(int local_rank, const bwt_t *bwt_meta, const bntseq_t *bns);
 int  mi355x_index_buffers(void **d_bwt, size_t *bwt_bytes, void **d_sa, size_t *sa_bytes, void **d_pac, size_t *pac_bytes);
+/* broadcast path: copy between a caller-owned device buffer and index buffer `which` (0 occ blocks, 1 SA, 2 pac);
+ * once all three are filled, mi355x_index_commit() expands the dense SA and makes the index usable */
+int  mi355x_index_d2d(int which, void *ext_device_ptr, size_t bytes, int to_index);
+int  mi355x_index_commit(void);
 void mi355x_finalize(void);
 
 /* own bwa-compatible index builder (formats of src/bwt.c:385-462,

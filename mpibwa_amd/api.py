@@ -15,7 +15,8 @@ libc.free.argtypes = [C.c_void_p]
 
 EXPORTS = [
     "mem_process_seqs", "mem_opt_init", "bwa_fill_scmat", "bwa_idx_load_from_disk", "bwa_mem2idx", "bwa_idx_destroy",
-    "mi355x_index_upload", "mi355x_index_alloc", "mi355x_index_buffers", "mi355x_finalize", "mi355x_index_build", "mi355x_index_build_gpu",
+    "mi355x_index_upload", "mi355x_index_alloc", "mi355x_index_buffers", "mi355x_index_d2d", "mi355x_index_commit",
+    "mi355x_finalize", "mi355x_index_build", "mi355x_index_build_gpu",
     "mi355x_smem_batch", "mi355x_sa_batch", "mi355x_sa_batch2", "mi355x_sa_dense_info", "mi355x_extend_batch", "mi355x_last_stats", "mi355x_host_cpus", "mi355x_collect_sam", "mi355x_host_ksw_align2",
 ]
 
@@ -46,6 +47,10 @@ def load_library(build_if_missing=True):
     sig("mem_process_seqs", None, [P(abi.mem_opt_t), P(abi.bwt_t), P(abi.bntseq_t), P(C.c_uint8), C.c_int64, C.c_int,
                                    P(abi.bseq1_t), P(abi.mem_pestat_t)])
     sig("mi355x_index_upload", C.c_int, [C.c_int, P(abi.bwt_t), P(abi.bntseq_t), P(C.c_uint8)])
+    sig("mi355x_index_alloc", C.c_int, [C.c_int, P(abi.bwt_t), P(abi.bntseq_t)])
+    sig("mi355x_index_buffers", C.c_int, [P(C.c_void_p), P(C.c_size_t)] * 3)
+    sig("mi355x_index_d2d", C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_int])
+    sig("mi355x_index_commit", C.c_int, [])
     sig("mi355x_smem_batch", C.c_int, [P(abi.mem_opt_t), C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                        C.c_void_p, P(C.c_double), P(C.c_uint64)])
     sig("mi355x_sa_batch", C.c_int, [C.c_int, C.c_void_p, C.c_void_p, P(C.c_double), P(C.c_uint64)])
@@ -61,6 +66,17 @@ def load_library(build_if_missing=True):
     return lib
 
 
+_HIP = None
+
+
+def _hip():
+    global _HIP
+    if _HIP is None:
+        _HIP = C.CDLL("libamdhip64.so")
+        _HIP.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    return _HIP
+
+
 def build_index(fasta, prefix):
     lib = load_library()
     if lib.mi355x_index_build(fasta.encode(), prefix.encode()) != 0:
@@ -70,17 +86,62 @@ def build_index(fasta, prefix):
 class Engine:
     """One rank = one GPU: loads a bwa index, uploads it to HBM and aligns batches."""
 
-    def __init__(self, prefix, device=0, upload=True):
+    def __init__(self, prefix, device=0, upload=True, dist=None, rank=0):
+        """dist given (torch.distributed, nccl = RCCL): rank 0 uploads the index from host memory, every other rank only
+        allocates the device buffers and receives occ blocks, SA and pac by broadcast over xGMI."""
         self.lib = load_library()
         self.idx = self.lib.bwa_idx_load_from_disk(prefix.encode(), 7)
         self.bwt = self.idx.contents.bwt
         self.bns = self.idx.contents.bns
         self.pac = self.idx.contents.pac
         self.uploaded = False
-        if upload:
+        self.bcast_seconds = None
+        if upload and dist is None:
             if self.lib.mi355x_index_upload(device, self.bwt, self.bns, self.pac) != 0:
                 raise RuntimeError("mi355x_index_upload failed")
             self.uploaded = True
+        elif upload:
+            self._upload_by_broadcast(device, dist, rank)
+
+    def _upload_by_broadcast(self, device, dist, rank):
+        import time
+        import torch
+        if rank == 0:
+            os.environ["MPIBWA_SA_DENSE"] = os.environ.get("MPIBWA_SA_DENSE", "1")
+            self.lib.mi355x_index_alloc(device, self.bwt, self.bns)
+            # rank 0 fills its buffers from the host copy (H2D once), the others get them over RCCL
+            sizes = [int(self.bwt.contents.bwt_size) * 4, int(self.bwt.contents.n_sa) * 8, int(self.bns.contents.l_pac) // 4 + 1]
+            srcs = [C.cast(self.bwt.contents.bwt, C.c_void_p), C.cast(self.bwt.contents.sa, C.c_void_p), C.cast(self.pac, C.c_void_p)]
+        else:
+            self.lib.mi355x_index_alloc(device, self.bwt, self.bns)
+            sizes = [int(self.bwt.contents.bwt_size) * 4, int(self.bwt.contents.n_sa) * 8, int(self.bns.contents.l_pac) // 4 + 1]
+            srcs = None
+        t0 = time.time()
+        for which, nbytes in enumerate(sizes):
+            # broadcast in 1 GiB pieces through a torch staging tensor (RCCL over xGMI), then a D2D copy into the index buffer
+            piece = 1 << 30
+            t = torch.empty(min(piece, nbytes), dtype=torch.uint8, device="cuda:%d" % device)
+            off = 0
+            pv = [C.c_void_p() for _ in range(3)]
+            sv = [C.c_size_t() for _ in range(3)]
+            self.lib.mi355x_index_buffers(C.byref(pv[0]), C.byref(sv[0]), C.byref(pv[1]), C.byref(sv[1]), C.byref(pv[2]), C.byref(sv[2]))
+            ptrs = [p.value for p in pv]
+            while off < nbytes:
+                n = min(piece, nbytes - off)
+                if rank == 0:
+                    host = (C.c_uint8 * n).from_address(srcs[which].value + off)
+                    t[:n].copy_(torch.frombuffer(host, dtype=torch.uint8))
+                dist.broadcast(t[:n], src=0)
+                torch.cuda.synchronize()
+                HIP = _hip()
+                dst = ptrs[which] + off
+                if HIP.hipMemcpy(C.c_void_p(dst), C.c_void_p(t.data_ptr()), C.c_size_t(n), 3) != 0:
+                    raise RuntimeError("hipMemcpy D2D failed")
+                off += n
+        self.bcast_seconds = time.time() - t0
+        if self.lib.mi355x_index_commit() != 0:
+            raise RuntimeError("mi355x_index_commit failed")
+        self.uploaded = True
 
     def opt(self, **kw):
         o = self.lib.mem_opt_init()

@@ -153,7 +153,9 @@ def make_or_get(workdir, genome_mbp=3100.0, seed=38, rank=0, world=1, local_rank
             log("FM-index built on the GPU in %.1f s" % secs.value)
     if dist is not None:
         dist.barrier()
-    # one rank per GPU: every rank reads the (page-cached, node-local) files; on a multi-node run the device copy
-    # would come from rank 0 over RCCL instead (api.Engine.broadcast_index)
-    eng = api.Engine(prefix, device=local_rank)
+    # one rank per GPU.  Every rank maps the host side of the index from the node-local files (the host stages need pac
+    # and the contig table); the device side is uploaded once by rank 0 and broadcast to the other GPUs over RCCL/xGMI.
+    eng = api.Engine(prefix, device=local_rank, dist=dist, rank=rank)
+    if log and eng.bcast_seconds is not None:
+        log("index broadcast over RCCL: %.2f s" % eng.bcast_seconds)
     return BigIndex(prefix, pac, lens, eng)

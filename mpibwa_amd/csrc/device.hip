@@ -113,8 +113,7 @@ static void maybe_expand_sa()
 extern "C" int mi355x_index_alloc(int local_rank, const bwt_t *bwt, const bntseq_t *bns)
 {
 	require_device(local_rank);
-	alloc_index(bwt, bns);
-	g_idx.ready = true;
+	alloc_index(bwt, bns);   // buffers only: fill them with mi355x_index_d2d / ncclBroadcast, then mi355x_index_commit()
 	return 0;
 }
 
@@ -134,10 +133,30 @@ extern "C" int mi355x_sa_batch(int n, const uint64_t *k, uint64_t *sa_out, doubl
 extern "C" int mi355x_index_buffers(void **d_bwt, size_t *bwt_bytes, void **d_sa, size_t *sa_bytes, void **d_pac,
                                     size_t *pac_bytes)
 {
-	if (!g_idx.ready) return -1;
+	if (!g_idx.d_blk) return -1;
 	*d_bwt = g_idx.d_blk; *bwt_bytes = g_idx.blk_bytes;
 	*d_sa = g_idx.d_sa; *sa_bytes = g_idx.sa_bytes;
 	*d_pac = g_idx.d_pac; *pac_bytes = g_idx.pac_bytes;
+	return 0;
+}
+
+// Copy `bytes` from a device pointer owned by the caller (e.g. a torch tensor that has just received an RCCL broadcast)
+// into index buffer `which` (0 = occ blocks, 1 = sampled SA, 2 = pac), or out of it when to_index == 0.
+extern "C" int mi355x_index_d2d(int which, void *ext, size_t bytes, int to_index)
+{
+	if (!g_idx.d_blk) return -1;
+	void *buf = which == 0 ? g_idx.d_blk : which == 1 ? g_idx.d_sa : g_idx.d_pac;
+	size_t cap = which == 0 ? g_idx.blk_bytes : which == 1 ? g_idx.sa_bytes : g_idx.pac_bytes;
+	if (bytes > cap) return -2;
+	HIP_OK(hipMemcpy(to_index ? buf : ext, to_index ? ext : buf, bytes, hipMemcpyDeviceToDevice));
+	return 0;
+}
+// after the three buffers have been filled by broadcast: expand the dense SA and mark the index usable
+extern "C" int mi355x_index_commit(void)
+{
+	if (!g_idx.d_blk) return -1;
+	maybe_expand_sa();
+	g_idx.ready = true;
 	return 0;
 }
 

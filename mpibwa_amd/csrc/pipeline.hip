@@ -61,8 +61,13 @@ static int usable_cpus()
 static int host_threads(const mem_opt_t *opt)
 {
 	if (const char *e = getenv("MPIBWA_HOST_THREADS")) { int v = atoi(e); if (v > 0) return v; }
-	(void)opt;   // the result does not depend on the thread count (as in the reference), so use what the box gives us
-	return std::min(usable_cpus(), 128);
+	(void)opt;   // the result does not depend on the thread count (as in the reference), so use what the box gives us,
+	             // divided among the ranks that share this node (one rank per GPU)
+	int ranks = 1;
+	if (const char *e = getenv("LOCAL_WORLD_SIZE")) ranks = atoi(e);
+	else if (const char *e2 = getenv("OMPI_COMM_WORLD_LOCAL_SIZE")) ranks = atoi(e2);
+	if (ranks < 1) ranks = 1;
+	return std::max(1, std::min(usable_cpus() / ranks, 128));
 }
 
 template <class F>
