@@ -213,6 +213,7 @@ typedef struct {
 	uint64_t n_reads, n_intv, n_seeds, n_chains, n_ext;
 	double plan_ms, aln_ms, k_aln_ms;            /* SAM stage: decisions+collect, CIGAR kernel round trip, its HIP-event time */
 	uint64_t n_aln;
+	double phase1_ms;                            /* wall time of stages 2-6 (sub-batches overlap, so it is less than their sum) */
 } mi355x_stats_t;
 void mi355x_last_stats(mi355x_stats_t *st);
 

@@ -114,9 +114,10 @@ struct EvTimer {
 struct Workspace {
 	DevBuf seq, off, len, intv, nintv, cnt, scratch, nseeds, lrep, seed_off, rows, qbl, sa;
 	DevBuf chain_off, chains, seeds, srt, reg_off, regs, nregs, tab, areq, ahdr, apool, agap;
-	const void *host_bwt = nullptr;
 };
-static Workspace g_ws;
+static Workspace g_ws[2];   // one per concurrent sub-batch
+static Workspace g_gws;     // batch-wide buffers (packed reads, CIGAR requests)
+static const void *g_host_bwt = nullptr;
 
 } // namespace mbw
 
@@ -153,14 +154,14 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 {
 	const double t_begin = now_ms(), c_begin = cpu_sec();
 	DevIndex &ix = dev_index();
-	if (!ix.ready || g_ws.host_bwt != (const void *)bwt->bwt) {
+	if (!ix.ready || g_host_bwt != (const void *)bwt->bwt) {
 		// first call with this index: make it resident (one rank per GPU; LOCAL_RANK as set by torchrun / mpirun wrappers)
 		int lr = 0;
 		if (const char *e = getenv("LOCAL_RANK")) lr = atoi(e);
 		else if (const char *e2 = getenv("OMPI_COMM_WORLD_LOCAL_RANK")) lr = atoi(e2);
 		else if (const char *e3 = getenv("MV2_COMM_WORLD_LOCAL_RANK")) lr = atoi(e3);
 		if (!ix.ready) mi355x_index_upload(lr, bwt, bns, pac);
-		g_ws.host_bwt = (const void *)bwt->bwt;
+		g_host_bwt = (const void *)bwt->bwt;
 	}
 	HIP_OK(hipSetDevice(ix.device));
 	memset(&g_stats, 0, sizeof g_stats);
@@ -168,8 +169,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	const int n_thr = host_threads(opt);
 	const bool pe = (opt->flag & MEM_F_PE) != 0;
 	hipStream_t st = 0;
-	Workspace &W = g_ws;
-	EvTimer ev_smem, ev_sa, ev_ext;
+	Workspace &W = g_gws;
 
 	// ---- 1. encode + pack ----
 	std::vector<int64_t> off(n + 1);   // 16-byte aligned slot of every read in the packed buffer
@@ -200,191 +200,243 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	HIP_OK(hipMemcpyAsync(d_seq, flat.data(), flat.size(), hipMemcpyHostToDevice, st));
 	HIP_OK(hipMemcpyAsync(d_off, off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
 	HIP_OK(hipMemcpyAsync(d_len, lens.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+	HIP_OK(hipStreamSynchronize(st));
 	unsigned long long *d_cnt = (unsigned long long *)W.cnt.ensure(256);
 
-	// ---- 2. SMEM seeding (retry with a larger per-read capacity in the rare overflow case) ----
-	int cap = std::max(64, std::min(max_len, 96));
-	uint64_t *d_intv; int *d_nintv;
-	unsigned long long cnt[8];
-	size_t per_quad = 0;
-	const bool lane_k = smem_use_lane();
-	int n_quads = lane_k ? smem_lane_grid(max_len, &per_quad) : smem_grid_quads(max_len, &per_quad);
-	void *d_scr = W.scratch.ensure(per_quad * n_quads);
-	for (;;) {
-		d_intv = (uint64_t *)W.intv.ensure((size_t)n * cap * 32);
-		d_nintv = (int *)W.nintv.ensure((size_t)n * 4);
-		HIP_OK(hipMemsetAsync(d_cnt, 0, 256, st));
-		ev_smem.start(st);
-		if (lane_k) launch_smem_lane(st, ix.fm, smem_params(opt), n, d_seq, d_off, d_len, cap, d_intv, d_nintv, d_cnt, d_scr, per_quad, n_quads);
-		else launch_smem(st, ix.fm, smem_params(opt), n, d_seq, d_off, d_len, cap, d_intv, d_nintv, max_len, d_cnt, d_scr, per_quad, n_quads);
-		ev_smem.stop(st);
-		HIP_OK(hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, st));
-		HIP_OK(hipStreamSynchronize(st));
-		HIP_OK(hipGetLastError());
-		g_stats.k_smem_ms += ev_smem.ms();
-		if (cnt[2] == 0) break;
-		cap *= 4;
-	}
-	g_stats.smem_bytes = cnt[1] * 64 + (uint64_t)total_bases;
-	double t2 = now_ms();
-
-	// ---- 3. seed enumeration + SA lookup ----
-	int *d_nseeds = (int *)W.nseeds.ensure((size_t)n * 4), *d_lrep = (int *)W.lrep.ensure((size_t)n * 4);
-	launch_seed_prep(st, n, cap, d_intv, d_nintv, opt->max_occ, d_nseeds, d_lrep);
-	std::vector<int> nseeds(n), lrep(n), nintv(n);
-	HIP_OK(hipMemcpyAsync(nseeds.data(), d_nseeds, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-	HIP_OK(hipMemcpyAsync(lrep.data(), d_lrep, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-	HIP_OK(hipMemcpyAsync(nintv.data(), d_nintv, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-	HIP_OK(hipStreamSynchronize(st));
-	std::vector<int64_t> seed_off(n + 1);
-	seed_off[0] = 0;
-	uint64_t n_intv = 0;
-	for (int i = 0; i < n; ++i) { seed_off[i + 1] = seed_off[i] + nseeds[i]; n_intv += nintv[i]; }
-	const int64_t S = seed_off[n];
-	g_stats.smem_bytes += n_intv * 32;
-	g_stats.n_intv = n_intv; g_stats.n_seeds = S;
-	std::vector<uint64_t> sa(S);
-	std::vector<int32_t> qbl(2 * S);
-	if (S > 0) {
-		int64_t *d_seed_off = (int64_t *)W.seed_off.ensure((size_t)(n + 1) * 8);
-		uint64_t *d_rows = (uint64_t *)W.rows.ensure((size_t)S * 8), *d_sa = (uint64_t *)W.sa.ensure((size_t)S * 8);
-		int32_t *d_qbl = (int32_t *)W.qbl.ensure((size_t)S * 8);
-		HIP_OK(hipMemcpyAsync(d_seed_off, seed_off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
-		launch_seed_enum(st, n, cap, d_intv, d_nintv, opt->max_occ, d_seed_off, d_rows, d_qbl);
-		if (S > 0x7fffffff) die("too many seeds in one batch");
-		HIP_OK(hipMemsetAsync(d_cnt, 0, 256, st));
-		ev_sa.start(st);
-		if (ix.fm.sa_full) launch_sa_dense(st, ix.fm, (int)S, d_rows, d_sa);   // one 8-byte load per row
-		else launch_sa(st, ix.fm, (int)S, d_rows, d_sa, d_cnt);                // LF walk on the sampled SA
-		ev_sa.stop(st);
-		HIP_OK(hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, st));
-		HIP_OK(hipMemcpyAsync(sa.data(), d_sa, (size_t)S * 8, hipMemcpyDeviceToHost, st));
-		HIP_OK(hipMemcpyAsync(qbl.data(), d_qbl, (size_t)S * 8, hipMemcpyDeviceToHost, st));
-		HIP_OK(hipStreamSynchronize(st));
-		HIP_OK(hipGetLastError());
-		g_stats.k_sa_ms = ev_sa.ms();
-		g_stats.sa_bytes = ix.fm.sa_full ? (uint64_t)S * 16 : cnt[1] * 64 + (uint64_t)S * 8;
-	}
-	double t3 = now_ms();
-
-	// ---- 4. chaining and chain filters (host) ----
-	std::vector<std::vector<HChain>> chains(n);
-	parallel_for(n_thr, n, 256, [&](int i) {
-		int ns = nseeds[i];
-		if (ns == 0) return;
-		std::vector<HSeed> hs(ns);
-		for (int k = 0; k < ns; ++k) {
-			int64_t o = seed_off[i] + k;
-			hs[k].rbeg = (int64_t)sa[o]; hs[k].qbeg = qbl[2 * o]; hs[k].len = hs[k].score = qbl[2 * o + 1];
-		}
-		chains_from_seeds(opt, bns, seqs[i].l_seq, hs.data(), ns, lrep[i], chains[i]);
-		chain_filter(opt, chains[i]);
-		filter_chained_seeds(opt, bns, pac, seqs[i].l_seq, (const uint8_t *)seqs[i].seq, chains[i]);
-	});
-	std::vector<int> chain_off(n + 1), reg_off(n + 1);
-	chain_off[0] = reg_off[0] = 0;
-	for (int i = 0; i < n; ++i) {
-		int ns = 0;
-		for (auto &c : chains[i]) ns += (int)c.seeds.size();
-		chain_off[i + 1] = chain_off[i] + (int)chains[i].size();
-		reg_off[i + 1] = reg_off[i] + ns;
-	}
-	const int NC = chain_off[n], NS = reg_off[n];
-	g_stats.n_chains = NC;
-	std::vector<DevChain> hchains(NC);
-	std::vector<DevSeed> hseeds(NS);
-	std::vector<unsigned int> hsrt(NS);
-	parallel_for(n_thr, n, 512, [&](int i) {
-		int so = reg_off[i];
-		for (size_t c = 0; c < chains[i].size(); ++c) {
-			const HChain &ch = chains[i][c];
-			DevChain &d = hchains[chain_off[i] + c];
-			int ns = (int)ch.seeds.size();
-			d.seed_beg = so; d.n_seeds = ns; d.rid = ch.rid; d.frac_rep = ch.frac_rep;
-			d.far_beg = d.far_end = 0;
-			if (ns) {
-				int is_rev;
-				bns_depos(bns, ch.seeds[0].rbeg, &is_rev);
-				int64_t fb = bns->anns[ch.rid].offset, fe = fb + bns->anns[ch.rid].len;
-				if (is_rev) { int64_t t = fb; fb = (bns->l_pac << 1) - fe; fe = (bns->l_pac << 1) - t; }
-				d.far_beg = fb; d.far_end = fe;
-			}
-			// seeds are visited by decreasing score, ties by decreasing index (src/bwamem.c:662-667)
-			std::vector<uint64_t> key(ns);
-			for (int k = 0; k < ns; ++k) {
-				hseeds[so + k].rbeg = ch.seeds[k].rbeg; hseeds[so + k].qbeg = ch.seeds[k].qbeg; hseeds[so + k].len = ch.seeds[k].len;
-				key[k] = (uint64_t)ch.seeds[k].score << 32 | (uint32_t)k;
-			}
-			std::sort(key.begin(), key.end());   // keys are distinct, any sort gives the reference's order
-			for (int k = 0; k < ns; ++k) hsrt[so + k] = (uint32_t)key[k];
-			so += ns;
-		}
-	});
-	double t4 = now_ms();
-
-	// ---- 5. chain -> regions on the GPU ----
-	std::vector<DevReg> hregs(NS);
-	std::vector<int> nregs(n, 0);
-	if (NS > 0) {
-		const int TS = max_len + 2;
-		std::vector<int> tab(5 * TS);
-		for (int l = 0; l < TS; ++l) {
-			tab[l] = cal_max_gap(opt, l);
-			tab[TS + l] = clamp_band(opt, l, 1 << 28, opt->pen_clip5);
-			tab[2 * TS + l] = clamp_band(opt, l, 1 << 28, opt->pen_clip3);
-			tab[3 * TS + l] = (int)ceil(l * .95);
-			tab[4 * TS + l] = (int)floor(.1 * l);
-		}
-		int *d_tab = (int *)W.tab.ensure(tab.size() * 4);
-		int *d_chain_off = (int *)W.chain_off.ensure((size_t)(n + 1) * 4), *d_reg_off = (int *)W.reg_off.ensure((size_t)(n + 1) * 4);
-		DevChain *d_chains = (DevChain *)W.chains.ensure((size_t)std::max(NC, 1) * sizeof(DevChain));
-		DevSeed *d_seeds = (DevSeed *)W.seeds.ensure((size_t)NS * sizeof(DevSeed));
-		unsigned int *d_srt = (unsigned int *)W.srt.ensure((size_t)NS * 4);
-		DevReg *d_regs = (DevReg *)W.regs.ensure((size_t)NS * sizeof(DevReg));
-		int *d_nregs = (int *)W.nregs.ensure((size_t)n * 4);
-		HIP_OK(hipMemcpyAsync(d_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, st));
-		HIP_OK(hipMemcpyAsync(d_chain_off, chain_off.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, st));
-		HIP_OK(hipMemcpyAsync(d_reg_off, reg_off.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, st));
-		HIP_OK(hipMemcpyAsync(d_chains, hchains.data(), (size_t)NC * sizeof(DevChain), hipMemcpyHostToDevice, st));
-		HIP_OK(hipMemcpyAsync(d_seeds, hseeds.data(), (size_t)NS * sizeof(DevSeed), hipMemcpyHostToDevice, st));
-		HIP_OK(hipMemcpyAsync(d_srt, hsrt.data(), (size_t)NS * 4, hipMemcpyHostToDevice, st));
-		HIP_OK(hipMemsetAsync(d_cnt, 0, 256, st));
-		C2aParams cp;
-		cp.l_pac = bns->l_pac; cp.a = opt->a; cp.w = opt->w; cp.pen_clip5 = opt->pen_clip5; cp.pen_clip3 = opt->pen_clip3;
-		ExtParams ep;
-		memcpy(ep.mat, opt->mat, 25);
-		ep.o_del = opt->o_del; ep.e_del = opt->e_del; ep.o_ins = opt->o_ins; ep.e_ins = opt->e_ins; ep.zdrop = opt->zdrop;
-		ev_ext.start(st);
-		launch_c2a(st, cp, ep, n, d_seq, d_off, d_len, d_chain_off, d_chains, d_seeds, d_srt, d_reg_off, d_regs, d_nregs, d_tab, TS,
-		           (const uint8_t *)ix.d_pac, d_cnt, max_len);
-		ev_ext.stop(st);
-		HIP_OK(hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, st));
-		HIP_OK(hipMemcpyAsync(hregs.data(), d_regs, (size_t)NS * sizeof(DevReg), hipMemcpyDeviceToHost, st));
-		HIP_OK(hipMemcpyAsync(nregs.data(), d_nregs, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-		HIP_OK(hipStreamSynchronize(st));
-		HIP_OK(hipGetLastError());
-		g_stats.k_ext_ms = ev_ext.ms();
-		g_stats.ext_cells = cnt[0]; g_stats.n_ext = cnt[1];
-	}
-	double t5 = now_ms();
-
-	// ---- 6. region post-processing (host) ----
+	// ---- 2-6. seeding -> SA -> chaining -> extension -> region clean-up, on one or two sub-batches ----
+	// The stages of one sub-batch are strictly dependent (GPU, host, GPU, host), so two sub-batches run on two host
+	// threads with their own HIP stream and workspace: the GPU work of one overlaps the host work of the other.
 	std::vector<HRegV> regs(n);
-	parallel_for(n_thr, n, 256, [&](int i) {
-		HRegV &v = regs[i];
-		int m = nregs[i];
-		v.resize(m);
-		for (int k = 0; k < m; ++k) {
-			const DevReg &d = hregs[reg_off[i] + k];
-			HReg &r = v[k];
-			r.rb = d.rb; r.re = d.re; r.qb = d.qb; r.qe = d.qe; r.rid = d.rid; r.score = d.score; r.truesc = d.truesc;
-			r.w = d.w; r.seedcov = d.seedcov; r.seedlen0 = d.seedlen0; r.frac_rep = d.frac_rep;
+	struct P1 { double k_smem = 0, k_sa = 0, k_ext = 0, smem = 0, sa = 0, chain = 0, ext = 0, regs = 0; uint64_t smem_bytes = 0, sa_bytes = 0, cells = 0, n_ext = 0, n_intv = 0, n_seeds = 0, n_chains = 0; };
+	auto phase1 = [&](int lo, int hi, Workspace &W, hipStream_t st, int n_thr, P1 &ps) {
+		const int n = hi - lo;
+		bseq1_t *seqs_r = seqs + lo;
+		const int64_t *d_off_r = d_off + lo;
+		const int *d_len_r = d_len + lo;
+		HIP_OK(hipSetDevice(ix.device));
+		EvTimer ev_smem, ev_sa, ev_ext;
+		unsigned long long *d_cnt = (unsigned long long *)W.cnt.ensure(256);
+		unsigned long long cnt[8];
+		double t1 = now_ms();
+		uint64_t range_bases = 0;
+		for (int i = 0; i < n; ++i) range_bases += lens[lo + i];
+		// SMEM seeding (retry with a larger per-read capacity in the rare overflow case)
+		int cap = std::max(64, std::min(max_len, 96));
+		uint64_t *d_intv; int *d_nintv;
+		size_t per_quad = 0;
+		const bool lane_k = smem_use_lane();
+		int n_quads = lane_k ? smem_lane_grid(max_len, &per_quad) : smem_grid_quads(max_len, &per_quad);
+		void *d_scr = W.scratch.ensure(per_quad * n_quads);
+		for (;;) {
+			d_intv = (uint64_t *)W.intv.ensure((size_t)n * cap * 32);
+			d_nintv = (int *)W.nintv.ensure((size_t)n * 4);
+			HIP_OK(hipMemsetAsync(d_cnt, 0, 256, st));
+			ev_smem.start(st);
+			if (lane_k) launch_smem_lane(st, ix.fm, smem_params(opt), n, d_seq, d_off_r, d_len_r, cap, d_intv, d_nintv, d_cnt, d_scr, per_quad, n_quads);
+			else launch_smem(st, ix.fm, smem_params(opt), n, d_seq, d_off_r, d_len_r, cap, d_intv, d_nintv, max_len, d_cnt, d_scr, per_quad, n_quads);
+			ev_smem.stop(st);
+			HIP_OK(hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, st));
+			HIP_OK(hipStreamSynchronize(st));
+			HIP_OK(hipGetLastError());
+			ps.k_smem += ev_smem.ms();
+			if (cnt[2] == 0) break;
+			cap *= 4;
 		}
-		sort_dedup_patch(opt, bns, pac, (uint8_t *)seqs[i].seq, v);
-		for (HReg &r : v)
-			if (r.rid >= 0 && bns->anns[r.rid].is_alt) r.is_alt = 1;
-	});
+		ps.smem_bytes = cnt[1] * 64 + range_bases;
+		double t2 = now_ms();
+
+		// seed enumeration + SA lookup
+		int *d_nseeds = (int *)W.nseeds.ensure((size_t)n * 4), *d_lrep = (int *)W.lrep.ensure((size_t)n * 4);
+		launch_seed_prep(st, n, cap, d_intv, d_nintv, opt->max_occ, d_nseeds, d_lrep);
+		std::vector<int> nseeds(n), lrep(n), nintv(n);
+		HIP_OK(hipMemcpyAsync(nseeds.data(), d_nseeds, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+		HIP_OK(hipMemcpyAsync(lrep.data(), d_lrep, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+		HIP_OK(hipMemcpyAsync(nintv.data(), d_nintv, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+		HIP_OK(hipStreamSynchronize(st));
+		std::vector<int64_t> seed_off(n + 1);
+		seed_off[0] = 0;
+		uint64_t n_intv = 0;
+		for (int i = 0; i < n; ++i) { seed_off[i + 1] = seed_off[i] + nseeds[i]; n_intv += nintv[i]; }
+		const int64_t S = seed_off[n];
+		ps.smem_bytes += n_intv * 32;
+		ps.n_intv = n_intv; ps.n_seeds = S;
+		std::vector<uint64_t> sa(S);
+		std::vector<int32_t> qbl(2 * S);
+		if (S > 0) {
+			int64_t *d_seed_off = (int64_t *)W.seed_off.ensure((size_t)(n + 1) * 8);
+			uint64_t *d_rows = (uint64_t *)W.rows.ensure((size_t)S * 8), *d_sa = (uint64_t *)W.sa.ensure((size_t)S * 8);
+			int32_t *d_qbl = (int32_t *)W.qbl.ensure((size_t)S * 8);
+			HIP_OK(hipMemcpyAsync(d_seed_off, seed_off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+			launch_seed_enum(st, n, cap, d_intv, d_nintv, opt->max_occ, d_seed_off, d_rows, d_qbl);
+			if (S > 0x7fffffff) die("too many seeds in one batch");
+			HIP_OK(hipMemsetAsync(d_cnt, 0, 256, st));
+			ev_sa.start(st);
+			if (ix.fm.sa_full) launch_sa_dense(st, ix.fm, (int)S, d_rows, d_sa);   // one 8-byte load per row
+			else launch_sa(st, ix.fm, (int)S, d_rows, d_sa, d_cnt);                // LF walk on the sampled SA
+			ev_sa.stop(st);
+			HIP_OK(hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, st));
+			HIP_OK(hipMemcpyAsync(sa.data(), d_sa, (size_t)S * 8, hipMemcpyDeviceToHost, st));
+			HIP_OK(hipMemcpyAsync(qbl.data(), d_qbl, (size_t)S * 8, hipMemcpyDeviceToHost, st));
+			HIP_OK(hipStreamSynchronize(st));
+			HIP_OK(hipGetLastError());
+			ps.k_sa = ev_sa.ms();
+			ps.sa_bytes = ix.fm.sa_full ? (uint64_t)S * 16 : cnt[1] * 64 + (uint64_t)S * 8;
+		}
+		double t3 = now_ms();
+
+		// chaining and chain filters (host)
+		std::vector<std::vector<HChain>> chains(n);
+		parallel_for(n_thr, n, 256, [&](int i) {
+			int ns = nseeds[i];
+			if (ns == 0) return;
+			std::vector<HSeed> hs(ns);
+			for (int k = 0; k < ns; ++k) {
+				int64_t o = seed_off[i] + k;
+				hs[k].rbeg = (int64_t)sa[o]; hs[k].qbeg = qbl[2 * o]; hs[k].len = hs[k].score = qbl[2 * o + 1];
+			}
+			chains_from_seeds(opt, bns, seqs_r[i].l_seq, hs.data(), ns, lrep[i], chains[i]);
+			chain_filter(opt, chains[i]);
+			filter_chained_seeds(opt, bns, pac, seqs_r[i].l_seq, (const uint8_t *)seqs_r[i].seq, chains[i]);
+		});
+		std::vector<int> chain_off(n + 1), reg_off(n + 1);
+		chain_off[0] = reg_off[0] = 0;
+		for (int i = 0; i < n; ++i) {
+			int ns = 0;
+			for (auto &c : chains[i]) ns += (int)c.seeds.size();
+			chain_off[i + 1] = chain_off[i] + (int)chains[i].size();
+			reg_off[i + 1] = reg_off[i] + ns;
+		}
+		const int NC = chain_off[n], NS = reg_off[n];
+		ps.n_chains = NC;
+		std::vector<DevChain> hchains(NC);
+		std::vector<DevSeed> hseeds(NS);
+		std::vector<unsigned int> hsrt(NS);
+		parallel_for(n_thr, n, 512, [&](int i) {
+			int so = reg_off[i];
+			for (size_t c = 0; c < chains[i].size(); ++c) {
+				const HChain &ch = chains[i][c];
+				DevChain &d = hchains[chain_off[i] + c];
+				int ns = (int)ch.seeds.size();
+				d.seed_beg = so; d.n_seeds = ns; d.rid = ch.rid; d.frac_rep = ch.frac_rep;
+				d.far_beg = d.far_end = 0;
+				if (ns) {
+					int is_rev;
+					bns_depos(bns, ch.seeds[0].rbeg, &is_rev);
+					int64_t fb = bns->anns[ch.rid].offset, fe = fb + bns->anns[ch.rid].len;
+					if (is_rev) { int64_t t = fb; fb = (bns->l_pac << 1) - fe; fe = (bns->l_pac << 1) - t; }
+					d.far_beg = fb; d.far_end = fe;
+				}
+				// seeds are visited by decreasing score, ties by decreasing index (src/bwamem.c:662-667)
+				uint64_t small_key[64];
+				std::vector<uint64_t> big_key;
+				uint64_t *key = small_key;
+				if (ns > 64) { big_key.resize(ns); key = big_key.data(); }
+				for (int k = 0; k < ns; ++k) {
+					hseeds[so + k].rbeg = ch.seeds[k].rbeg; hseeds[so + k].qbeg = ch.seeds[k].qbeg; hseeds[so + k].len = ch.seeds[k].len;
+					key[k] = (uint64_t)ch.seeds[k].score << 32 | (uint32_t)k;
+				}
+				std::sort(key, key + ns);   // keys are distinct, any sort gives the reference's order
+				for (int k = 0; k < ns; ++k) hsrt[so + k] = (uint32_t)key[k];
+				so += ns;
+			}
+			std::vector<HChain>().swap(chains[i]);   // done with this read's chains
+		});
+		double t4 = now_ms();
+
+		// chain -> regions on the GPU
+		std::vector<DevReg> hregs(NS);
+		std::vector<int> nregs(n, 0);
+		if (NS > 0) {
+			const int TS = max_len + 2;
+			std::vector<int> tab(5 * TS);
+			for (int l = 0; l < TS; ++l) {
+				tab[l] = cal_max_gap(opt, l);
+				tab[TS + l] = clamp_band(opt, l, 1 << 28, opt->pen_clip5);
+				tab[2 * TS + l] = clamp_band(opt, l, 1 << 28, opt->pen_clip3);
+				tab[3 * TS + l] = (int)ceil(l * .95);
+				tab[4 * TS + l] = (int)floor(.1 * l);
+			}
+			int *d_tab = (int *)W.tab.ensure(tab.size() * 4);
+			int *d_chain_off = (int *)W.chain_off.ensure((size_t)(n + 1) * 4), *d_reg_off = (int *)W.reg_off.ensure((size_t)(n + 1) * 4);
+			DevChain *d_chains = (DevChain *)W.chains.ensure((size_t)std::max(NC, 1) * sizeof(DevChain));
+			DevSeed *d_seeds = (DevSeed *)W.seeds.ensure((size_t)NS * sizeof(DevSeed));
+			unsigned int *d_srt = (unsigned int *)W.srt.ensure((size_t)NS * 4);
+			DevReg *d_regs = (DevReg *)W.regs.ensure((size_t)NS * sizeof(DevReg));
+			int *d_nregs = (int *)W.nregs.ensure((size_t)n * 4);
+			HIP_OK(hipMemcpyAsync(d_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, st));
+			HIP_OK(hipMemcpyAsync(d_chain_off, chain_off.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, st));
+			HIP_OK(hipMemcpyAsync(d_reg_off, reg_off.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, st));
+			HIP_OK(hipMemcpyAsync(d_chains, hchains.data(), (size_t)NC * sizeof(DevChain), hipMemcpyHostToDevice, st));
+			HIP_OK(hipMemcpyAsync(d_seeds, hseeds.data(), (size_t)NS * sizeof(DevSeed), hipMemcpyHostToDevice, st));
+			HIP_OK(hipMemcpyAsync(d_srt, hsrt.data(), (size_t)NS * 4, hipMemcpyHostToDevice, st));
+			HIP_OK(hipMemsetAsync(d_cnt, 0, 256, st));
+			C2aParams cp;
+			cp.l_pac = bns->l_pac; cp.a = opt->a; cp.w = opt->w; cp.pen_clip5 = opt->pen_clip5; cp.pen_clip3 = opt->pen_clip3;
+			ExtParams ep;
+			memcpy(ep.mat, opt->mat, 25);
+			ep.o_del = opt->o_del; ep.e_del = opt->e_del; ep.o_ins = opt->o_ins; ep.e_ins = opt->e_ins; ep.zdrop = opt->zdrop;
+			ev_ext.start(st);
+			launch_c2a(st, cp, ep, n, d_seq, d_off_r, d_len_r, d_chain_off, d_chains, d_seeds, d_srt, d_reg_off, d_regs, d_nregs, d_tab, TS,
+			           (const uint8_t *)ix.d_pac, d_cnt, max_len);
+			ev_ext.stop(st);
+			HIP_OK(hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, st));
+			HIP_OK(hipMemcpyAsync(hregs.data(), d_regs, (size_t)NS * sizeof(DevReg), hipMemcpyDeviceToHost, st));
+			HIP_OK(hipMemcpyAsync(nregs.data(), d_nregs, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+			HIP_OK(hipStreamSynchronize(st));
+			HIP_OK(hipGetLastError());
+			ps.k_ext = ev_ext.ms();
+			ps.cells = cnt[0]; ps.n_ext = cnt[1];
+		}
+		double t5 = now_ms();
+
+		// region post-processing (host)
+		parallel_for(n_thr, n, 256, [&](int i) {
+			HRegV &v = regs[lo + i];
+			int m = nregs[i];
+			v.resize(m);
+			for (int k = 0; k < m; ++k) {
+				const DevReg &d = hregs[reg_off[i] + k];
+				HReg &r = v[k];
+				r.rb = d.rb; r.re = d.re; r.qb = d.qb; r.qe = d.qe; r.rid = d.rid; r.score = d.score; r.truesc = d.truesc;
+				r.w = d.w; r.seedcov = d.seedcov; r.seedlen0 = d.seedlen0; r.frac_rep = d.frac_rep;
+			}
+			sort_dedup_patch(opt, bns, pac, (uint8_t *)seqs_r[i].seq, v);
+			for (HReg &r : v)
+				if (r.rid >= 0 && bns->anns[r.rid].is_alt) r.is_alt = 1;
+		});
+		double t6 = now_ms();
+		ps.smem = t2 - t1; ps.sa = t3 - t2; ps.chain = t4 - t3; ps.ext = t5 - t4; ps.regs = t6 - t5;
+	};
+
+	int n_sub = 2;
+	if (const char *e = getenv("MPIBWA_SUBBATCH")) n_sub = atoi(e);
+	if (n_sub < 1) n_sub = 1;
+	if (n_sub > 2) n_sub = 2;
+	int min_sub = 40000;   // below this a chunk is not worth splitting
+	if (const char *e = getenv("MPIBWA_SUBBATCH_MIN")) min_sub = atoi(e);
+	if (n < min_sub) n_sub = 1;
+	P1 ps[2];
+	if (n_sub == 1) phase1(0, n, g_ws[0], st, n_thr, ps[0]);
+	else {
+		static hipStream_t s_streams[2] = {nullptr, nullptr};
+		if (!s_streams[0]) { HIP_OK(hipStreamCreateWithFlags(&s_streams[0], hipStreamNonBlocking)); HIP_OK(hipStreamCreateWithFlags(&s_streams[1], hipStreamNonBlocking)); }
+		int mid = (n / 2) & ~1;   // keep mates together
+		const int thr_each = std::max(1, (n_thr + 1) / 2);
+		std::thread other([&]() { phase1(mid, n, g_ws[1], s_streams[1], thr_each, ps[1]); });
+		phase1(0, mid, g_ws[0], s_streams[0], thr_each, ps[0]);
+		other.join();
+	}
+	for (int k = 0; k < n_sub; ++k) {
+		g_stats.k_smem_ms += ps[k].k_smem; g_stats.k_sa_ms += ps[k].k_sa; g_stats.k_ext_ms += ps[k].k_ext;
+		g_stats.smem_bytes += ps[k].smem_bytes; g_stats.sa_bytes += ps[k].sa_bytes; g_stats.ext_cells += ps[k].cells; g_stats.n_ext += ps[k].n_ext;
+		g_stats.n_intv += ps[k].n_intv; g_stats.n_seeds += ps[k].n_seeds; g_stats.n_chains += ps[k].n_chains;
+		// per-stage wall times of the sub-batches overlap in time: report the longest of each
+		g_stats.smem_ms = std::max(g_stats.smem_ms, ps[k].smem); g_stats.sa_ms = std::max(g_stats.sa_ms, ps[k].sa);
+		g_stats.chain_ms = std::max(g_stats.chain_ms, ps[k].chain); g_stats.ext_ms = std::max(g_stats.ext_ms, ps[k].ext);
+		g_stats.regs_ms = std::max(g_stats.regs_ms, ps[k].regs);
+	}
 	double t6 = now_ms();
+	g_stats.phase1_ms = t6 - t1;
 
 	// ---- 7. insert-size statistics over the whole batch ----
 	mem_pestat_t pes[4];
@@ -434,6 +486,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	}
 	double t8a = now_ms();
 	const size_t n_req = all_req.size();
+	unsigned long long cnt[8] = {0};
 	std::vector<AlnHdrH> hdr(n_req);
 	std::vector<uint8_t> pool;
 	if (gpu_aln && n_req) {
@@ -491,11 +544,10 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	double t8 = now_ms();
 	hprof_report("sam stage");
 	// release the per-read containers in parallel (millions of small blocks: serial destruction costs ~0.2 s per chunk)
-	parallel_for(n_thr, n, 1024, [&](int i) { std::vector<HChain>().swap(chains[i]); HRegV().swap(regs[i]); });
+	parallel_for(n_thr, n, 1024, [&](int i) { HRegV().swap(regs[i]); });
 	g_stats.n_reads = n;
 	g_stats.h2d_ms = t1 - t_begin;
-	g_stats.smem_ms = t2 - t1; g_stats.sa_ms = t3 - t2; g_stats.chain_ms = t4 - t3; g_stats.ext_ms = t5 - t4;
-	g_stats.regs_ms = t6 - t5; g_stats.pestat_ms = t7 - t6; g_stats.sam_ms = t8 - t7; g_stats.total_ms = now_ms() - t_begin;
+	g_stats.pestat_ms = t7 - t6; g_stats.sam_ms = t8 - t7; g_stats.total_ms = now_ms() - t_begin;
 	if (bwa_verbose >= 3)
 		fprintf(stderr, "[M::%s] Processed %d reads in %.3f CPU sec, %.3f real sec\n", "mem_process_seqs", n, cpu_sec() - c_begin,
 		        (t8 - t_begin) * 1e-3);

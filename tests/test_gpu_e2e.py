@@ -148,3 +148,19 @@ def test_edge_reads(both, genome):
     _cmp(eng, ref, [(n, a, None) for n, a, b in reads], dict(flag=0))
     # empty batch: returns without touching anything
     assert eng.process(eng.opt(flag=0), []) == []
+
+
+@needs_ref
+def test_overlapped_sub_batches_and_host_cigar_paths(both, reads_pe, monkeypatch):
+    """The two-sub-batch overlap (normally only used for big chunks) and the host-side CIGAR path give the same bytes."""
+    eng, ref = both
+    ra = simulate.reads_to_ascii(reads_pe)
+    want = ref.process(ref.opt(flag=abi.MEM_F_PE), ra)
+    monkeypatch.setenv("MPIBWA_SUBBATCH_MIN", "100")
+    assert eng.process(eng.opt(flag=abi.MEM_F_PE), ra) == want
+    monkeypatch.setenv("MPIBWA_SUBBATCH", "1")
+    assert eng.process(eng.opt(flag=abi.MEM_F_PE), ra) == want
+    monkeypatch.setenv("MPIBWA_HOST_CIGAR", "1")
+    assert eng.process(eng.opt(flag=abi.MEM_F_PE), ra) == want
+    monkeypatch.setenv("MPIBWA_SMEM", "lane")
+    assert eng.process(eng.opt(flag=abi.MEM_F_PE), ra) == want
