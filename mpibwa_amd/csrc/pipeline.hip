@@ -113,7 +113,7 @@ struct EvTimer {
 // device work buffers, grown on demand and kept across calls
 struct Workspace {
 	DevBuf seq, off, len, intv, nintv, cnt, scratch, nseeds, lrep, seed_off, rows, qbl, sa;
-	DevBuf chain_off, chains, seeds, srt, reg_off, regs, nregs, tab, areq, ahdr, apool, agap;
+	DevBuf chain_off, chains, seeds, srt, reg_off, regs, nregs, tab, areq, ahdr, apool, agap, acnt, areq2, ahdr2, apool2, acnt2;
 };
 static Workspace g_ws[2];   // one per concurrent sub-batch
 static Workspace g_gws;     // batch-wide buffers (packed reads, CIGAR requests)
@@ -447,24 +447,50 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	double t7 = now_ms();
 
 	// ---- 8. pairing decisions, then CIGAR/MD/NM on the GPU, then SAM text ----
-	// A: decisions + a COLLECT pass that records which regions need a global re-alignment (mem_reg2aln's DP);
-	// B: aln_kernel does them all at once;  C: the same emission again (REPLAY) with the results plugged in.
+	// Per part of the chunk:  A  decisions + a COLLECT pass that records which regions need a global re-alignment
+	// (mem_reg2aln's DP);  B  aln_kernel does them all at once;  C  the same emission again (REPLAY) with the results
+	// plugged in.  Two parts are software-pipelined so that B of one part runs while the host does A / C of the other.
 	const int n_units = pe ? n >> 1 : n;
 	std::vector<PairPlan> plans(pe ? n_units : 0);
 	const bool gpu_aln = getenv("MPIBWA_HOST_CIGAR") == nullptr;
-	std::vector<AlnReqH> all_req;
-	std::vector<uint32_t> unit_base(n_units + 1, 0);
-	{
-		// one request list per block of 256 units (a block is handled by exactly one thread); each unit remembers (first, count)
-		const int n_blk = (n_units + 255) / 256;
+	const int n_parts = (gpu_aln && n_units >= 20000 && n_sub > 1) ? 2 : 1;
+	struct Part {
+		int lo = 0, hi = 0;
+		std::vector<AlnReqH> req;
+		std::vector<uint32_t> base;       // first request of every unit of the part
+		std::vector<AlnHdrH> hdr;
+		std::vector<uint8_t> pool;
+		unsigned long long cnt[8] = {0};
+		AlnHdr *d_hdr = nullptr; uint8_t *d_pool = nullptr; unsigned long long *d_cnt = nullptr;
+		size_t pool_bytes = 0;
+		hipStream_t st = 0;
+		EvTimer ev;
+	};
+	Part parts[2];
+	static hipStream_t a_streams[2] = {nullptr, nullptr};
+	if (!a_streams[0]) { HIP_OK(hipStreamCreateWithFlags(&a_streams[0], hipStreamNonBlocking)); HIP_OK(hipStreamCreateWithFlags(&a_streams[1], hipStreamNonBlocking)); }
+	std::vector<int> gaptab(max_len + 2);
+	for (int l = 0; l <= max_len + 1; ++l) {   // max_gap of bwa_gen_cigar2 (src/bwa.c:155-158), a function of l_query only
+		int max_ins = (int)((double)(((l + 1) >> 1) * opt->mat[0] - opt->o_ins) / opt->e_ins + 1.);
+		int max_del = (int)((double)(((l + 1) >> 1) * opt->mat[0] - opt->o_del) / opt->e_del + 1.);
+		int g = max_ins > max_del ? max_ins : max_del;
+		gaptab[l] = g > 1 ? g : 1;
+	}
+	int *d_gap = (int *)W.agap.ensure(gaptab.size() * 4);
+	HIP_OK(hipMemcpy(d_gap, gaptab.data(), gaptab.size() * 4, hipMemcpyHostToDevice));
+	double plan_ms = 0, aln_wait_ms = 0;
+
+	auto collect = [&](Part &P) {   // A
+		double ta = now_ms();
+		const int nu = P.hi - P.lo, n_blk = (nu + 255) / 256;
 		std::vector<std::vector<AlnReqH>> blk_req(n_blk);
-		std::vector<uint32_t> u_first(n_units), u_cnt(n_units);
+		std::vector<uint32_t> u_first(nu), u_cnt(nu);
 		parallel_for(n_thr, n_blk, 1, [&](int blk) {
 			std::vector<AlnReqH> &rq = blk_req[blk];
 			rq.reserve(256 * 3);
 			AlnCtx ctx;
 			ctx.mode = AlnCtx::COLLECT; ctx.reqs = &rq;
-			const int lo = blk * 256, hi = std::min(n_units, lo + 256);
+			const int lo = P.lo + blk * 256, hi = std::min(P.hi, lo + 256);
 			for (int i = lo; i < hi; ++i) {
 				const size_t before = rq.size();
 				if (pe) {
@@ -475,72 +501,83 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 					if (opt->flag & MEM_F_PRIMARY5) reorder_primary5(opt->T, regs[i]);
 					if (gpu_aln) reg2sam(opt, bns, pac, &seqs[i], regs[i], 0, 0, &ctx, i);
 				}
-				u_first[i] = (uint32_t)before; u_cnt[i] = (uint32_t)(rq.size() - before);
+				u_first[i - P.lo] = (uint32_t)before; u_cnt[i - P.lo] = (uint32_t)(rq.size() - before);
 			}
 		});
-		for (int i = 0; i < n_units; ++i) unit_base[i + 1] = unit_base[i] + u_cnt[i];
-		all_req.resize(unit_base[n_units]);
-		parallel_for(n_thr, n_units, 4096, [&](int i) {
-			if (u_cnt[i]) memcpy(&all_req[unit_base[i]], &blk_req[i >> 8][u_first[i]], (size_t)u_cnt[i] * sizeof(AlnReqH));
+		P.base.assign(nu + 1, 0);
+		for (int i = 0; i < nu; ++i) P.base[i + 1] = P.base[i] + u_cnt[i];
+		P.req.resize(P.base[nu]);
+		parallel_for(n_thr, nu, 4096, [&](int i) {
+			if (u_cnt[i]) memcpy(&P.req[P.base[i]], &blk_req[i >> 8][u_first[i]], (size_t)u_cnt[i] * sizeof(AlnReqH));
 		});
-	}
-	double t8a = now_ms();
-	const size_t n_req = all_req.size();
-	unsigned long long cnt[8] = {0};
-	std::vector<AlnHdrH> hdr(n_req);
-	std::vector<uint8_t> pool;
-	if (gpu_aln && n_req) {
-		const int tcap = max_len + 256;
-		std::vector<int> gaptab(max_len + 2);
-		for (int l = 0; l <= max_len + 1; ++l) {   // max_gap of bwa_gen_cigar2 (src/bwa.c:155-158), a function of l_query only
-			int max_ins = (int)((double)(((l + 1) >> 1) * opt->mat[0] - opt->o_ins) / opt->e_ins + 1.);
-			int max_del = (int)((double)(((l + 1) >> 1) * opt->mat[0] - opt->o_del) / opt->e_del + 1.);
-			int g = max_ins > max_del ? max_ins : max_del;
-			gaptab[l] = g > 1 ? g : 1;
-		}
-		const size_t pool_bytes = n_req * 96 + (1 << 20);
-		AlnReq *d_req = (AlnReq *)W.areq.ensure(n_req * sizeof(AlnReq));
-		AlnHdr *d_hdr = (AlnHdr *)W.ahdr.ensure(n_req * sizeof(AlnHdr));
-		uint8_t *d_pool = (uint8_t *)W.apool.ensure(pool_bytes);
-		int *d_gap = (int *)W.agap.ensure(gaptab.size() * 4);
+		plan_ms += now_ms() - ta;
+	};
+	auto launch = [&](Part &P, int slot) {   // B (asynchronous)
+		const size_t n_req = P.req.size();
+		P.hdr.resize(n_req);
+		if (!gpu_aln || n_req == 0) return;
 		static_assert(sizeof(AlnReq) == sizeof(AlnReqH) && sizeof(AlnHdr) == sizeof(AlnHdrH), "host/device record layouts differ");
-		HIP_OK(hipMemcpyAsync(d_req, all_req.data(), n_req * sizeof(AlnReq), hipMemcpyHostToDevice, st));
-		HIP_OK(hipMemcpyAsync(d_gap, gaptab.data(), gaptab.size() * 4, hipMemcpyHostToDevice, st));
-		HIP_OK(hipMemsetAsync(d_cnt, 0, 256, st));
+		P.st = a_streams[slot];
+		P.pool_bytes = n_req * 96 + (1 << 20);
+		AlnReq *d_req = (AlnReq *)(slot ? W.areq2 : W.areq).ensure(n_req * sizeof(AlnReq));
+		P.d_hdr = (AlnHdr *)(slot ? W.ahdr2 : W.ahdr).ensure(n_req * sizeof(AlnHdr));
+		P.d_pool = (uint8_t *)(slot ? W.apool2 : W.apool).ensure(P.pool_bytes);
+		P.d_cnt = (unsigned long long *)(slot ? W.acnt2 : W.acnt).ensure(256);
+		HIP_OK(hipMemcpyAsync(d_req, P.req.data(), n_req * sizeof(AlnReq), hipMemcpyHostToDevice, P.st));
+		HIP_OK(hipMemsetAsync(P.d_cnt, 0, 256, P.st));
 		AlnParams ap;
 		ap.l_pac = bns->l_pac; ap.a = opt->a; ap.w = opt->w;
 		ExtParams ep;
 		memcpy(ep.mat, opt->mat, 25);
 		ep.o_del = opt->o_del; ep.e_del = opt->e_del; ep.o_ins = opt->o_ins; ep.e_ins = opt->e_ins; ep.zdrop = opt->zdrop;
-		EvTimer ev_aln;
-		ev_aln.start(st);
-		launch_aln(st, ap, ep, (int)n_req, d_req, d_seq, d_off, (const uint8_t *)ix.d_pac, d_gap, d_hdr, d_pool, d_cnt, pool_bytes, max_len, tcap);
-		ev_aln.stop(st);
-		HIP_OK(hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, st));
-		HIP_OK(hipMemcpyAsync(hdr.data(), d_hdr, n_req * sizeof(AlnHdr), hipMemcpyDeviceToHost, st));
-		HIP_OK(hipStreamSynchronize(st));
+		P.ev.start(P.st);
+		launch_aln(P.st, ap, ep, (int)n_req, d_req, d_seq, d_off, (const uint8_t *)ix.d_pac, d_gap, P.d_hdr, P.d_pool, P.d_cnt, P.pool_bytes, max_len,
+		           max_len + 256);
+		P.ev.stop(P.st);   // results are fetched in finish(): a D2H copy into pageable memory would block the host here
+	};
+	auto finish = [&](Part &P) {   // wait for B, fetch the pool
+		const size_t n_req = P.req.size();
+		if (!gpu_aln || n_req == 0) return;
+		double ta = now_ms();
+		HIP_OK(hipStreamSynchronize(P.st));
 		HIP_OK(hipGetLastError());
-		g_stats.k_aln_ms = ev_aln.ms();
-		size_t used = std::min<size_t>(cnt[0], pool_bytes);
-		pool.resize(used + 16);
-		if (used) HIP_OK(hipMemcpy(pool.data(), d_pool, used, hipMemcpyDeviceToHost));
-		g_stats.n_aln = n_req;
-	}
-	double t8b = now_ms();
-	if (pe) {
-		parallel_for(n_thr, n_units, 128, [&](int i) {
-			AlnCtx ctx;
-			if (gpu_aln) { ctx.mode = AlnCtx::REPLAY; ctx.hdr = hdr.data(); ctx.pool = pool.data(); ctx.cursor = unit_base[i]; }
-			sam_pe_emit(opt, bns, pac, pes, &seqs[i << 1], &regs[i << 1], plans[i], gpu_aln ? &ctx : nullptr, i << 1);
-		});
+		HIP_OK(hipMemcpy(P.cnt, P.d_cnt, 64, hipMemcpyDeviceToHost));
+		HIP_OK(hipMemcpy(P.hdr.data(), P.d_hdr, n_req * sizeof(AlnHdr), hipMemcpyDeviceToHost));
+		g_stats.k_aln_ms += P.ev.ms();
+		size_t used = std::min<size_t>(P.cnt[0], P.pool_bytes);
+		P.pool.resize(used + 16);
+		if (used) HIP_OK(hipMemcpy(P.pool.data(), P.d_pool, used, hipMemcpyDeviceToHost));
+		g_stats.n_aln += n_req;
+		aln_wait_ms += now_ms() - ta;
+	};
+	auto replay = [&](Part &P) {   // C
+		if (pe) {
+			parallel_for(n_thr, P.hi - P.lo, 128, [&](int k) {
+				const int i = P.lo + k;
+				AlnCtx ctx;
+				if (gpu_aln) { ctx.mode = AlnCtx::REPLAY; ctx.hdr = P.hdr.data(); ctx.pool = P.pool.data(); ctx.cursor = P.base[k]; }
+				sam_pe_emit(opt, bns, pac, pes, &seqs[i << 1], &regs[i << 1], plans[i], gpu_aln ? &ctx : nullptr, i << 1);
+			});
+		} else {
+			parallel_for(n_thr, P.hi - P.lo, 256, [&](int k) {
+				const int i = P.lo + k;
+				AlnCtx ctx;
+				if (gpu_aln) { ctx.mode = AlnCtx::REPLAY; ctx.hdr = P.hdr.data(); ctx.pool = P.pool.data(); ctx.cursor = P.base[k]; }
+				reg2sam(opt, bns, pac, &seqs[i], regs[i], 0, 0, gpu_aln ? &ctx : nullptr, i);
+			});
+		}
+	};
+	if (n_parts == 1) {
+		parts[0].lo = 0; parts[0].hi = n_units;
+		collect(parts[0]); launch(parts[0], 0); finish(parts[0]); replay(parts[0]);
 	} else {
-		parallel_for(n_thr, n_units, 256, [&](int i) {
-			AlnCtx ctx;
-			if (gpu_aln) { ctx.mode = AlnCtx::REPLAY; ctx.hdr = hdr.data(); ctx.pool = pool.data(); ctx.cursor = unit_base[i]; }
-			reg2sam(opt, bns, pac, &seqs[i], regs[i], 0, 0, gpu_aln ? &ctx : nullptr, i);
-		});
+		parts[0].lo = 0; parts[0].hi = n_units / 2; parts[1].lo = n_units / 2; parts[1].hi = n_units;
+		collect(parts[0]); launch(parts[0], 0);
+		collect(parts[1]); launch(parts[1], 1);
+		finish(parts[0]); replay(parts[0]);
+		finish(parts[1]); replay(parts[1]);
 	}
-	g_stats.plan_ms = t8a - t7; g_stats.aln_ms = t8b - t8a;
+	g_stats.plan_ms = plan_ms; g_stats.aln_ms = aln_wait_ms;
 	double t8 = now_ms();
 	hprof_report("sam stage");
 	// release the per-read containers in parallel (millions of small blocks: serial destruction costs ~0.2 s per chunk)
