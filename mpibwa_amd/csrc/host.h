@@ -2,7 +2,10 @@
 #ifndef MBW_HOST_H
 #define MBW_HOST_H
 #include "internal.h"
+#include <cstdlib>
+#include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace mbw {
@@ -32,7 +35,56 @@ struct HReg {            // mem_alnreg_t, src/bwamem.h:59-77
 	float frac_rep = 0;
 	uint64_t hash = 0;
 };
-typedef std::vector<HReg> HRegV;
+// The regions of one read.  A plain growable array, but able to live in a slice of a batch-wide arena (attach) so
+// that a chunk of 667 k reads does not cost 667 k heap blocks that are later freed by other threads; it only falls back
+// to its own heap block when a read outgrows its slice (mate rescue adds a few regions at most).
+class HRegV {
+	HReg *p_ = nullptr;
+	uint32_t n_ = 0, cap_ = 0;
+	bool own_ = false;
+	void grow(uint32_t want)
+	{
+		uint32_t nc = cap_ ? cap_ * 2 : 4;
+		if (nc < want) nc = want;
+		HReg *q = (HReg *)malloc((size_t)nc * sizeof(HReg));
+		if (n_) memcpy((void *)q, (const void *)p_, (size_t)n_ * sizeof(HReg));
+		if (own_) free(p_);
+		p_ = q; cap_ = nc; own_ = true;
+	}
+public:
+	HRegV() {}
+	~HRegV() { if (own_) free(p_); }
+	HRegV(const HRegV &) = delete;
+	HRegV &operator=(const HRegV &) = delete;
+	HRegV(HRegV &&o) noexcept : p_(o.p_), n_(o.n_), cap_(o.cap_), own_(o.own_) { o.p_ = nullptr; o.n_ = o.cap_ = 0; o.own_ = false; }
+	HRegV &operator=(HRegV &&o) noexcept { swap(o); return *this; }
+	void attach(HReg *ext, uint32_t cap) { if (own_) free(p_); p_ = ext; n_ = 0; cap_ = cap; own_ = false; }
+	void swap(HRegV &o) { std::swap(p_, o.p_); std::swap(n_, o.n_); std::swap(cap_, o.cap_); std::swap(own_, o.own_); }
+	size_t size() const { return n_; }
+	bool empty() const { return n_ == 0; }
+	HReg *data() { return p_; }
+	const HReg *data() const { return p_; }
+	HReg *begin() { return p_; }
+	HReg *end() { return p_ + n_; }
+	const HReg *begin() const { return p_; }
+	const HReg *end() const { return p_ + n_; }
+	HReg &operator[](size_t i) { return p_[i]; }
+	const HReg &operator[](size_t i) const { return p_[i]; }
+	void push_back(const HReg &r) { if (n_ == cap_) grow(n_ + 1); p_[n_++] = r; }
+	void insert(HReg *pos, const HReg &r)
+	{
+		size_t at = pos - p_;
+		if (n_ == cap_) grow(n_ + 1);
+		memmove((void *)(p_ + at + 1), (const void *)(p_ + at), (n_ - at) * sizeof(HReg));
+		p_[at] = r; ++n_;
+	}
+	void resize(size_t m)
+	{
+		if (m > cap_) grow((uint32_t)m);
+		for (size_t i = n_; i < m; ++i) p_[i] = HReg();
+		n_ = (uint32_t)m;
+	}
+};
 
 struct HAln {            // mem_aln_t, src/bwamem.h:87-98 (cigar + MD kept as separate members)
 	int64_t pos = 0;

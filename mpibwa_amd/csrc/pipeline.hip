@@ -111,7 +111,14 @@ struct EvTimer {
 };
 
 // device work buffers, grown on demand and kept across calls
+// grow-only host buffer kept across calls (no page faults / frees per chunk)
+struct HostBuf {
+	void *p = nullptr; size_t cap = 0;
+	void *ensure(size_t bytes) { if (bytes > cap) { free(p); cap = bytes + bytes / 4 + 4096; p = malloc(cap); if (!p) die("out of memory"); } return p; }
+};
+
 struct Workspace {
+	HostBuf reg_arena;
 	DevBuf seq, off, len, intv, nintv, cnt, scratch, nseeds, lrep, seed_off, rows, qbl, sa;
 	DevBuf chain_off, chains, seeds, srt, reg_off, regs, nregs, tab, areq, ahdr, apool, agap, acnt, areq2, ahdr2, apool2, acnt2;
 };
@@ -389,10 +396,16 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		}
 		double t5 = now_ms();
 
-		// region post-processing (host)
+		// region post-processing (host); every read gets a slice of the batch-wide arena: its regions + room for rescued mates
+		const int SLACK = 4;
+		std::vector<int64_t> slice(n + 1);
+		slice[0] = 0;
+		for (int i = 0; i < n; ++i) slice[i + 1] = slice[i] + nregs[i] + SLACK;
+		HReg *arena = (HReg *)W.reg_arena.ensure((size_t)slice[n] * sizeof(HReg));
 		parallel_for(n_thr, n, 256, [&](int i) {
 			HRegV &v = regs[lo + i];
 			int m = nregs[i];
+			v.attach(arena + slice[i], (uint32_t)(m + SLACK));
 			v.resize(m);
 			for (int k = 0; k < m; ++k) {
 				const DevReg &d = hregs[reg_off[i] + k];
@@ -581,7 +594,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	double t8 = now_ms();
 	hprof_report("sam stage");
 	// release the per-read containers in parallel (millions of small blocks: serial destruction costs ~0.2 s per chunk)
-	parallel_for(n_thr, n, 1024, [&](int i) { HRegV().swap(regs[i]); });
+	parallel_for(n_thr, n, 8192, [&](int i) { HRegV().swap(regs[i]); });   // only reads that outgrew their arena slice own memory
 	g_stats.n_reads = n;
 	g_stats.h2d_ms = t1 - t_begin;
 	g_stats.pestat_ms = t7 - t6; g_stats.sam_ms = t8 - t7; g_stats.total_ms = now_ms() - t_begin;
