@@ -146,11 +146,21 @@ KswResult ksw_align2(int qlen, uint8_t *query, int tlen, uint8_t *target, const 
 
 // ---- per-read stages ----
 int  cal_max_gap(const mem_opt_t *opt, int qlen);
+// per-thread scratch of the chaining stage, recycled from read to read (no heap traffic once warm); the HChain
+// pointers handed out stay valid until the next chains_from_seeds() on the same scratch
+struct ChainScratch {
+	struct Impl;
+	Impl *p;
+	ChainScratch();
+	~ChainScratch();
+	ChainScratch(const ChainScratch &) = delete;
+	ChainScratch &operator=(const ChainScratch &) = delete;
+};
 void chains_from_seeds(const mem_opt_t *opt, const bntseq_t *bns, int l_query, const HSeed *seeds, int n_seeds, int l_rep,
-                       std::vector<HChain> &chains);
-void chain_filter(const mem_opt_t *opt, std::vector<HChain> &chains);
+                       ChainScratch &S, std::vector<HChain *> &chains);
+void chain_filter(const mem_opt_t *opt, ChainScratch &S, std::vector<HChain *> &chains);
 void filter_chained_seeds(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, int l_query, const uint8_t *query,
-                          std::vector<HChain> &chains);
+                          std::vector<HChain *> &chains);
 int  sort_dedup_patch(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, uint8_t *query, HRegV &regs);
 int  mark_primary_se(const mem_opt_t *opt, HRegV &a, int64_t id);
 void reorder_primary5(int T, HRegV &a);
@@ -163,7 +173,7 @@ void reg2sam(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, bseq
              AlnCtx *ctx = nullptr, int read_idx = 0);
 
 // ---- per-batch / per-pair stages (src/bwamem_pair.c) ----
-void pestat(const mem_opt_t *opt, int64_t l_pac, int n, const HRegV *regs, mem_pestat_t pes[4]);
+void pestat(const mem_opt_t *opt, int64_t l_pac, int n, const HRegV *regs, mem_pestat_t pes[4], int n_threads = 1);
 int  sam_pe(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, const mem_pestat_t pes[4], uint64_t id, bseq1_t s[2],
             HRegV a[2]);
 // the same in two halves: decisions (mutates a[]), then emission (pure; honours ctx, read0 = index of s[0] in the batch)

@@ -98,25 +98,26 @@ namespace {
 struct BTree {
 	static const int T = 5, MAXK = 2 * T - 1;
 	struct Node {
-		bool internal = false;
-		int n = 0;
+		bool internal;
+		int n;
 		int key[MAXK];
-		Node *child[MAXK + 1];
+		int child[MAXK + 1];   // indices into `nodes`
 	};
-	std::vector<std::unique_ptr<Node>> pool;
-	Node *root;
+	std::vector<Node> &nodes;  // recycled across reads by the caller
+	int root;
 	int n_keys = 0;
 	const std::vector<HChain> &ch;
 
-	explicit BTree(const std::vector<HChain> &chains) : ch(chains) { root = make(); }
-	Node *make()
+	BTree(const std::vector<HChain> &chains, std::vector<Node> &pool) : nodes(pool), ch(chains) { nodes.clear(); root = make(); }
+	int make()
 	{
-		pool.emplace_back(new Node());
-		return pool.back().get();
+		nodes.emplace_back();
+		nodes.back().internal = false; nodes.back().n = 0;
+		return (int)nodes.size() - 1;
 	}
 	int cmp(int64_t a, int64_t b) const { return (b < a) - (a < b); }
 	// index of the first key >= pos, stepped back by one when that key is > pos;
-	// *r = sign(pos - key[returned+?]) exactly as the reference's __kb_getp_aux
+	// *r = sign(pos - key[...]) exactly as the reference's __kb_getp_aux
 	int locate(const Node *x, int64_t pos, int *r) const
 	{
 		int tr, begin = 0, end = x->n;
@@ -134,42 +135,43 @@ struct BTree {
 	// closest key <= pos on the search path (or -1)
 	int lower(int64_t pos) const
 	{
-		int low = -1, r = 0;
-		const Node *x = root;
-		while (x) {
+		int low = -1, r = 0, xi = root;
+		for (;;) {
+			const Node *x = &nodes[xi];
 			int i = locate(x, pos, &r);
 			if (i >= 0 && r == 0) return x->key[i];
 			if (i >= 0) low = x->key[i];
 			if (!x->internal) return low;
-			x = x->child[i + 1];
+			xi = x->child[i + 1];
 		}
-		return low;
 	}
-	void split(Node *x, int i, Node *y)
+	void split(int xi, int i, int yi)
 	{
-		Node *z = make();
+		int zi = make();   // may move `nodes`: take the pointers afterwards
+		Node *x = &nodes[xi], *y = &nodes[yi], *z = &nodes[zi];
 		z->internal = y->internal;
 		z->n = T - 1;
 		memcpy(z->key, y->key + T, sizeof(int) * (T - 1));
-		if (y->internal) memcpy(z->child, y->child + T, sizeof(Node *) * T);
+		if (y->internal) memcpy(z->child, y->child + T, sizeof(int) * T);
 		y->n = T - 1;
-		memmove(x->child + i + 2, x->child + i + 1, sizeof(Node *) * (x->n - i));
-		x->child[i + 1] = z;
+		memmove(x->child + i + 2, x->child + i + 1, sizeof(int) * (x->n - i));
+		x->child[i + 1] = zi;
 		memmove(x->key + i + 1, x->key + i, sizeof(int) * (x->n - i));
 		x->key[i] = y->key[T - 1];
 		++x->n;
 	}
-	void put_nonfull(Node *x, int k)
+	void put_nonfull(int xi, int k)
 	{
 		int64_t pos = ch[k].pos;
-		while (x->internal) {
-			int i = locate(x, pos, 0) + 1;
-			if (x->child[i]->n == MAXK) {
-				split(x, i, x->child[i]);
-				if (cmp(pos, ch[x->key[i]].pos) > 0) ++i;
+		while (nodes[xi].internal) {
+			int i = locate(&nodes[xi], pos, 0) + 1;
+			if (nodes[nodes[xi].child[i]].n == MAXK) {
+				split(xi, i, nodes[xi].child[i]);
+				if (cmp(pos, ch[nodes[xi].key[i]].pos) > 0) ++i;
 			}
-			x = x->child[i];
+			xi = nodes[xi].child[i];
 		}
+		Node *x = &nodes[xi];
 		int i = locate(x, pos, 0);
 		if (i != x->n - 1) memmove(x->key + i + 2, x->key + i + 1, (x->n - i - 1) * sizeof(int));
 		x->key[i + 1] = k;
@@ -178,21 +180,23 @@ struct BTree {
 	void put(int k)
 	{
 		++n_keys;
-		Node *r = root;
-		if (r->n == MAXK) {
-			Node *s = make();
-			root = s; s->internal = true; s->n = 0;
-			s->child[0] = r;
-			split(s, 0, r);
-			r = s;
+		int r = root;
+		if (nodes[r].n == MAXK) {
+			int si = make();
+			root = si; nodes[si].internal = true; nodes[si].n = 0;
+			nodes[si].child[0] = r;
+			split(si, 0, r);
+			r = si;
 		}
 		put_nonfull(r, k);
 	}
-	void inorder(const Node *x, std::vector<int> &out) const
+	void inorder(int xi, std::vector<int> &out) const
 	{
+		const Node *x = &nodes[xi];
 		for (int i = 0; i < x->n; ++i) {
 			if (x->internal) inorder(x->child[i], out);
-			out.push_back(x->key[i]);
+			out.push_back(nodes[xi].key[i]);
+			x = &nodes[xi];
 		}
 		if (x->internal) inorder(x->child[x->n], out);
 	}
@@ -235,13 +239,24 @@ int chain_weight(const HChain &c)
 
 } // namespace
 
-void chains_from_seeds(const mem_opt_t *opt, const bntseq_t *bns, int l_query, const HSeed *seeds, int n_seeds, int l_rep,
-                       std::vector<HChain> &chains)
-{
-	chains.clear();
+// Scratch recycled from read to read by one thread: chain objects (their seed vectors keep their capacity), B-tree nodes.
+struct ChainScratch::Impl {
 	std::vector<HChain> pool;
-	pool.reserve(n_seeds ? n_seeds : 1);   // indices stay valid; reserve avoids moving vectors around
-	BTree tree(pool);
+	size_t used = 0;
+	std::vector<BTree::Node> nodes;
+	std::vector<int> order, kept;
+};
+ChainScratch::ChainScratch() : p(new Impl()) {}
+ChainScratch::~ChainScratch() { delete p; }
+
+void chains_from_seeds(const mem_opt_t *opt, const bntseq_t *bns, int l_query, const HSeed *seeds, int n_seeds, int l_rep,
+                       ChainScratch &S, std::vector<HChain *> &chains)
+{
+	ChainScratch::Impl &W = *S.p;
+	chains.clear();
+	if ((int)W.pool.size() < n_seeds) W.pool.resize(n_seeds);   // at most one chain per seed; pointers stay valid during this read
+	W.used = 0;
+	BTree tree(W.pool, W.nodes);
 	for (int k = 0; k < n_seeds; ++k) {
 		const HSeed &s = seeds[k];
 		int rid = bns_intv2rid(bns, s.rbeg, s.rbeg + s.len);
@@ -249,49 +264,50 @@ void chains_from_seeds(const mem_opt_t *opt, const bntseq_t *bns, int l_query, c
 		bool add = true;
 		if (tree.n_keys) {
 			int low = tree.lower(s.rbeg);
-			if (low >= 0 && test_and_merge(opt, bns->l_pac, pool[low], s, rid)) add = false;
+			if (low >= 0 && test_and_merge(opt, bns->l_pac, W.pool[low], s, rid)) add = false;
 		}
 		if (add) {
-			pool.emplace_back();
-			HChain &c = pool.back();
+			HChain &c = W.pool[W.used];
 			c.pos = s.rbeg; c.rid = rid; c.is_alt = !!bns->anns[rid].is_alt;
-			c.seeds.reserve(4);
+			c.first = -1; c.w = 0; c.kept = 0;
+			c.seeds.clear();
 			c.seeds.push_back(s);
-			tree.put((int)pool.size() - 1);
+			tree.put((int)W.used);
+			++W.used;
 		}
 	}
-	std::vector<int> order;
-	order.reserve(pool.size());
-	tree.inorder(tree.root, order);
-	chains.reserve(order.size());
+	W.order.clear();
+	tree.inorder(tree.root, W.order);
 	float frac = (float)l_rep / l_query;
-	for (int id : order) {
-		chains.push_back(std::move(pool[id]));
-		chains.back().frac_rep = frac;
+	for (int id : W.order) {
+		W.pool[id].frac_rep = frac;
+		chains.push_back(&W.pool[id]);
 	}
 }
 
-#define CHN_BEG(c) ((c).seeds.front().qbeg)
-#define CHN_END(c) ((c).seeds.back().qbeg + (c).seeds.back().len)
+#define CHN_BEG(c) ((c)->seeds.front().qbeg)
+#define CHN_END(c) ((c)->seeds.back().qbeg + (c)->seeds.back().len)
 
-void chain_filter(const mem_opt_t *opt, std::vector<HChain> &a)
+// The reference sorts the chain structs themselves with its unstable introsort; sorting pointers with the same
+// comparator performs the same comparisons and swaps, hence the same order, without copying seed arrays.
+void chain_filter(const mem_opt_t *opt, ChainScratch &S, std::vector<HChain *> &a)
 {
 	if (a.empty()) return;
 	size_t k = 0;
 	for (size_t i = 0; i < a.size(); ++i) {
-		HChain &c = a[i];
-		c.first = -1; c.kept = 0;
-		c.w = (uint32_t)chain_weight(c) & 0x1fffffffu;   // 29-bit field in the reference
-		if ((int)c.w < opt->min_chain_weight) continue;
-		if (k != i) a[k] = std::move(c);
-		++k;
+		HChain *c = a[i];
+		c->first = -1; c->kept = 0;
+		c->w = (uint32_t)chain_weight(*c) & 0x1fffffffu;   // 29-bit field in the reference
+		if ((int)c->w < opt->min_chain_weight) continue;
+		a[k++] = c;
 	}
 	a.resize(k);
 	int n = (int)a.size();
 	if (n == 0) return;   // (the reference would index a[0] here; min_chain_weight = 0 by default so this cannot happen there)
-	ks_introsort((size_t)n, a.data(), [](const HChain &x, const HChain &y) { return x.w > y.w; });
-	std::vector<int> kept;   // indices of chains that survived so far
-	a[0].kept = 3;
+	ks_introsort((size_t)n, a.data(), [](const HChain *x, const HChain *y) { return x->w > y->w; });
+	std::vector<int> &kept = S.p->kept;   // indices of chains that survived so far
+	kept.clear();
+	a[0]->kept = 3;
 	kept.push_back(0);
 	for (int i = 1; i < n; ++i) {
 		bool large_ovlp = false;
@@ -300,35 +316,34 @@ void chain_filter(const mem_opt_t *opt, std::vector<HChain> &a)
 			int j = kept[kk];
 			int b_max = CHN_BEG(a[j]) > CHN_BEG(a[i]) ? CHN_BEG(a[j]) : CHN_BEG(a[i]);
 			int e_min = CHN_END(a[j]) < CHN_END(a[i]) ? CHN_END(a[j]) : CHN_END(a[i]);
-			if (e_min > b_max && (!a[j].is_alt || a[i].is_alt)) {
+			if (e_min > b_max && (!a[j]->is_alt || a[i]->is_alt)) {
 				int li = CHN_END(a[i]) - CHN_BEG(a[i]), lj = CHN_END(a[j]) - CHN_BEG(a[j]);
 				int min_l = li < lj ? li : lj;
 				if (e_min - b_max >= min_l * opt->mask_level && min_l < opt->max_chain_gap) {
 					large_ovlp = true;
-					if (a[j].first < 0) a[j].first = i;
-					if ((int)a[i].w < (int)a[j].w * opt->drop_ratio && (int)a[j].w - (int)a[i].w >= opt->min_seed_len << 1) break;
+					if (a[j]->first < 0) a[j]->first = i;
+					if ((int)a[i]->w < (int)a[j]->w * opt->drop_ratio && (int)a[j]->w - (int)a[i]->w >= opt->min_seed_len << 1) break;
 				}
 			}
 		}
 		if (kk == kept.size()) {
 			kept.push_back(i);
-			a[i].kept = large_ovlp ? 2 : 3;
+			a[i]->kept = large_ovlp ? 2 : 3;
 		}
 	}
 	for (int j : kept)
-		if (a[j].first >= 0) a[a[j].first].kept = 1;
+		if (a[j]->first >= 0) a[a[j]->first]->kept = 1;
 	int i = 0, cnt = 0;
 	for (; i < n; ++i) {   // at most max_chain_extend chains with kept = 1 or 2 are extended
-		if (a[i].kept == 0 || a[i].kept == 3) continue;
+		if (a[i]->kept == 0 || a[i]->kept == 3) continue;
 		if (++cnt >= opt->max_chain_extend) break;
 	}
 	for (; i < n; ++i)
-		if (a[i].kept < 3) a[i].kept = 0;
+		if (a[i]->kept < 3) a[i]->kept = 0;
 	k = 0;
 	for (int q = 0; q < n; ++q) {
-		if (a[q].kept == 0) continue;
-		if ((int)k != q) a[k] = std::move(a[q]);
-		++k;
+		if (a[q]->kept == 0) continue;
+		a[k++] = a[q];
 	}
 	a.resize(k);
 }
@@ -358,12 +373,13 @@ static int seed_sw(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac
 }
 
 void filter_chained_seeds(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, int l_query, const uint8_t *query,
-                          std::vector<HChain> &chains)
+                          std::vector<HChain *> &chains)
 {
 	double min_l = opt->min_chain_weight ? 1.1f * opt->min_chain_weight : 5.5f * log(l_query);
 	int min_HSP_score = (int)(opt->a * min_l + .499);
 	if (min_l > 0.05f * l_query) return;   // short reads: nothing to do
-	for (HChain &c : chains) {
+	for (HChain *cp : chains) {
+		HChain &c = *cp;
 		size_t k = 0;
 		for (size_t j = 0; j < c.seeds.size(); ++j) {
 			HSeed &s = c.seeds[j];

@@ -4,6 +4,8 @@
 //   mem_pair     best consistent pair                             src/bwamem_pair.c:182-243
 //   mem_sam_pe   pairing decision, MAPQ and the two SAM records   src/bwamem_pair.c:250-393
 #include "host.h"
+#include <thread>
+#include <algorithm>
 #include "sortutil.h"
 #include "hprof.h"
 
@@ -44,19 +46,53 @@ static int cal_sub(const mem_opt_t *opt, const HRegV &r)
 	return j < r.size() ? r[j].score : opt->min_seed_len * opt->a;
 }
 
-void pestat(const mem_opt_t *opt, int64_t l_pac, int n, const HRegV *regs, mem_pestat_t pes[4])
+void pestat(const mem_opt_t *opt, int64_t l_pac, int n, const HRegV *regs, mem_pestat_t pes[4], int n_threads)
 {
 	std::vector<uint64_t> isize[4];
 	memset(pes, 0, 4 * sizeof(mem_pestat_t));
-	for (int i = 0; i < n >> 1; ++i) {
-		const HRegV &r0 = regs[i << 1 | 0], &r1 = regs[i << 1 | 1];
-		if (r0.empty() || r1.empty()) continue;
-		if (cal_sub(opt, r0) > 0.8 * r0[0].score) continue;   // only unique hits vote
-		if (cal_sub(opt, r1) > 0.8 * r1[0].score) continue;
-		if (r0[0].rid != r1[0].rid) continue;
-		int64_t is;
-		int dir = infer_dir(l_pac, r0[0].rb, r1[0].rb, &is);
-		if (is && is <= opt->max_ins) isize[dir].push_back(is);
+	// The votes are only ever used sorted, so they can be gathered by several threads in any order; with the usual
+	// max_ins (10 000) sorting is a counting sort over the insert sizes.
+	const int np = n >> 1;
+	const bool counting = opt->max_ins > 0 && opt->max_ins <= (1 << 20);
+	int nt = std::max(1, std::min(n_threads, np / 4096));
+	std::vector<std::vector<uint64_t>> part(nt * 4);
+	auto gather = [&](int t) {
+		int lo = (int)((int64_t)np * t / nt), hi = (int)((int64_t)np * (t + 1) / nt);
+		std::vector<uint64_t> *out = &part[t * 4];
+		if (counting) for (int d = 0; d < 4; ++d) out[d].assign((size_t)opt->max_ins + 1, 0);
+		for (int i = lo; i < hi; ++i) {
+			const HRegV &r0 = regs[i << 1 | 0], &r1 = regs[i << 1 | 1];
+			if (r0.empty() || r1.empty()) continue;
+			if (cal_sub(opt, r0) > 0.8 * r0[0].score) continue;   // only unique hits vote
+			if (cal_sub(opt, r1) > 0.8 * r1[0].score) continue;
+			if (r0[0].rid != r1[0].rid) continue;
+			int64_t is;
+			int dir = infer_dir(l_pac, r0[0].rb, r1[0].rb, &is);
+			if (is && is <= opt->max_ins) {
+				if (counting) ++out[dir][is];
+				else out[dir].push_back(is);
+			}
+		}
+	};
+	{
+		std::vector<std::thread> th;
+		for (int t = 1; t < nt; ++t) th.emplace_back(gather, t);
+		gather(0);
+		for (auto &t : th) t.join();
+	}
+	for (int d = 0; d < 4; ++d) {
+		if (counting) {
+			std::vector<uint64_t> &h = part[d];
+			for (int t = 1; t < nt; ++t)
+				for (size_t v = 0; v < h.size(); ++v) h[v] += part[t * 4 + d][v];
+			size_t tot = 0;
+			for (uint64_t c : h) tot += c;
+			isize[d].reserve(tot);
+			for (size_t v = 0; v < h.size(); ++v) isize[d].insert(isize[d].end(), h[v], (uint64_t)v);
+		} else {
+			for (int t = 0; t < nt; ++t) isize[d].insert(isize[d].end(), part[t * 4 + d].begin(), part[t * 4 + d].end());
+			std::sort(isize[d].begin(), isize[d].end());   // plain integers: every sort gives the same array
+		}
 	}
 	if (bwa_verbose >= 3)
 		fprintf(stderr, "[M::%s] # candidate unique pairs for (FF, FR, RF, RR): (%ld, %ld, %ld, %ld)\n", "mem_pestat",
@@ -69,7 +105,6 @@ void pestat(const mem_opt_t *opt, int64_t l_pac, int n, const HRegV *regs, mem_p
 			r->failed = 1;
 			continue;
 		} else fprintf(stderr, "[M::%s] analyzing insert size distribution for orientation %c%c...\n", "mem_pestat", "FR"[d >> 1 & 1], "FR"[d & 1]);
-		ks_introsort(q.size(), q.data(), [](uint64_t a, uint64_t b) { return a < b; });
 		int p25 = (int)q[(int)(.25 * q.size() + .499)];
 		int p50 = (int)q[(int)(.50 * q.size() + .499)];
 		int p75 = (int)q[(int)(.75 * q.size() + .499)];

@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <atomic>
+#include <memory>
+#include <mutex>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -90,6 +92,29 @@ static void parallel_for(int n_threads, int n, int chunk, F f)
 	for (auto &t : th) t.join();
 }
 
+// same, handing whole blocks to f(thread, block, lo, hi) so that a stage can keep per-thread scratch and per-block output
+template <class F>
+static void parallel_blocks(int n_threads, int n, int chunk, F f)
+{
+	if (n <= 0) return;
+	const int nb = (n + chunk - 1) / chunk;
+	if (n_threads > nb) n_threads = nb;
+	std::atomic<int> next(0);
+	auto work = [&](int tid) {
+		for (;;) {
+			int b = next.fetch_add(1);
+			if (b >= nb) break;
+			f(tid, b, b * chunk, std::min(n, (b + 1) * chunk));
+		}
+	};
+	std::vector<std::thread> th;
+	for (int t = 1; t < n_threads; ++t) th.emplace_back(work, t);
+	work(0);
+	for (auto &t : th) t.join();
+}
+
+static std::mutex g_smem_turn, g_c2a_turn;
+
 static double now_ms()
 {
 	return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -117,8 +142,23 @@ struct HostBuf {
 	void *ensure(size_t bytes) { if (bytes > cap) { free(p); cap = bytes + bytes / 4 + 4096; p = malloc(cap); if (!p) die("out of memory"); } return p; }
 };
 
+// grow-only page-locked host buffer: staging for the bulk H2D / D2H copies (full PCIe rate, no per-chunk page faults)
+struct PinBuf {
+	void *p = nullptr; size_t cap = 0;
+	void *ensure(size_t bytes)
+	{
+		if (bytes > cap) {
+			if (p) HIP_OK(hipHostFree(p));
+			cap = bytes + bytes / 4 + 4096;
+			HIP_OK(hipHostMalloc(&p, cap, hipHostMallocDefault));
+		}
+		return p;
+	}
+};
+
 struct Workspace {
 	HostBuf reg_arena;
+	PinBuf h_flat, h_sa, h_qbl, h_chains, h_seeds, h_srt, h_regs, h_nregs;
 	DevBuf seq, off, len, intv, nintv, cnt, scratch, nseeds, lrep, seed_off, rows, qbl, sa;
 	DevBuf chain_off, chains, seeds, srt, reg_off, regs, nregs, tab, areq, ahdr, apool, agap, acnt, areq2, ahdr2, apool2, acnt2;
 };
@@ -190,10 +230,11 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		max_len = std::max(max_len, seqs[i].l_seq);
 		total_bases += seqs[i].l_seq;
 	}
-	std::vector<uint8_t> flat(off[n] + 16);
+	const size_t flat_bytes = (size_t)off[n] + 16;
+	uint8_t *flat = (uint8_t *)W.h_flat.ensure(flat_bytes);
 	parallel_for(n_thr, n, 4096, [&](int i) {
 		char *s = seqs[i].seq;
-		uint8_t *d = flat.data() + off[i];
+		uint8_t *d = flat + off[i];
 		for (int k = 0; k < seqs[i].l_seq; ++k) {
 			s[k] = s[k] < 4 ? s[k] : (char)nt4_table[(uint8_t)s[k]];
 			d[k] = (uint8_t)s[k];
@@ -201,10 +242,10 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	});
 	if ((size_t)max_len + 2 > 9000) die("read of %d bp exceeds the on-chip band buffers of this build (max 8998 bp)", max_len);
 	double t1 = now_ms();
-	uint8_t *d_seq = (uint8_t *)W.seq.ensure(flat.size());
+	uint8_t *d_seq = (uint8_t *)W.seq.ensure(flat_bytes);
 	int64_t *d_off = (int64_t *)W.off.ensure((size_t)(n + 1) * 8);
 	int *d_len = (int *)W.len.ensure((size_t)n * 4);
-	HIP_OK(hipMemcpyAsync(d_seq, flat.data(), flat.size(), hipMemcpyHostToDevice, st));
+	HIP_OK(hipMemcpyAsync(d_seq, flat, flat_bytes, hipMemcpyHostToDevice, st));
 	HIP_OK(hipMemcpyAsync(d_off, off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
 	HIP_OK(hipMemcpyAsync(d_len, lens.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
 	HIP_OK(hipStreamSynchronize(st));
@@ -238,6 +279,9 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			d_intv = (uint64_t *)W.intv.ensure((size_t)n * cap * 32);
 			d_nintv = (int *)W.nintv.ensure((size_t)n * 4);
 			HIP_OK(hipMemsetAsync(d_cnt, 0, 256, st));
+			// the two sub-batches take turns on the big kernels: each one fills the chip by itself, and running them one
+			// after the other staggers the sub-batches so that the host stages of one fall under the kernels of the other
+			std::unique_lock<std::mutex> turn(g_smem_turn);
 			ev_smem.start(st);
 			if (lane_k) launch_smem_lane(st, ix.fm, smem_params(opt), n, d_seq, d_off_r, d_len_r, cap, d_intv, d_nintv, d_cnt, d_scr, per_quad, n_quads);
 			else launch_smem(st, ix.fm, smem_params(opt), n, d_seq, d_off_r, d_len_r, cap, d_intv, d_nintv, max_len, d_cnt, d_scr, per_quad, n_quads);
@@ -245,6 +289,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			HIP_OK(hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, st));
 			HIP_OK(hipStreamSynchronize(st));
 			HIP_OK(hipGetLastError());
+			turn.unlock();
 			ps.k_smem += ev_smem.ms();
 			if (cnt[2] == 0) break;
 			cap *= 4;
@@ -267,8 +312,8 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		const int64_t S = seed_off[n];
 		ps.smem_bytes += n_intv * 32;
 		ps.n_intv = n_intv; ps.n_seeds = S;
-		std::vector<uint64_t> sa(S);
-		std::vector<int32_t> qbl(2 * S);
+		uint64_t *sa = (uint64_t *)W.h_sa.ensure((size_t)S * 8 + 8);
+		int32_t *qbl = (int32_t *)W.h_qbl.ensure((size_t)S * 8 + 8);
 		if (S > 0) {
 			int64_t *d_seed_off = (int64_t *)W.seed_off.ensure((size_t)(n + 1) * 8);
 			uint64_t *d_rows = (uint64_t *)W.rows.ensure((size_t)S * 8), *d_sa = (uint64_t *)W.sa.ensure((size_t)S * 8);
@@ -282,8 +327,8 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			else launch_sa(st, ix.fm, (int)S, d_rows, d_sa, d_cnt);                // LF walk on the sampled SA
 			ev_sa.stop(st);
 			HIP_OK(hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, st));
-			HIP_OK(hipMemcpyAsync(sa.data(), d_sa, (size_t)S * 8, hipMemcpyDeviceToHost, st));
-			HIP_OK(hipMemcpyAsync(qbl.data(), d_qbl, (size_t)S * 8, hipMemcpyDeviceToHost, st));
+			HIP_OK(hipMemcpyAsync(sa, d_sa, (size_t)S * 8, hipMemcpyDeviceToHost, st));
+			HIP_OK(hipMemcpyAsync(qbl, d_qbl, (size_t)S * 8, hipMemcpyDeviceToHost, st));
 			HIP_OK(hipStreamSynchronize(st));
 			HIP_OK(hipGetLastError());
 			ps.k_sa = ev_sa.ms();
@@ -291,68 +336,93 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		}
 		double t3 = now_ms();
 
-		// chaining and chain filters (host)
-		std::vector<std::vector<HChain>> chains(n);
-		parallel_for(n_thr, n, 256, [&](int i) {
-			int ns = nseeds[i];
-			if (ns == 0) return;
-			std::vector<HSeed> hs(ns);
-			for (int k = 0; k < ns; ++k) {
-				int64_t o = seed_off[i] + k;
-				hs[k].rbeg = (int64_t)sa[o]; hs[k].qbeg = qbl[2 * o]; hs[k].len = hs[k].score = qbl[2 * o + 1];
-			}
-			chains_from_seeds(opt, bns, seqs_r[i].l_seq, hs.data(), ns, lrep[i], chains[i]);
-			chain_filter(opt, chains[i]);
-			filter_chained_seeds(opt, bns, pac, seqs_r[i].l_seq, (const uint8_t *)seqs_r[i].seq, chains[i]);
-		});
+		// chaining and chain filters (host).  Each block of reads is chained by one thread with recycled scratch and packed
+		// straight into the device layout (block-local offsets); the blocks are then concatenated after a prefix sum.
+		const int CB = 256, n_cb = (n + CB - 1) / CB;
+		struct BlockOut { std::vector<DevChain> ch; std::vector<DevSeed> sd; std::vector<unsigned int> srt; };
+		std::vector<BlockOut> bo(n_cb);
 		std::vector<int> chain_off(n + 1), reg_off(n + 1);
-		chain_off[0] = reg_off[0] = 0;
-		for (int i = 0; i < n; ++i) {
-			int ns = 0;
-			for (auto &c : chains[i]) ns += (int)c.seeds.size();
-			chain_off[i + 1] = chain_off[i] + (int)chains[i].size();
-			reg_off[i + 1] = reg_off[i] + ns;
+		{
+			const int nt = std::max(1, n_thr);
+			std::vector<std::unique_ptr<ChainScratch>> scr(nt);
+			std::vector<std::vector<HSeed>> hsv(nt);
+			std::vector<std::vector<HChain *>> chv(nt);
+			std::vector<std::vector<uint64_t>> keyv(nt);
+			parallel_blocks(nt, n, CB, [&](int tid, int b, int lo, int hi) {
+				if (!scr[tid]) scr[tid].reset(new ChainScratch());
+				std::vector<HSeed> &hs = hsv[tid];
+				std::vector<HChain *> &chains = chv[tid];
+				std::vector<uint64_t> &key = keyv[tid];
+				BlockOut &o = bo[b];
+				int64_t est = seed_off[hi] - seed_off[lo];
+				o.sd.reserve(est); o.srt.reserve(est); o.ch.reserve((hi - lo) * 2);
+				for (int i = lo; i < hi; ++i) {
+					int ns = nseeds[i];
+					chain_off[i + 1] = reg_off[i + 1] = 0;
+					if (ns == 0) continue;
+					hs.resize(ns);
+					for (int k = 0; k < ns; ++k) {
+						int64_t so = seed_off[i] + k;
+						hs[k].rbeg = (int64_t)sa[so]; hs[k].qbeg = qbl[2 * so]; hs[k].len = hs[k].score = qbl[2 * so + 1];
+					}
+					chains_from_seeds(opt, bns, seqs_r[i].l_seq, hs.data(), ns, lrep[i], *scr[tid], chains);
+					chain_filter(opt, *scr[tid], chains);
+					filter_chained_seeds(opt, bns, pac, seqs_r[i].l_seq, (const uint8_t *)seqs_r[i].seq, chains);
+					int tot = 0;
+					for (const HChain *cp_ : chains) {
+						const HChain &ch = *cp_;
+						const int cs = (int)ch.seeds.size();
+						DevChain d;
+						d.seed_beg = (int)o.sd.size(); d.n_seeds = cs; d.rid = ch.rid; d.frac_rep = ch.frac_rep;   // block-local for now
+						d.far_beg = d.far_end = 0;
+						if (cs) {
+							int is_rev;
+							bns_depos(bns, ch.seeds[0].rbeg, &is_rev);
+							int64_t fb = bns->anns[ch.rid].offset, fe = fb + bns->anns[ch.rid].len;
+							if (is_rev) { int64_t t = fb; fb = (bns->l_pac << 1) - fe; fe = (bns->l_pac << 1) - t; }
+							d.far_beg = fb; d.far_end = fe;
+						}
+						o.ch.push_back(d);
+						// seeds are visited by decreasing score, ties by decreasing index (src/bwamem.c:662-667)
+						key.resize(cs);
+						for (int k = 0; k < cs; ++k) {
+							DevSeed ds;
+							ds.rbeg = ch.seeds[k].rbeg; ds.qbeg = ch.seeds[k].qbeg; ds.len = ch.seeds[k].len;
+							o.sd.push_back(ds);
+							key[k] = (uint64_t)ch.seeds[k].score << 32 | (uint32_t)k;
+						}
+						if (cs > 1) std::sort(key.begin(), key.end());   // keys are distinct, any sort gives the reference's order
+						for (int k = 0; k < cs; ++k) o.srt.push_back((unsigned int)key[k]);
+						tot += cs;
+					}
+					chain_off[i + 1] = (int)chains.size();
+					reg_off[i + 1] = tot;
+				}
+			});
 		}
+		chain_off[0] = reg_off[0] = 0;
+		for (int i = 0; i < n; ++i) { chain_off[i + 1] += chain_off[i]; reg_off[i + 1] += reg_off[i]; }
 		const int NC = chain_off[n], NS = reg_off[n];
 		ps.n_chains = NC;
-		std::vector<DevChain> hchains(NC);
-		std::vector<DevSeed> hseeds(NS);
-		std::vector<unsigned int> hsrt(NS);
-		parallel_for(n_thr, n, 512, [&](int i) {
-			int so = reg_off[i];
-			for (size_t c = 0; c < chains[i].size(); ++c) {
-				const HChain &ch = chains[i][c];
-				DevChain &d = hchains[chain_off[i] + c];
-				int ns = (int)ch.seeds.size();
-				d.seed_beg = so; d.n_seeds = ns; d.rid = ch.rid; d.frac_rep = ch.frac_rep;
-				d.far_beg = d.far_end = 0;
-				if (ns) {
-					int is_rev;
-					bns_depos(bns, ch.seeds[0].rbeg, &is_rev);
-					int64_t fb = bns->anns[ch.rid].offset, fe = fb + bns->anns[ch.rid].len;
-					if (is_rev) { int64_t t = fb; fb = (bns->l_pac << 1) - fe; fe = (bns->l_pac << 1) - t; }
-					d.far_beg = fb; d.far_end = fe;
-				}
-				// seeds are visited by decreasing score, ties by decreasing index (src/bwamem.c:662-667)
-				uint64_t small_key[64];
-				std::vector<uint64_t> big_key;
-				uint64_t *key = small_key;
-				if (ns > 64) { big_key.resize(ns); key = big_key.data(); }
-				for (int k = 0; k < ns; ++k) {
-					hseeds[so + k].rbeg = ch.seeds[k].rbeg; hseeds[so + k].qbeg = ch.seeds[k].qbeg; hseeds[so + k].len = ch.seeds[k].len;
-					key[k] = (uint64_t)ch.seeds[k].score << 32 | (uint32_t)k;
-				}
-				std::sort(key, key + ns);   // keys are distinct, any sort gives the reference's order
-				for (int k = 0; k < ns; ++k) hsrt[so + k] = (uint32_t)key[k];
-				so += ns;
+		DevChain *hchains = (DevChain *)W.h_chains.ensure((size_t)NC * sizeof(DevChain) + 8);
+		DevSeed *hseeds = (DevSeed *)W.h_seeds.ensure((size_t)NS * sizeof(DevSeed) + 8);
+		unsigned int *hsrt = (unsigned int *)W.h_srt.ensure((size_t)NS * 4 + 8);
+		parallel_blocks(n_thr, n, CB, [&](int, int b, int lo, int) {
+			BlockOut &o = bo[b];
+			const int c0 = chain_off[lo], s0 = reg_off[lo];
+			for (size_t c = 0; c < o.ch.size(); ++c) { hchains[c0 + c] = o.ch[c]; hchains[c0 + c].seed_beg += s0; }
+			if (!o.sd.empty()) {
+				memcpy((void *)(hseeds + s0), (const void *)o.sd.data(), o.sd.size() * sizeof(DevSeed));
+				memcpy(hsrt + s0, o.srt.data(), o.srt.size() * 4);
 			}
-			std::vector<HChain>().swap(chains[i]);   // done with this read's chains
+			BlockOut().ch.swap(o.ch); std::vector<DevSeed>().swap(o.sd); std::vector<unsigned int>().swap(o.srt);
 		});
 		double t4 = now_ms();
 
 		// chain -> regions on the GPU
-		std::vector<DevReg> hregs(NS);
-		std::vector<int> nregs(n, 0);
+		DevReg *hregs = (DevReg *)W.h_regs.ensure((size_t)NS * sizeof(DevReg) + 8);
+		int *nregs = (int *)W.h_nregs.ensure((size_t)n * 4 + 8);
+		if (NS == 0) memset(nregs, 0, (size_t)n * 4);
 		if (NS > 0) {
 			const int TS = max_len + 2;
 			std::vector<int> tab(5 * TS);
@@ -373,24 +443,26 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			HIP_OK(hipMemcpyAsync(d_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, st));
 			HIP_OK(hipMemcpyAsync(d_chain_off, chain_off.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, st));
 			HIP_OK(hipMemcpyAsync(d_reg_off, reg_off.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, st));
-			HIP_OK(hipMemcpyAsync(d_chains, hchains.data(), (size_t)NC * sizeof(DevChain), hipMemcpyHostToDevice, st));
-			HIP_OK(hipMemcpyAsync(d_seeds, hseeds.data(), (size_t)NS * sizeof(DevSeed), hipMemcpyHostToDevice, st));
-			HIP_OK(hipMemcpyAsync(d_srt, hsrt.data(), (size_t)NS * 4, hipMemcpyHostToDevice, st));
+			HIP_OK(hipMemcpyAsync(d_chains, hchains, (size_t)NC * sizeof(DevChain), hipMemcpyHostToDevice, st));
+			HIP_OK(hipMemcpyAsync(d_seeds, hseeds, (size_t)NS * sizeof(DevSeed), hipMemcpyHostToDevice, st));
+			HIP_OK(hipMemcpyAsync(d_srt, hsrt, (size_t)NS * 4, hipMemcpyHostToDevice, st));
 			HIP_OK(hipMemsetAsync(d_cnt, 0, 256, st));
 			C2aParams cp;
 			cp.l_pac = bns->l_pac; cp.a = opt->a; cp.w = opt->w; cp.pen_clip5 = opt->pen_clip5; cp.pen_clip3 = opt->pen_clip3;
 			ExtParams ep;
 			memcpy(ep.mat, opt->mat, 25);
 			ep.o_del = opt->o_del; ep.e_del = opt->e_del; ep.o_ins = opt->o_ins; ep.e_ins = opt->e_ins; ep.zdrop = opt->zdrop;
+			std::unique_lock<std::mutex> turn(g_c2a_turn);
 			ev_ext.start(st);
 			launch_c2a(st, cp, ep, n, d_seq, d_off_r, d_len_r, d_chain_off, d_chains, d_seeds, d_srt, d_reg_off, d_regs, d_nregs, d_tab, TS,
 			           (const uint8_t *)ix.d_pac, d_cnt, max_len);
 			ev_ext.stop(st);
 			HIP_OK(hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, st));
-			HIP_OK(hipMemcpyAsync(hregs.data(), d_regs, (size_t)NS * sizeof(DevReg), hipMemcpyDeviceToHost, st));
-			HIP_OK(hipMemcpyAsync(nregs.data(), d_nregs, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+			HIP_OK(hipMemcpyAsync(hregs, d_regs, (size_t)NS * sizeof(DevReg), hipMemcpyDeviceToHost, st));
+			HIP_OK(hipMemcpyAsync(nregs, d_nregs, (size_t)n * 4, hipMemcpyDeviceToHost, st));
 			HIP_OK(hipStreamSynchronize(st));
 			HIP_OK(hipGetLastError());
+			turn.unlock();
 			ps.k_ext = ev_ext.ms();
 			ps.cells = cnt[0]; ps.n_ext = cnt[1];
 		}
@@ -455,7 +527,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	mem_pestat_t pes[4];
 	if (pe) {
 		if (pes0) memcpy(pes, pes0, 4 * sizeof(mem_pestat_t));
-		else pestat(opt, bns->l_pac, n, regs.data(), pes);
+		else pestat(opt, bns->l_pac, n, regs.data(), pes, n_thr);
 	}
 	double t7 = now_ms();
 
