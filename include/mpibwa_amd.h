@@ -205,6 +205,14 @@ int mi355x_extend_batch(const mem_opt_t *opt, int n, const uint8_t *q, const int
                         const uint8_t *t, const int64_t *toff, const int *w, const int *h0,
                         const int *end_bonus, int *out6, double *kernel_ms, uint64_t *cells);
 
+/* Mate-rescue local alignment: ksw_align2() exactly as mem_matesw() calls it (src/bwamem_pair.c:150-177,
+ * src/ksw.c:321-356), for n_req windows [rb,re) of a 2-bit packed reference (doubled coordinate) against reads
+ * given as nt4 codes (read r = reads[off[r]..off[r+1]) ).  out8 per request: score, te, qe, score2, te2, tb, qb
+ * (kswr_t, src/ksw.h:14-20) and flags (1 = the device declined, recompute on the host). */
+int mi355x_matesw_batch(const mem_opt_t *opt, int64_t l_pac, const uint8_t *pac, int n_reads, const uint8_t *reads,
+                        const int64_t *off, int n_req, const int64_t *rb, const int64_t *re, const int *read,
+                        const int *is_rev, int *out8, double *kernel_ms);
+
 /* timing of the last mem_process_seqs() call, per stage (ms) */
 typedef struct {
 	double total_ms, h2d_ms, smem_ms, sa_ms, chain_ms, ext_ms, regs_ms, pestat_ms, sam_ms;
@@ -214,6 +222,8 @@ typedef struct {
 	double plan_ms, aln_ms, k_aln_ms;            /* SAM stage: decisions+collect, CIGAR kernel round trip, its HIP-event time */
 	uint64_t n_aln;
 	double phase1_ms;                            /* wall time of stages 2-6 (sub-batches overlap, so it is less than their sum) */
+	double msw_ms, k_msw_ms;                     /* mate rescue: listing the alignments + waiting for them, HIP-event kernel time */
+	uint64_t n_msw;                              /* local alignments computed by the mate-rescue kernel */
 } mi355x_stats_t;
 void mi355x_last_stats(mi355x_stats_t *st);
 

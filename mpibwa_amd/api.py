@@ -17,7 +17,7 @@ EXPORTS = [
     "mem_process_seqs", "mem_opt_init", "bwa_fill_scmat", "bwa_idx_load_from_disk", "bwa_mem2idx", "bwa_idx_destroy",
     "mi355x_index_upload", "mi355x_index_alloc", "mi355x_index_buffers", "mi355x_index_d2d", "mi355x_index_commit",
     "mi355x_finalize", "mi355x_index_build", "mi355x_index_build_gpu",
-    "mi355x_smem_batch", "mi355x_sa_batch", "mi355x_sa_batch2", "mi355x_sa_dense_info", "mi355x_extend_batch", "mi355x_last_stats", "mi355x_host_cpus", "mi355x_collect_sam", "mi355x_host_ksw_align2",
+    "mi355x_smem_batch", "mi355x_sa_batch", "mi355x_sa_batch2", "mi355x_sa_dense_info", "mi355x_extend_batch", "mi355x_matesw_batch", "mi355x_last_stats", "mi355x_host_cpus", "mi355x_collect_sam", "mi355x_host_ksw_align2",
 ]
 
 
@@ -57,6 +57,7 @@ def load_library(build_if_missing=True):
     sig("mi355x_sa_batch2", C.c_int, [C.c_int, C.c_void_p, C.c_void_p, P(C.c_double), C.c_int])
     sig("mi355x_sa_dense_info", C.c_double, [P(C.c_size_t)])
     sig("mi355x_extend_batch", C.c_int, [P(abi.mem_opt_t), C.c_int] + [C.c_void_p] * 8 + [P(C.c_double), P(C.c_uint64)])
+    sig("mi355x_matesw_batch", C.c_int, [P(abi.mem_opt_t), C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [P(C.c_double)])
     sig("mi355x_last_stats", None, [P(abi.mi355x_stats_t)])
     sig("mi355x_finalize", None, [])
     sig("mi355x_host_ksw_align2", None, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p])
@@ -201,6 +202,23 @@ class Engine:
         ms = C.c_double(0)
         rc = self.lib.mi355x_sa_batch2(len(ks), ks.ctypes.data, out.ctypes.data, C.byref(ms), 1)
         return (out, ms.value) if rc == 0 else None
+
+    def matesw(self, opt, l_pac, pac, reads, rb, re, read, is_rev):
+        """mem_matesw's ksw_align2 for windows of `pac`; returns (n_req x 8 int32, kernel ms)."""
+        n = len(reads)
+        off = np.zeros(n + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(s) for s in reads])
+        flat = np.concatenate(reads).astype(np.uint8)
+        rb = np.ascontiguousarray(rb, dtype=np.int64)
+        re = np.ascontiguousarray(re, dtype=np.int64)
+        read = np.ascontiguousarray(read, dtype=np.int32)
+        is_rev = np.ascontiguousarray(is_rev, dtype=np.int32)
+        pac = np.ascontiguousarray(pac, dtype=np.uint8)
+        out = np.zeros((len(rb), 8), dtype=np.int32)
+        ms = C.c_double(0)
+        self.lib.mi355x_matesw_batch(opt, int(l_pac), pac.ctypes.data, n, flat.ctypes.data, off.ctypes.data, len(rb), rb.ctypes.data,
+                                     re.ctypes.data, read.ctypes.data, is_rev.ctypes.data, out.ctypes.data, C.byref(ms))
+        return out, ms.value
 
     def extend(self, opt, qs, ts, w, h0, end_bonus):
         n = len(qs)

@@ -110,6 +110,27 @@ void launch_aln(void *stream, const AlnParams &P, const ExtParams &ep, int n_req
                 const int64_t *d_off, const uint8_t *d_pac, const int *d_gaptab, AlnHdr *d_hdr, uint8_t *d_pool,
                 unsigned long long *d_counters, size_t pool_bytes, int max_len, int tcap);
 
+// ---- mate-rescue local alignment on the device (msw_kernel.hip) ----
+struct MswReq {                  // one ksw_align2() call of mem_matesw (src/bwamem_pair.c:150-177)
+	int64_t rb, re;              // target window in the doubled coordinate, already clipped to the contig
+	int32_t read;                // the mate to align (index into the batch)
+	int32_t is_rev;              // align its reverse complement
+};
+struct MswRes { int32_t score, te, qe, score2, te2, tb, qb, flags; };   // kswr_t + flags (1 = recompute on the host)
+struct MswParams {
+	int64_t l_pac;
+	uint32_t slo[4];             // scores of target base t against query codes 0..3, one byte each
+	int s4[4];                   // ... against query code 4 (N)
+	int o_del, e_del, o_ins, e_ins;
+	int a, min_seed_len;
+	int max_sc, shift;           // max(mat) and -min(mat) as the striped kernel derives them (src/ksw.c:83-88)
+};
+size_t msw_lds_bytes(int max_len);
+// d_rows: scratch of n_req * (longest window) u16
+void launch_msw(void *stream, const MswParams &P, int n_req, const MswReq *d_req, const uint8_t *d_seq, const int64_t *d_off, const int *d_len,
+                const uint8_t *d_pac, MswRes *d_res, uint16_t *d_rows, int max_len);
+MswParams msw_params(const mem_opt_t *opt, int64_t l_pac);
+
 // ---- seed enumeration between SMEM and SA lookup (fm_kernels.hip) ----
 // per read: sort intervals by info, l_rep (src/bwamem.c:265-272) and the number of SA rows to look up
 void launch_seed_prep(void *stream, int n_reads, int cap, uint64_t *d_intv, const int *d_nintv, int max_occ, int *d_nseeds, int *d_lrep);

@@ -364,3 +364,80 @@ extern "C" int mi355x_extend_batch(const mem_opt_t *opt, int n, const uint8_t *q
 	if (cells) *cells = c;
 	return 0;
 }
+
+namespace mbw {
+MswParams msw_params(const mem_opt_t *opt, int64_t l_pac)
+{
+	MswParams P;
+	P.l_pac = l_pac;
+	int8_t mn = 127, mx = 0;   // initial values of the reference's scan (src/ksw.c:83-87)
+	for (int i = 0; i < 25; ++i) {
+		if (opt->mat[i] < mn) mn = opt->mat[i];
+		if (opt->mat[i] > mx) mx = opt->mat[i];
+	}
+	for (int t = 0; t < 4; ++t) {
+		P.slo[t] = 0;
+		for (int q = 0; q < 4; ++q) P.slo[t] |= (uint32_t)(uint8_t)opt->mat[t * 5 + q] << (8 * q);
+		P.s4[t] = opt->mat[t * 5 + 4];
+	}
+	P.o_del = opt->o_del; P.e_del = opt->e_del; P.o_ins = opt->o_ins; P.e_ins = opt->e_ins;
+	P.a = opt->a; P.min_seed_len = opt->min_seed_len;
+	P.max_sc = mx > 0 ? mx : 1;
+	P.shift = (uint8_t)(256 - (uint8_t)mn);
+	return P;
+}
+}
+
+// Stage-level entry point of the mate-rescue alignment (tests, micro-benchmarks): n_req windows [rb,re) of the packed
+// reference `pac` (doubled coordinate, 2 bits per base, l_pac bases) against reads of a batch given as nt4 codes.
+// out8 per request: score, te, qe, score2, te2, tb, qb, flags — kswr_t of ksw_align2 with mem_matesw's flags.
+extern "C" int mi355x_matesw_batch(const mem_opt_t *opt, int64_t l_pac, const uint8_t *pac, int n_reads, const uint8_t *reads, const int64_t *off,
+                                   int n_req, const int64_t *rb, const int64_t *re, const int *read, const int *is_rev, int *out8,
+                                   double *kernel_ms)
+{
+	int nd = 0;
+	if (hipGetDeviceCount(&nd) != hipSuccess || nd == 0) die("no HIP device visible (no CPU fallback)");
+	if (n_req <= 0) return 0;
+	hipStream_t st = 0;
+	// reads go into 16-byte slots as in the pipeline
+	std::vector<int64_t> slot(n_reads + 1);
+	std::vector<int> lens(n_reads);
+	int max_len = 0;
+	slot[0] = 0;
+	for (int i = 0; i < n_reads; ++i) {
+		lens[i] = (int)(off[i + 1] - off[i]);
+		slot[i + 1] = slot[i] + ((lens[i] + 15) & ~15);
+		max_len = std::max(max_len, lens[i]);
+	}
+	if ((int64_t)max_len * opt->a >= 8192 || msw_lds_bytes(max_len) > 160 * 1024) die("mate-rescue kernel: reads too long for the device path");
+	std::vector<uint8_t> flat(slot[n_reads] + 16, 4);
+	for (int i = 0; i < n_reads; ++i) memcpy(flat.data() + slot[i], reads + off[i], lens[i]);
+	std::vector<MswReq> rq(n_req);
+	int max_t = 1;
+	for (int i = 0; i < n_req; ++i) {
+		rq[i].rb = rb[i]; rq[i].re = re[i]; rq[i].read = read[i]; rq[i].is_rev = is_rev[i];
+		if (re[i] < rb[i] || re[i] > 2 * l_pac || rb[i] < 0 || read[i] < 0 || read[i] >= n_reads) die("mi355x_matesw_batch: bad request %d", i);
+		max_t = std::max(max_t, (int)(re[i] - rb[i]));
+	}
+	uint8_t *d_seq, *d_pac; int64_t *d_off; int *d_len; MswReq *d_req; MswRes *d_res; uint16_t *d_rows;
+	HIP_OK(hipMalloc(&d_seq, flat.size())); HIP_OK(hipMalloc(&d_pac, l_pac / 4 + 16));
+	HIP_OK(hipMalloc(&d_off, (size_t)(n_reads + 1) * 8)); HIP_OK(hipMalloc(&d_len, (size_t)n_reads * 4));
+	HIP_OK(hipMalloc(&d_req, (size_t)n_req * sizeof(MswReq))); HIP_OK(hipMalloc(&d_res, (size_t)n_req * sizeof(MswRes)));
+	HIP_OK(hipMalloc(&d_rows, (size_t)n_req * max_t * 2));
+	HIP_OK(hipMemcpy(d_seq, flat.data(), flat.size(), hipMemcpyHostToDevice));
+	HIP_OK(hipMemcpy(d_pac, pac, l_pac / 4 + 1, hipMemcpyHostToDevice));
+	HIP_OK(hipMemcpy(d_off, slot.data(), (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice));
+	HIP_OK(hipMemcpy(d_len, lens.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice));
+	HIP_OK(hipMemcpy(d_req, rq.data(), (size_t)n_req * sizeof(MswReq), hipMemcpyHostToDevice));
+	Timer tm;
+	tm.start(st);
+	launch_msw(st, msw_params(opt, l_pac), n_req, d_req, d_seq, d_off, d_len, d_pac, d_res, d_rows, max_len);
+	double ms = tm.stop(st);
+	HIP_OK(hipGetLastError());
+	static_assert(sizeof(MswRes) == 32, "MswRes layout");
+	HIP_OK(hipMemcpy(out8, d_res, (size_t)n_req * sizeof(MswRes), hipMemcpyDeviceToHost));
+	(void)hipFree(d_seq); (void)hipFree(d_pac); (void)hipFree(d_off); (void)hipFree(d_len); (void)hipFree(d_req); (void)hipFree(d_res);
+	(void)hipFree(d_rows);
+	if (kernel_ms) *kernel_ms = ms;
+	return 0;
+}

@@ -117,6 +117,13 @@ struct AlnCtx {
 	bool text() const { return mode != COLLECT; }
 };
 
+// ---- where mem_matesw's local alignment is computed ----
+// Same idea as AlnCtx: the alignments a pair will need are listed up front, computed in one launch of msw_kernel.hip, and
+// looked up (by mate, window and strand — the alignment is a pure function of those) when the rescue logic runs.
+struct MswReqH { int64_t rb, re; int32_t read, is_rev; };                 // same layout as the device's MswReq
+struct MswResH { int32_t score, te, qe, score2, te2, tb, qb, flags; };    // ... MswRes
+struct MswCtx { const MswReqH *req = nullptr; const MswResH *res = nullptr; int n = 0; };
+
 struct PairPlan {        // every decision mem_sam_pe takes before it formats anything (src/bwamem_pair.c:264-345)
 	int n_pri[2] = {0, 0}, z[2] = {0, 0}, q_se[2] = {0, 0};
 	int extra_flag = 1;
@@ -178,7 +185,9 @@ int  sam_pe(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, const
             HRegV a[2]);
 // the same in two halves: decisions (mutates a[]), then emission (pure; honours ctx, read0 = index of s[0] in the batch)
 void sam_pe_plan(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, const mem_pestat_t pes[4], uint64_t id, bseq1_t s[2],
-                 HRegV a[2], PairPlan &plan);
+                 HRegV a[2], PairPlan &plan, const MswCtx *mctx = nullptr, int read0 = 0);
+void sam_pe_msw_collect(const mem_opt_t *opt, const bntseq_t *bns, const mem_pestat_t pes[4], const bseq1_t s[2], const HRegV a[2], int read0,
+                        int max_tlen, std::vector<MswReqH> &out);
 void sam_pe_emit(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, const mem_pestat_t pes[4], bseq1_t s[2], HRegV a[2],
                  const PairPlan &plan, AlnCtx *ctx, int read0);
 

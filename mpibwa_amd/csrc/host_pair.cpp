@@ -139,42 +139,85 @@ void pestat(const mem_opt_t *opt, int64_t l_pac, int n, const HRegV *regs, mem_p
 		}
 }
 
-static int matesw(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, const mem_pestat_t pes[4], const HReg *a, int l_ms,
-                  const uint8_t *ms, HRegV &ma)
+// Window of the reference in which the mate of hit `a` is searched for orientation r (src/bwamem_pair.c:131-149), clipped
+// to the contig the way bns_fetch_seq does (src/bntseq.c:423-446).  False when mem_matesw would not align there.
+static bool matesw_window(const mem_opt_t *opt, const bntseq_t *bns, const mem_pestat_t pes[4], const HReg *a, int l_ms, int r, int64_t *rb_,
+                          int64_t *re_, int *is_rev_)
 {
-	HProf hp_(HP_MATESW);
-	int64_t l_pac = bns->l_pac;
-	int skip[4], n = 0, rid = -1;
+	const int64_t l_pac = bns->l_pac;
+	int is_rev = (r >> 1 != (r & 1));   // mate must be reverse-complemented
+	int is_larger = !(r >> 1);          // mate lies at the larger coordinate
+	int64_t rb, re;
+	if (!is_rev) {
+		rb = is_larger ? a->rb + pes[r].low : a->rb - pes[r].high;
+		re = (is_larger ? a->rb + pes[r].high : a->rb - pes[r].low) + l_ms;
+	} else {
+		rb = (is_larger ? a->rb + pes[r].low : a->rb - pes[r].high) - l_ms;
+		re = is_larger ? a->rb + pes[r].high : a->rb - pes[r].low;
+	}
+	if (rb < 0) rb = 0;
+	if (re > l_pac << 1) re = l_pac << 1;
+	*is_rev_ = is_rev;
+	if (rb >= re) return false;
+	int rev_mid;
+	const int64_t mid = (rb + re) >> 1;
+	int rid = bns_pos2rid(bns, bns_depos(bns, mid, &rev_mid));
+	int64_t far_beg = bns->anns[rid].offset, far_end = far_beg + bns->anns[rid].len;
+	if (rev_mid) {
+		int64_t t = far_beg;
+		far_beg = (l_pac << 1) - far_end;
+		far_end = (l_pac << 1) - t;
+	}
+	rb = std::max(rb, far_beg);
+	re = std::min(re, far_end);
+	*rb_ = rb; *re_ = re;
+	return a->rid == rid && re - rb >= opt->min_seed_len;
+}
+
+static inline void matesw_skips(const bntseq_t *bns, const mem_pestat_t pes[4], const HReg *a, const HRegV &ma, int skip[4])
+{
 	for (int r = 0; r < 4; ++r) skip[r] = pes[r].failed ? 1 : 0;
 	for (size_t i = 0; i < ma.size(); ++i) {   // orientations already explained by an existing mate hit
 		int64_t dist;
-		int r = infer_dir(l_pac, a->rb, ma[i].rb, &dist);
+		int r = infer_dir(bns->l_pac, a->rb, ma[i].rb, &dist);
 		if (dist >= pes[r].low && dist <= pes[r].high) skip[r] = 1;
 	}
+}
+
+static int matesw(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, const mem_pestat_t pes[4], const HReg *a, int l_ms,
+                  const uint8_t *ms, HRegV &ma, const MswCtx *mctx, int mate_read)
+{
+	HProf hp_(HP_MATESW);
+	int64_t l_pac = bns->l_pac;
+	int skip[4], n = 0;
+	matesw_skips(bns, pes, a, ma, skip);
 	if (skip[0] + skip[1] + skip[2] + skip[3] == 4) return 0;
 	for (int r = 0; r < 4; ++r) {
 		if (skip[r]) continue;
-		int is_rev = (r >> 1 != (r & 1));   // mate must be reverse-complemented
-		int is_larger = !(r >> 1);          // mate lies at the larger coordinate
-		std::vector<uint8_t> seq(ms, ms + l_ms), ref;
-		if (is_rev)
-			for (int i = 0; i < l_ms; ++i) seq[l_ms - 1 - i] = ms[i] < 4 ? 3 - ms[i] : 4;
-		int64_t rb, re;
-		if (!is_rev) {
-			rb = is_larger ? a->rb + pes[r].low : a->rb - pes[r].high;
-			re = (is_larger ? a->rb + pes[r].high : a->rb - pes[r].low) + l_ms;
-		} else {
-			rb = (is_larger ? a->rb + pes[r].low : a->rb - pes[r].high) - l_ms;
-			re = is_larger ? a->rb + pes[r].high : a->rb - pes[r].low;
-		}
-		if (rb < 0) rb = 0;
-		if (re > l_pac << 1) re = l_pac << 1;
-		if (rb < re) ref = bns_fetch_seq(bns, pac, &rb, (rb + re) >> 1, &re, &rid);
-		if (a->rid == rid && re - rb >= opt->min_seed_len) {
-			int xtra = KSW_XSUBO | KSW_XSTART | (l_ms * opt->a < 250 ? KSW_XBYTE : 0) | (opt->min_seed_len * opt->a);
-			HProf hp2_(HP_ALIGN2);
-			KswResult aln = ksw_align2(l_ms, seq.data(), (int)(re - rb), ref.data(), opt->mat, opt->o_del, opt->e_del, opt->o_ins,
-			                           opt->e_ins, xtra);
+		int is_rev;
+		int64_t rb = 0, re = 0;
+		if (matesw_window(opt, bns, pes, a, l_ms, r, &rb, &re, &is_rev)) {
+			KswResult aln;
+			const MswResH *hit = nullptr;
+			if (mctx)
+				for (int k = 0; k < mctx->n; ++k)
+					if (mctx->req[k].read == mate_read && mctx->req[k].rb == rb && mctx->req[k].re == re && mctx->req[k].is_rev == is_rev) {
+						if (mctx->res[k].flags == 0) hit = &mctx->res[k];
+						break;
+					}
+			if (hit) {   // computed on the device (msw_kernel.hip)
+				aln.score = hit->score; aln.te = hit->te; aln.qe = hit->qe; aln.score2 = hit->score2; aln.te2 = hit->te2; aln.tb = hit->tb; aln.qb = hit->qb;
+			} else {
+				HProf hp2_(HP_ALIGN2);
+				std::vector<uint8_t> seq(ms, ms + l_ms);
+				if (is_rev)
+					for (int i = 0; i < l_ms; ++i) seq[l_ms - 1 - i] = ms[i] < 4 ? 3 - ms[i] : 4;
+				int rid;
+				int64_t fb = rb, fe = re;
+				std::vector<uint8_t> ref = bns_fetch_seq(bns, pac, &fb, (rb + re) >> 1, &fe, &rid);
+				int xtra = KSW_XSUBO | KSW_XSTART | (l_ms * opt->a < 250 ? KSW_XBYTE : 0) | (opt->min_seed_len * opt->a);
+				aln = ksw_align2(l_ms, seq.data(), (int)(re - rb), ref.data(), opt->mat, opt->o_del, opt->e_del, opt->o_ins, opt->e_ins, xtra);
+			}
 			if (aln.score >= opt->min_seed_len && aln.qb >= 0) {
 				HReg b;
 				b.rid = a->rid;
@@ -197,6 +240,36 @@ static int matesw(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac,
 		if (n) sort_dedup_patch(opt, 0, 0, 0, ma);
 	}
 	return n;
+}
+
+// The alignments mem_sam_pe's rescue loop will ask for, judged from the hits as they are before any rescue: a request for
+// every (candidate hit, orientation) that is not already explained by a mate hit.  Later rescues of the same pair can
+// only make some of them unnecessary (or, through de-duplication, very rarely need one that is not here: matesw then
+// computes it on the host), so plugging the device results into the sequential logic changes nothing.
+void sam_pe_msw_collect(const mem_opt_t *opt, const bntseq_t *bns, const mem_pestat_t pes[4], const bseq1_t s[2], const HRegV a[2], int read0,
+                        int max_tlen, std::vector<MswReqH> &out)
+{
+	if (opt->flag & MEM_F_NO_RESCUE) return;
+	for (int i = 0; i < 2; ++i) {
+		if (a[i].empty()) continue;
+		const int l_ms = s[!i].l_seq;
+		int nb = 0;
+		for (size_t j = 0; j < a[i].size() && nb < opt->max_matesw; ++j) {
+			if (a[i][j].score < a[i][0].score - opt->pen_unpaired) continue;
+			++nb;
+			int skip[4];
+			matesw_skips(bns, pes, &a[i][j], a[!i], skip);
+			for (int r = 0; r < 4; ++r) {
+				if (skip[r]) continue;
+				MswReqH q;
+				int is_rev;
+				if (!matesw_window(opt, bns, pes, &a[i][j], l_ms, r, &q.rb, &q.re, &is_rev)) continue;
+				if (q.re - q.rb > max_tlen) continue;
+				q.read = read0 + !i; q.is_rev = is_rev;
+				out.push_back(q);
+			}
+		}
+	}
 }
 
 struct Pair64 { uint64_t x, y; };
@@ -263,7 +336,7 @@ static int pair_hits(const mem_opt_t *opt, const bntseq_t *bns, const mem_pestat
 
 // ---- decisions: mate rescue, primary marking, pairing, MAPQ (everything that mutates a[]) ----
 void sam_pe_plan(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, const mem_pestat_t pes[4], uint64_t id, bseq1_t s[2],
-                 HRegV a[2], PairPlan &P)
+                 HRegV a[2], PairPlan &P, const MswCtx *mctx, int read0)
 {
 	int n = 0, o, subo = 0, n_sub = 0;
 	P = PairPlan();
@@ -274,7 +347,7 @@ void sam_pe_plan(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, 
 				if (a[i][j].score >= a[i][0].score - opt->pen_unpaired) b[i].push_back(a[i][j]);
 		for (int i = 0; i < 2; ++i)
 			for (size_t j = 0; j < b[i].size() && (int)j < opt->max_matesw; ++j)
-				n += matesw(opt, bns, pac, pes, &b[i][j], s[!i].l_seq, (uint8_t *)s[!i].seq, a[!i]);
+				n += matesw(opt, bns, pac, pes, &b[i][j], s[!i].l_seq, (uint8_t *)s[!i].seq, a[!i], mctx, read0 + !i);
 	}
 	P.n_rescue = n;
 	P.n_pri[0] = mark_primary_se(opt, a[0], id << 1 | 0);

@@ -1,0 +1,217 @@
+// msw_kernel.hip — mate-rescue local alignment on the device: ksw_align2() as mem_matesw() calls it
+// (src/bwamem_pair.c:150-177 -> src/ksw.c:321-356, kernels ksw_u8 src/ksw.c:111-237 and ksw_i16 src/ksw.c:239-319).
+//
+// What has to be reproduced is not textbook Smith-Waterman.  The reference runs Farrar's striped SSE2 kernel, in which a
+// query of qlen bases is cut into P segments of slen = ceil(qlen / P) positions (P = 16 byte lanes when qlen * a < 250,
+// else 8 word lanes) and
+//   * inside the main loop F only propagates within a segment (every lane starts a row with F = 0);
+//   * E(i+1,j) is computed there, from the H that main loop sees ("we disallow adjacent insertion and then
+//     deletion", src/ksw.c:176) — i.e. from Hpre = max(Hdiag + s, E, Fseg), not from the final H;
+//   * the lazy-F loop afterwards carries F across segment borders and only raises H (exactly: its early exit
+//     never drops a carry that could still matter);
+//   * positions qlen .. slen*P-1 are padding that scores 0 against everything, and they do take part in the row maximum;
+//   * the row maximum feeds a run-length list b[] whose "consecutive row" test looks at the row stored in the last
+//     entry, not at the previous row.
+// All of this is observable in (score, te, qe, score2, te2), so the kernel keeps two F values per cell — Fseg (reset
+// at every segment start) and Ffull (never reset) — and computes
+//     Hpre = max(Hdiag + s, E, Fseg)      H = max(Hpre, Ffull)
+//     E'   = max(E - e_del, Hpre - oe_del, 0)
+//     F*'  = max(F* - e_ins, Hpre - oe_ins, 0)
+// which is value-for-value what the striped kernel leaves in its H / E arrays once a row is finished.  No value can
+// saturate in the byte flavour (qlen * a < 250 and shift = -min(mat)); a request whose scores could reach the 8-bit
+// ceiling is flagged and recomputed on the host.
+//
+// Mapping: one request per lane, 64 requests per wave, one wave per workgroup.  The row state of a lane — H(i-1,k), E(i,k)
+// and the query base of position k packed in one dword (13 + 13 + 3 bits) — lives in LDS as cell[k][lane], so the 64
+// lanes of a wave touch 64 consecutive dwords (no bank conflicts) and the whole DP runs out of LDS and registers.
+// HBM traffic is the target window (2 bits per row) and one u16 per row for the b[] pass.  The work is VALU-bound:
+// ~30 integer ops per cell.
+#include <hip/hip_runtime.h>
+#include "device.h"
+
+namespace mbw {
+
+#define HIP_OK(call)                                                                                             \
+	do {                                                                                                         \
+		hipError_t e_ = (call);                                                                                  \
+		if (e_ != hipSuccess) die("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);    \
+	} while (0)
+
+namespace {
+
+#define MSW_PAD 7u
+
+__device__ __forceinline__ int msw_base(const uint8_t *__restrict__ pac, int64_t l_pac, int64_t p)
+{
+	if (p >= l_pac) {
+		int64_t f = (l_pac << 1) - 1 - p;
+		return 3 - ((pac[f >> 2] >> ((~f & 3) << 1)) & 3);
+	}
+	return (pac[p >> 2] >> ((~p & 3) << 1)) & 3;
+}
+
+struct MswPassOut { int score, te, qe; };
+
+// One striped-SW pass for the 64 requests of the wave.  Per lane: `npos` positions already laid out in LDS (query codes,
+// H = E = 0), `tn` target rows, row i reads doubled-coordinate position t0 + i * tdir.
+// rows != nullptr: the row maxima are written to rows[i * row_stride] (the b[] list is rebuilt from them afterwards).
+__device__ __forceinline__ MswPassOut msw_pass(uint32_t *cell, const MswParams &P, const uint8_t *__restrict__ pac, bool live, int npos, int slen,
+                                               int tn, int64_t t0, int tdir, int endsc, int sat_limit, uint16_t *rows, size_t row_stride,
+                                               int *sat_hit)
+{
+	const int lane = threadIdx.x;
+	int gmax = 0, te = -1, qe = -1;
+	bool run = live && tn > 0;
+	const int oe_del = P.o_del + P.e_del, oe_ins = P.o_ins + P.e_ins, e_del = P.e_del, e_ins = P.e_ins;
+	int tb_next = run ? msw_base(pac, P.l_pac, t0) : 0;
+	for (int i = 0; __any(run); ++i) {
+		const int tb = tb_next;
+		if (run && i + 1 < tn) tb_next = msw_base(pac, P.l_pac, t0 + (int64_t)(i + 1) * tdir);   // in flight during this row
+		// scores of this row's target base against query codes 0..3 (one byte each) and 4
+		const uint32_t slo = tb == 0 ? P.slo[0] : tb == 1 ? P.slo[1] : tb == 2 ? P.slo[2] : P.slo[3];
+		const int s4 = tb == 0 ? P.s4[0] : tb == 1 ? P.s4[1] : tb == 2 ? P.s4[2] : P.s4[3];
+		int diag = 0, fseg = 0, ffull = 0, cnt = slen;
+		uint32_t key = 0;   // (row maximum << 16) | (0xffff - first position reaching it)
+		const int kmax = run ? npos : 0;
+		// uniform trip count: the longest row in the wave (positions are multiples of 8)
+		int kwave = kmax;
+		for (int o = 32; o; o >>= 1) kwave = max(kwave, __shfl_xor(kwave, o));
+		for (int k = 0; k < kwave; k += 4) {
+			if (k < kmax) {
+				uint32_t w[4];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) w[u] = cell[(k + u) * 64 + lane];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					const int hk = w[u] & 0x1fff;
+					int e = (w[u] >> 13) & 0x1fff;
+					const uint32_t q = w[u] >> 26;
+					int s = (int)(int8_t)(slo >> ((q & 3) << 3));
+					s = q < 4 ? s : (q == 4 ? s4 : 0);
+					int h = max(max(diag + s, e), fseg);                 // Hpre(i,k)
+					key = max(key, (uint32_t)h << 16 | (uint32_t)(0xffff - (k + u)));
+					const int hfin = max(h, ffull);                      // H(i,k) after the lazy-F pass
+					e = max(max(e - e_del, h - oe_del), 0);
+					const int t2 = h - oe_ins;
+					fseg = max(max(fseg - e_ins, t2), 0);
+					ffull = max(max(ffull - e_ins, t2), 0);
+					if (--cnt == 0) { fseg = 0; cnt = slen; }
+					diag = hk;
+					w[u] = (uint32_t)hfin | (uint32_t)e << 13 | q << 26;
+				}
+#pragma unroll
+				for (int u = 0; u < 4; ++u) cell[(k + u) * 64 + lane] = w[u];
+			}
+		}
+		if (run) {
+			const int imax = (int)(key >> 16);
+			if (rows) rows[(size_t)i * row_stride] = (uint16_t)imax;
+			if (imax > gmax) {
+				gmax = imax; te = i; qe = 0xffff - (int)(key & 0xffff);
+				if (gmax >= sat_limit) { *sat_hit = 1; run = false; }
+				if (gmax >= endsc) run = false;
+			}
+			if (i + 1 >= tn) run = false;
+		}
+	}
+	MswPassOut o = {gmax, te, qe};
+	return o;
+}
+
+__global__ __launch_bounds__(64) void msw_kernel(MswParams P, int n_req, const MswReq *__restrict__ req, const uint8_t *__restrict__ seq,
+                                                 const int64_t *__restrict__ off, const int *__restrict__ lens, const uint8_t *__restrict__ pac,
+                                                 MswRes *__restrict__ res, uint16_t *__restrict__ rows)
+{
+	extern __shared__ uint32_t cell[];   // [positions][64 lanes]
+	const int lane = threadIdx.x;
+	const int r = blockIdx.x * 64 + lane;
+	const bool live = r < n_req;
+	MswReq rq;
+	rq.rb = rq.re = 0; rq.read = 0; rq.is_rev = 0;
+	if (live) rq = req[r];
+	const int qlen = live ? lens[rq.read] : 0;
+	const int tlen = (int)(rq.re - rq.rb);
+	const bool byte_flavour = qlen * P.a < 250;          // KSW_XBYTE as mem_matesw sets it
+	const int PP = byte_flavour ? 16 : 8;
+	int slen = (qlen + PP - 1) / PP;
+	int npos = slen * PP;
+	// query codes -> LDS (reverse-complemented for the orientations that need it), H = E = 0
+	if (live) {
+		const uint8_t *ms = seq + off[rq.read];
+		for (int k = 0; k < npos; ++k) {
+			uint32_t c = MSW_PAD;
+			if (k < qlen) {
+				if (rq.is_rev) { uint32_t b = ms[qlen - 1 - k]; c = b < 4 ? 3 - b : 4; }
+				else { c = ms[k]; if (c > 4) c = 4; }
+			}
+			cell[k * 64 + lane] = c << 26;
+		}
+	}
+	const int minsc = P.min_seed_len * P.a;              // KSW_XSUBO | min_seed_len * a
+	const int sat_limit = byte_flavour ? 255 - P.shift : 0x10000;
+	int sat = 0;
+	MswPassOut f = msw_pass(cell, P, pac, live, npos, slen, tlen, rq.rb, 1, 0x10000, sat_limit, live ? rows + r : nullptr, (size_t)n_req, &sat);
+	MswRes out;
+	out.score = f.score; out.te = f.te; out.qe = f.qe; out.score2 = -1; out.te2 = -1; out.tb = -1; out.qb = -1; out.flags = sat;
+	// b[]: runs of rows whose maximum reaches minsc; second best = best run outside te +- ceil(score / max)
+	if (live && !sat && f.te >= 0) {
+		const int d = (f.score + P.max_sc - 1) / P.max_sc;
+		const int low = f.te - d, high = f.te + d;
+		int last_sc = -1, last_i = -1;
+		const int rows_done = f.te >= 0 ? tlen : 0;   // the forward pass never stops early (no KSW_XSTOP, no saturation)
+		for (int i = 0; i < rows_done; ++i) {
+			const int im = rows[(size_t)i * n_req + r];
+			if (im < minsc) continue;
+			if (last_i < 0 || last_i + 1 != i) {
+				if (last_i >= 0 && (last_i < low || last_i > high) && last_sc > out.score2) { out.score2 = last_sc; out.te2 = last_i; }
+				last_sc = im; last_i = i;
+			} else if (last_sc < im) { last_sc = im; last_i = i; }
+		}
+		if (last_i >= 0 && (last_i < low || last_i > high) && last_sc > out.score2) { out.score2 = last_sc; out.te2 = last_i; }
+	}
+	// second pass over the reversed prefixes: where does the best local alignment start (KSW_XSTART)
+	const bool second = live && !sat && f.score >= minsc && f.qe >= 0 && f.te >= 0;
+	int qlen2 = second ? f.qe + 1 : 0;
+	if (second && f.qe >= qlen) qlen2 = 0;   // cannot happen (the maximum of a row is reached on a real base first); stay in bounds
+	const int slen2 = (qlen2 + PP - 1) / PP, npos2 = slen2 * PP;
+	if (qlen2 > 0) {
+		// reverse the codes of positions 0..qe in place, pad the rest, clear H and E
+		for (int k = 0; k < (qlen2 + 1) / 2; ++k) {
+			uint32_t a = cell[k * 64 + lane] >> 26, b = cell[(qlen2 - 1 - k) * 64 + lane] >> 26;
+			cell[k * 64 + lane] = b << 26;
+			cell[(qlen2 - 1 - k) * 64 + lane] = a << 26;
+		}
+		for (int k = qlen2; k < npos2; ++k) cell[k * 64 + lane] = MSW_PAD << 26;
+	}
+	int sat2 = 0;
+	MswPassOut g = msw_pass(cell, P, pac, qlen2 > 0, npos2, slen2, f.te + 1, rq.rb + f.te, -1, f.score, sat_limit, nullptr, 0, &sat2);
+	if (qlen2 > 0 && g.score == f.score) { out.tb = f.te - g.te; out.qb = f.qe - g.qe; }
+	if (second && qlen2 == 0) out.flags = 1;
+	if (sat2) out.flags = 1;
+	if (live) res[r] = out;
+}
+
+} // namespace
+
+size_t msw_lds_bytes(int max_len)
+{
+	return (size_t)((max_len + 15) / 16 * 16) * 64 * 4;   // padded to 16 covers both lane widths
+}
+
+void launch_msw(void *stream, const MswParams &P, int n_req, const MswReq *d_req, const uint8_t *d_seq, const int64_t *d_off, const int *d_len,
+                const uint8_t *d_pac, MswRes *d_res, uint16_t *d_rows, int max_len)
+{
+	if (n_req <= 0) return;
+	const size_t lds = msw_lds_bytes(max_len);
+	if (lds > 160 * 1024) die("mate-rescue kernel: reads of %d bp do not fit the LDS row buffers", max_len);
+	static size_t s_attr = 0;
+	if (lds > s_attr) {
+		HIP_OK(hipFuncSetAttribute((const void *)msw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		s_attr = lds;
+	}
+	const int blocks = (n_req + 63) / 64;
+	hipLaunchKernelGGL(msw_kernel, dim3(blocks), dim3(64), lds, (hipStream_t)stream, P, n_req, d_req, d_seq, d_off, d_len, d_pac, d_res, d_rows);
+	HIP_OK(hipGetLastError());
+}
+
+} // namespace mbw

@@ -158,7 +158,8 @@ struct PinBuf {
 
 struct Workspace {
 	HostBuf reg_arena;
-	PinBuf h_flat, h_sa, h_qbl, h_chains, h_seeds, h_srt, h_regs, h_nregs;
+	PinBuf h_flat, h_sa, h_qbl, h_chains, h_seeds, h_srt, h_regs, h_nregs, h_mreq[2], h_mres[2];
+	DevBuf mreq[2], mres[2], mrows[2];
 	DevBuf seq, off, len, intv, nintv, cnt, scratch, nseeds, lrep, seed_off, rows, qbl, sa;
 	DevBuf chain_off, chains, seeds, srt, reg_off, regs, nregs, tab, areq, ahdr, apool, agap, acnt, areq2, ahdr2, apool2, acnt2;
 };
@@ -546,6 +547,12 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		std::vector<AlnHdrH> hdr;
 		std::vector<uint8_t> pool;
 		unsigned long long cnt[8] = {0};
+		// mate-rescue alignments of the part: requests of unit k are mreq[mbase[k] .. mbase[k+1])
+		MswReqH *mreq = nullptr; MswResH *mres = nullptr;
+		std::vector<uint32_t> mbase;
+		size_t n_mreq = 0;
+		EvTimer mev;
+		bool m_launched = false;
 		AlnHdr *d_hdr = nullptr; uint8_t *d_pool = nullptr; unsigned long long *d_cnt = nullptr;
 		size_t pool_bytes = 0;
 		hipStream_t st = 0;
@@ -565,6 +572,70 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	HIP_OK(hipMemcpy(d_gap, gaptab.data(), gaptab.size() * 4, hipMemcpyHostToDevice));
 	double plan_ms = 0, aln_wait_ms = 0;
 
+	// mate rescue on the device: list the local alignments the pairs of a part will ask for, run them in one launch
+	static_assert(sizeof(MswReq) == sizeof(MswReqH) && sizeof(MswRes) == sizeof(MswResH), "host/device record layouts differ");
+	const int MSW_MAX_T = 4096;
+	const bool gpu_msw = pe && !(opt->flag & MEM_F_NO_RESCUE) && getenv("MPIBWA_HOST_MATESW") == nullptr && (int64_t)max_len * opt->a < 8192 &&
+	                     msw_lds_bytes(max_len) <= 160 * 1024;
+	double msw_ms = 0;
+	auto mcollect = [&](Part &P, int slot) {
+		if (!gpu_msw) return;
+		double ta = now_ms();
+		const int nu = P.hi - P.lo, n_blk = (nu + 255) / 256;
+		std::vector<std::vector<MswReqH>> blk_req(n_blk);
+		std::vector<uint32_t> u_first(nu), u_cnt(nu);
+		parallel_for(n_thr, n_blk, 1, [&](int blk) {
+			std::vector<MswReqH> &rq = blk_req[blk];
+			rq.reserve(256);
+			const int lo = P.lo + blk * 256, hi = std::min(P.hi, lo + 256);
+			for (int i = lo; i < hi; ++i) {
+				const size_t before = rq.size();
+				sam_pe_msw_collect(opt, bns, pes, &seqs[i << 1], &regs[i << 1], i << 1, MSW_MAX_T, rq);
+				u_first[i - P.lo] = (uint32_t)before; u_cnt[i - P.lo] = (uint32_t)(rq.size() - before);
+			}
+		});
+		P.mbase.assign(nu + 1, 0);
+		for (int i = 0; i < nu; ++i) P.mbase[i + 1] = P.mbase[i] + u_cnt[i];
+		P.n_mreq = P.mbase[nu];
+		P.mreq = (MswReqH *)W.h_mreq[slot].ensure(P.n_mreq * sizeof(MswReqH) + 64);
+		P.mres = (MswResH *)W.h_mres[slot].ensure(P.n_mreq * sizeof(MswResH) + 64);
+		parallel_for(n_thr, nu, 4096, [&](int i) {
+			if (u_cnt[i]) memcpy(&P.mreq[P.mbase[i]], &blk_req[i >> 8][u_first[i]], (size_t)u_cnt[i] * sizeof(MswReqH));
+		});
+		msw_ms += now_ms() - ta;
+	};
+	auto mlaunch = [&](Part &P, int slot) {   // asynchronous
+		if (!gpu_msw || P.n_mreq == 0) return;
+		P.st = a_streams[slot];
+		int max_t = 1;
+		for (size_t k = 0; k < P.n_mreq; ++k) max_t = std::max(max_t, (int)(P.mreq[k].re - P.mreq[k].rb));
+		MswReq *d_req = (MswReq *)W.mreq[slot].ensure(P.n_mreq * sizeof(MswReq));
+		MswRes *d_res = (MswRes *)W.mres[slot].ensure(P.n_mreq * sizeof(MswRes));
+		// row-maximum scratch: at most 2 GiB at a time
+		size_t per = std::max<size_t>(64, (((size_t)1 << 31) / ((size_t)max_t * 2)) & ~(size_t)63);
+		per = std::min(per, (P.n_mreq + 63) & ~(size_t)63);
+		uint16_t *d_rows = (uint16_t *)W.mrows[slot].ensure(per * (size_t)max_t * 2);
+		HIP_OK(hipMemcpyAsync(d_req, P.mreq, P.n_mreq * sizeof(MswReq), hipMemcpyHostToDevice, P.st));
+		const MswParams mp = msw_params(opt, bns->l_pac);
+		P.mev.start(P.st);
+		for (size_t b = 0; b < P.n_mreq; b += per) {
+			const int cnt = (int)std::min(per, P.n_mreq - b);
+			launch_msw(P.st, mp, cnt, d_req + b, d_seq, d_off, d_len, (const uint8_t *)ix.d_pac, d_res + b, d_rows, max_len);
+		}
+		P.mev.stop(P.st);
+		HIP_OK(hipMemcpyAsync(P.mres, d_res, P.n_mreq * sizeof(MswRes), hipMemcpyDeviceToHost, P.st));   // pinned: truly asynchronous
+		P.m_launched = true;
+	};
+	auto mfinish = [&](Part &P) {
+		if (!P.m_launched) return;
+		double ta = now_ms();
+		HIP_OK(hipStreamSynchronize(P.st));
+		HIP_OK(hipGetLastError());
+		g_stats.k_msw_ms += P.mev.ms();
+		g_stats.n_msw += P.n_mreq;
+		msw_ms += now_ms() - ta;
+	};
+
 	auto collect = [&](Part &P) {   // A
 		double ta = now_ms();
 		const int nu = P.hi - P.lo, n_blk = (nu + 255) / 256;
@@ -579,7 +650,10 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			for (int i = lo; i < hi; ++i) {
 				const size_t before = rq.size();
 				if (pe) {
-					sam_pe_plan(opt, bns, pac, pes, (uint64_t)((n_processed >> 1) + i), &seqs[i << 1], &regs[i << 1], plans[i]);
+					MswCtx mc;
+					if (P.m_launched) { mc.req = P.mreq + P.mbase[i - P.lo]; mc.res = P.mres + P.mbase[i - P.lo]; mc.n = (int)(P.mbase[i - P.lo + 1] - P.mbase[i - P.lo]); }
+					sam_pe_plan(opt, bns, pac, pes, (uint64_t)((n_processed >> 1) + i), &seqs[i << 1], &regs[i << 1], plans[i], P.m_launched ? &mc : nullptr,
+					            i << 1);
 					if (gpu_aln) sam_pe_emit(opt, bns, pac, pes, &seqs[i << 1], &regs[i << 1], plans[i], &ctx, i << 1);
 				} else {
 					mark_primary_se(opt, regs[i], n_processed + i);
@@ -654,15 +728,18 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	};
 	if (n_parts == 1) {
 		parts[0].lo = 0; parts[0].hi = n_units;
+		mcollect(parts[0], 0); mlaunch(parts[0], 0); mfinish(parts[0]);
 		collect(parts[0]); launch(parts[0], 0); finish(parts[0]); replay(parts[0]);
 	} else {
 		parts[0].lo = 0; parts[0].hi = n_units / 2; parts[1].lo = n_units / 2; parts[1].hi = n_units;
-		collect(parts[0]); launch(parts[0], 0);
-		collect(parts[1]); launch(parts[1], 1);
+		mcollect(parts[0], 0); mlaunch(parts[0], 0);
+		mcollect(parts[1], 1); mlaunch(parts[1], 1);
+		mfinish(parts[0]); collect(parts[0]); launch(parts[0], 0);
+		mfinish(parts[1]); collect(parts[1]); launch(parts[1], 1);
 		finish(parts[0]); replay(parts[0]);
 		finish(parts[1]); replay(parts[1]);
 	}
-	g_stats.plan_ms = plan_ms; g_stats.aln_ms = aln_wait_ms;
+	g_stats.plan_ms = plan_ms; g_stats.aln_ms = aln_wait_ms; g_stats.msw_ms = msw_ms;
 	double t8 = now_ms();
 	hprof_report("sam stage");
 	// release the per-read containers in parallel (millions of small blocks: serial destruction costs ~0.2 s per chunk)

@@ -164,3 +164,10 @@ def test_overlapped_sub_batches_and_host_cigar_paths(both, reads_pe, monkeypatch
     assert eng.process(eng.opt(flag=abi.MEM_F_PE), ra) == want
     monkeypatch.setenv("MPIBWA_SMEM", "lane")
     assert eng.process(eng.opt(flag=abi.MEM_F_PE), ra) == want
+    monkeypatch.setenv("MPIBWA_HOST_MATESW", "1")   # mate rescue computed by the host's striped SW instead of msw_kernel
+    assert eng.process(eng.opt(flag=abi.MEM_F_PE), ra) == want
+    assert eng.stats()["n_msw"] == 0
+    monkeypatch.delenv("MPIBWA_HOST_MATESW")
+    monkeypatch.delenv("MPIBWA_HOST_CIGAR")
+    assert eng.process(eng.opt(flag=abi.MEM_F_PE), ra) == want
+    assert eng.stats()["n_msw"] > 0

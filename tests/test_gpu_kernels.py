@@ -128,3 +128,101 @@ def test_extend_kernel_matches_oracle(engine):
         assert (got[i] == want).all(), (i, len(qs[i]), len(ts[i]), ws[i], h0s[i], got[i], want)
         tot += c
     assert cells == tot
+
+
+def _matesw_cases(rng, l_pac, ref, n_req, read_lens):
+    """Random mate-rescue problems: windows of the doubled reference, reads planted in them with noise and gaps."""
+    dref = np.concatenate([ref, 3 - ref[::-1]]).astype(np.uint8)   # the doubled coordinate: forward, then reverse complement
+    reads, rb, re, rd, rev = [], [], [], [], []
+    for i in range(n_req):
+        ql = int(rng.choice(read_lens))
+        tl = int(rng.integers(max(ql // 2, 19), ql + 600))
+        strand = int(rng.integers(0, 2))
+        b = int(rng.integers(0, l_pac - tl)) + strand * l_pac
+        win = dref[b:b + tl]
+        mode = rng.random()
+        if mode < 0.75 and tl >= ql // 2:
+            p = int(rng.integers(-ql // 3, tl - ql // 2))
+            src = win[max(p, 0):max(p, 0) + ql].copy()
+            q = rng.integers(0, 4, size=ql).astype(np.uint8)
+            q[:len(src)] = src
+            mut = rng.random(ql) < rng.choice([0.0, 0.02, 0.08, 0.2])
+            q[mut] = rng.integers(0, 4, size=int(mut.sum()))
+            for _ in range(int(rng.integers(0, 4))):   # gaps, long ones included (they cross the striped segments)
+                g, at = int(rng.integers(1, 25)), int(rng.integers(1, ql - 1))
+                if rng.random() < 0.5:
+                    q = np.concatenate([q[:at], rng.integers(0, 4, size=g).astype(np.uint8), q[at:]])[:ql]
+                else:
+                    q = np.concatenate([q[:at], q[at + g:], rng.integers(0, 4, size=g).astype(np.uint8)])[:ql]
+            if rng.random() < 0.25:   # a second, weaker copy far away -> score2 / te2
+                p2 = int(rng.integers(0, max(1, tl - ql)))
+                q2 = q.copy()
+                m2 = rng.random(ql) < 0.1
+                q2[m2] = rng.integers(0, 4, size=int(m2.sum()))
+                seg = q2[:min(ql, tl - p2)]
+                # the window is what it is: plant into the read instead (repeat inside the read)
+                q[:len(seg) // 3] = win[p2:p2 + len(seg) // 3]
+        elif mode < 0.9:   # low complexity
+            q = np.repeat(rng.integers(0, 4, size=(ql + 2) // 3), 3)[:ql].astype(np.uint8)
+        else:
+            q = rng.integers(0, 4, size=ql).astype(np.uint8)
+        if rng.random() < 0.1:
+            q[int(rng.integers(0, ql))] = 4
+        is_rev = int(rng.integers(0, 2))
+        # the kernel aligns the (reverse-complemented) read: store the read so that its transform is q
+        stored = q if not is_rev else np.where(q[::-1] < 4, 3 - q[::-1], 4).astype(np.uint8)
+        reads.append(stored)
+        rb.append(b); re.append(b + tl); rd.append(i); rev.append(is_rev)
+    return reads, rb, re, rd, rev
+
+
+def test_matesw_kernel_matches_reference_ksw_align2(engine):
+    """msw_kernel == ksw_align2 with mem_matesw's flags (src/bwamem_pair.c:150-177), byte and word flavours."""
+    import ctypes as C
+    from mpibwa_amd import api
+    lib = api.load_library()
+    rng = np.random.default_rng(2024)
+    l_pac = 40000
+    ref = rng.integers(0, 4, size=l_pac).astype(np.uint8)
+    ref[5000:5600] = np.tile(ref[5000:5006], 100)   # a tandem repeat
+    pac = np.zeros(l_pac // 4 + 1, dtype=np.uint8)
+    for k in range(4):
+        pac[:l_pac // 4] |= (ref[k::4] << ((3 - k) * 2)).astype(np.uint8)
+    opt_p = engine.opt()
+    opt = opt_p.contents
+    mat = np.frombuffer(bytes(opt.mat), dtype=np.int8).copy()
+    reads, rb, re, rd, rev = _matesw_cases(rng, l_pac, ref, 3000, [50, 100, 150, 151, 249, 250, 251, 301])
+    got, ms = engine.matesw(opt_p, l_pac, pac, reads, rb, re, rd, rev)
+    use_ref = po.ref_available()
+    if use_ref:
+        class kswr_t(C.Structure):
+            _fields_ = [(n, C.c_int) for n in ("score", "te", "qe", "score2", "te2", "tb", "qb")]
+        rl = po.ref_lib()
+        rl.ksw_align2.restype = kswr_t
+        rl.ksw_align2.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
+    n_hit = n_second = 0
+    dref = np.concatenate([ref, 3 - ref[::-1]]).astype(np.uint8)
+    for i in range(len(rb)):
+        tl = re[i] - rb[i]
+        win = np.ascontiguousarray(dref[rb[i]:re[i]])
+        s = reads[i]
+        q = s if not rev[i] else np.where(s[::-1] < 4, 3 - s[::-1], 4).astype(np.uint8)
+        q = np.ascontiguousarray(q)
+        xtra = 0x40000 | 0x80000 | (0x10000 if len(q) * opt.a < 250 else 0) | (opt.min_seed_len * opt.a)
+        want = np.zeros(7, dtype=np.int32)
+        lib.mi355x_host_ksw_align2(len(q), q.ctypes.data, tl, win.ctypes.data, mat.ctypes.data, opt.o_del, opt.e_del, opt.o_ins, opt.e_ins,
+                                   xtra, 1, want.ctypes.data)
+        if use_ref:
+            qq, tt = q.copy(), win.copy()
+            w = rl.ksw_align2(len(q), qq.ctypes.data, tl, tt.ctypes.data, 5, mat.ctypes.data, opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, xtra, None)
+            assert (want == np.array([w.score, w.te, w.qe, w.score2, w.te2, w.tb, w.qb])).all()
+        assert got[i, 7] == 0
+        g = got[i, :7]
+        # below min_seed_len * a the caller drops the result and the reference leaves te/qe of its scan; compare what is used
+        if want[0] < opt.min_seed_len * opt.a:
+            assert g[0] == want[0] and g[5] == -1 and g[6] == -1, (i, g, want)
+        else:
+            assert (g == want).all(), (i, len(q), tl, rev[i], g, want)
+            n_hit += 1
+            n_second += want[3] > 0
+    assert n_hit > 1500 and n_second > 50
