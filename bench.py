@@ -149,7 +149,7 @@ def main():
         "sam_bytes_per_step": int(sam_bytes / args.steps),
         "roofline": roofline,
         "stage_ms_per_step": {k: round(acc[k] / args.steps, 2) for k in
-                              ("total_ms", "h2d_ms", "phase1_ms", "smem_ms", "sa_ms", "chain_ms", "ext_ms", "regs_ms", "pestat_ms", "sam_ms", "msw_ms", "plan_ms", "aln_ms", "k_smem_ms", "k_sa_ms", "k_ext_ms", "k_msw_ms", "k_aln_ms")},
+                              ("total_ms", "h2d_ms", "phase1_ms", "smem_ms", "sa_ms", "chain_ms", "ext_ms", "regs_ms", "pestat_ms", "sam_ms", "msw_ms", "plan_ms", "aln_ms", "emit_ms", "k_smem_ms", "k_sa_ms", "k_ext_ms", "k_msw_ms", "k_aln_ms")},
         "aux_kernels": {
             "sa_kernel_GBps": round(acc["sa_bytes"] / (acc["k_sa_ms"] * 1e-3) / 1e9, 1) if acc.get("k_sa_ms") else None,
             "c2a_kernel_GCUPS": round(acc["ext_cells"] / (acc["k_ext_ms"] * 1e-3) / 1e9, 2) if acc.get("k_ext_ms") else None},

@@ -224,6 +224,7 @@ typedef struct {
 	double phase1_ms;                            /* wall time of stages 2-6 (sub-batches overlap, so it is less than their sum) */
 	double msw_ms, k_msw_ms;                     /* mate rescue: listing the alignments + waiting for them, HIP-event kernel time */
 	uint64_t n_msw;                              /* local alignments computed by the mate-rescue kernel */
+	double emit_ms;                              /* SAM stage: the pass that formats the records */
 } mi355x_stats_t;
 void mi355x_last_stats(mi355x_stats_t *st);
 

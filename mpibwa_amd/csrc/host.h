@@ -86,11 +86,51 @@ public:
 	}
 };
 
+// CIGAR of one record: a few operations almost always, so they live inside the object (no heap block per record)
+class CigarV {
+	static const uint32_t INL = 8;
+	uint32_t *p_;
+	uint32_t n_ = 0, cap_ = INL;
+	uint32_t inl_[INL];
+	void grow(uint32_t want)
+	{
+		uint32_t nc = cap_ * 2 > want ? cap_ * 2 : want;
+		uint32_t *q = (uint32_t *)malloc((size_t)nc * 4);
+		memcpy(q, p_, (size_t)n_ * 4);
+		if (p_ != inl_) free(p_);
+		p_ = q; cap_ = nc;
+	}
+public:
+	CigarV() : p_(inl_) {}
+	~CigarV() { if (p_ != inl_) free(p_); }
+	CigarV(const CigarV &o) : p_(inl_) { assign(o.begin(), o.end()); }
+	CigarV &operator=(const CigarV &o) { if (this != &o) assign(o.begin(), o.end()); return *this; }
+	void assign(const uint32_t *b, const uint32_t *e)
+	{
+		uint32_t m = (uint32_t)(e - b);
+		if (m > cap_) { n_ = 0; grow(m); }
+		if (m) memmove(p_, b, (size_t)m * 4);
+		n_ = m;
+	}
+	size_t size() const { return n_; }
+	bool empty() const { return n_ == 0; }
+	void clear() { n_ = 0; }
+	uint32_t &operator[](size_t i) { return p_[i]; }
+	uint32_t operator[](size_t i) const { return p_[i]; }
+	uint32_t back() const { return p_[n_ - 1]; }
+	const uint32_t *begin() const { return p_; }
+	const uint32_t *end() const { return p_ + n_; }
+	void push_back(uint32_t v) { if (n_ == cap_) grow(n_ + 1); p_[n_++] = v; }
+	void pop_back() { --n_; }
+	void push_front(uint32_t v) { if (n_ == cap_) grow(n_ + 1); memmove(p_ + 1, p_, (size_t)n_ * 4); p_[0] = v; ++n_; }
+	void pop_front() { memmove(p_, p_ + 1, (size_t)(n_ - 1) * 4); --n_; }
+};
+
 struct HAln {            // mem_aln_t, src/bwamem.h:87-98 (cigar + MD kept as separate members)
 	int64_t pos = 0;
 	int rid = 0, flag = 0;
 	uint32_t is_rev = 0, is_alt = 0, mapq = 0, NM = 0;
-	std::vector<uint32_t> cigar;
+	CigarV cigar;
 	std::string md;
 	bool has_xa = false;
 	std::string xa;

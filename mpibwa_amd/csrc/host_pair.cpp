@@ -17,7 +17,7 @@
 
 namespace mbw {
 
-void aln2sam_pub(const mem_opt_t *opt, const bntseq_t *bns, std::string &str, const bseq1_t *s, int n, const HAln *list, int which,
+void aln2sam_pub(const mem_opt_t *opt, const bntseq_t *bns, std::string &str, const bseq1_t *s, int n, const HAln *const *list, int which,
                  const HAln *m);
 bool gen_alt(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, const HRegV &a, int l_query, const char *query,
              std::vector<std::string> &xa, std::vector<char> &has, AlnCtx *ctx, int read_idx);
@@ -415,29 +415,31 @@ void sam_pe_emit(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, 
 		bool have_xa[2] = {false, false};
 		if (!(opt->flag & MEM_F_ALL))
 			for (int i = 0; i < 2; ++i) have_xa[i] = gen_alt(opt, bns, pac, a[i], s[i].l_seq, s[i].seq, xa[i], has[i], ctx, read0 + i);
-		std::vector<HAln> aa[2];
+		const HAln *aa[2][2];   // the lines of each read: the chosen hit, then possibly its best ALT hit
+		int n_aa[2] = {0, 0};
 		HAln g[2];
 		for (int i = 0; i < 2; ++i) {
 			h[i] = reg2aln(opt, bns, pac, s[i].l_seq, s[i].seq, &a[i][z[i]], ctx, read0 + i);
 			h[i].mapq = P.q_se[i] & 0xff;
 			h[i].flag |= 0x40 << i | P.extra_flag;
 			if (text && have_xa[i] && has[i][z[i]]) { h[i].has_xa = true; h[i].xa = xa[i][z[i]]; }
-			aa[i].push_back(h[i]);
+			aa[i][n_aa[i]++] = &h[i];
 			if (n_pri[i] < (int)a[i].size()) {   // the read also has ALT hits
 				HReg *p = &a[i][n_pri[i]];
 				if (p->score < opt->T || p->secondary >= 0 || !p->is_alt) continue;
 				g[i] = reg2aln(opt, bns, pac, s[i].l_seq, s[i].seq, p, ctx, read0 + i);
 				g[i].flag |= 0x800 | 0x40 << i | P.extra_flag;
 				if (text && have_xa[i] && has[i][n_pri[i]]) { g[i].has_xa = true; g[i].xa = xa[i][n_pri[i]]; }
-				aa[i].push_back(g[i]);
+				aa[i][n_aa[i]++] = &g[i];
 			}
 		}
 		if (!text) return;
-		std::string str;
-		for (size_t i = 0; i < aa[0].size(); ++i) aln2sam_pub(opt, bns, str, &s[0], (int)aa[0].size(), aa[0].data(), (int)i, &h[1]);
+		static thread_local std::string str;   // keeps its capacity from pair to pair
+		str.clear();
+		for (int i = 0; i < n_aa[0]; ++i) aln2sam_pub(opt, bns, str, &s[0], n_aa[0], aa[0], i, &h[1]);
 		s[0].sam = sam_to_c(str);
 		str.clear();
-		for (size_t i = 0; i < aa[1].size(); ++i) aln2sam_pub(opt, bns, str, &s[1], (int)aa[1].size(), aa[1].data(), (int)i, &h[0]);
+		for (int i = 0; i < n_aa[1]; ++i) aln2sam_pub(opt, bns, str, &s[1], n_aa[1], aa[1], i, &h[0]);
 		s[1].sam = sam_to_c(str);
 		if (strcmp(s[0].name, s[1].name) != 0) die("paired reads have different names: \"%s\", \"%s\"", s[0].name, s[1].name);
 		return;

@@ -345,10 +345,12 @@ HAln reg2aln(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, int 
 		std::vector<uint8_t> query(l_query);
 		for (int i = 0; i < l_query; ++i) query[i] = query_[i] < 5 ? query_[i] : nt4_table[(uint8_t)query_[i]];
 		int i = 0;
+		std::vector<uint32_t> cg;
 		do {
 			w2 = w2 < opt->w << 2 ? w2 : opt->w << 2;
 			gen_cigar2(opt->mat, opt->o_del, opt->e_del, opt->o_ins, opt->e_ins, w2, bns->l_pac, pac, qe - qb, &query[qb], rb, re, &score,
-			           &a.cigar, &a.md, &NM);
+			           &cg, &a.md, &NM);
+			a.cigar.assign(cg.data(), cg.data() + cg.size());
 			if (score == last_sc || w2 == opt->w << 2) break;   // global and local scores may legitimately differ
 			last_sc = score;
 			w2 <<= 1;
@@ -360,12 +362,12 @@ HAln reg2aln(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, int 
 	if (!a.cigar.empty()) {   // squeeze out a leading or trailing deletion
 		if ((a.cigar[0] & 0xf) == 2) {
 			pos += a.cigar[0] >> 4;
-			a.cigar.erase(a.cigar.begin());
+			a.cigar.pop_front();
 		} else if ((a.cigar.back() & 0xf) == 2) a.cigar.pop_back();
 	}
 	if (qb != 0 || qe != l_query) {   // soft clips
 		int clip5 = is_rev ? l_query - qe : qb, clip3 = is_rev ? qb : l_query - qe;
-		if (clip5) a.cigar.insert(a.cigar.begin(), (uint32_t)clip5 << 4 | 3);
+		if (clip5) a.cigar.push_front((uint32_t)clip5 << 4 | 3);
 		if (clip3) a.cigar.push_back((uint32_t)clip3 << 4 | 3);
 	}
 	a.rid = bns_pos2rid(bns, pos);
@@ -379,7 +381,7 @@ HAln reg2aln(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, int 
 // ---------------------------------------------------------------------------
 // SAM text
 // ---------------------------------------------------------------------------
-static inline int get_rlen(const std::vector<uint32_t> &cigar)
+static inline int get_rlen(const CigarV &cigar)
 {
 	int l = 0;
 	for (uint32_t c : cigar)
@@ -387,10 +389,25 @@ static inline int get_rlen(const std::vector<uint32_t> &cigar)
 	return l;
 }
 
-static void add_cigar(const mem_opt_t *opt, const HAln *p, std::string &str, int which)
+// the fields of a record that mem_aln2sam adjusts on its private copies of the read's and the mate's alignment
+struct AlnView {
+	const HAln *a;
+	int64_t pos;
+	int rid, flag;
+	uint32_t is_rev, is_alt, mapq, NM;
+	int score, sub, alt_sc;
+	bool has_xa, no_cigar;
+	explicit AlnView(const HAln *h)
+	    : a(h), pos(h->pos), rid(h->rid), flag(h->flag), is_rev(h->is_rev), is_alt(h->is_alt), mapq(h->mapq), NM(h->NM), score(h->score),
+	      sub(h->sub), alt_sc(h->alt_sc), has_xa(h->has_xa), no_cigar(false) {}
+	int n_cigar() const { return no_cigar ? 0 : (int)a->cigar.size(); }
+	const CigarV &cigar() const { return a->cigar; }
+};
+
+static void add_cigar(const mem_opt_t *opt, const AlnView *p, std::string &str, int which)
 {
 	if (p->n_cigar()) {
-		for (uint32_t cg : p->cigar) {
+		for (uint32_t cg : p->cigar()) {
 			int c = cg & 0xf;
 			if (!(opt->flag & MEM_F_SOFTCLIP) && !p->is_alt && (c == 3 || c == 4)) c = which ? 4 : 3;   // hard clips on supplementary lines
 			put_int(str, cg >> 4);
@@ -399,17 +416,18 @@ static void add_cigar(const mem_opt_t *opt, const HAln *p, std::string &str, int
 	} else str.push_back('*');
 }
 
-static void aln2sam(const mem_opt_t *opt, const bntseq_t *bns, std::string &str, const bseq1_t *s, int n, const HAln *list, int which,
+static void aln2sam(const mem_opt_t *opt, const bntseq_t *bns, std::string &str, const bseq1_t *s, int n, const HAln *const *list, int which,
                     const HAln *m_)
 {
 	HProf hp_(HP_ALN2SAM);
-	HAln ptmp = list[which], *p = &ptmp, mtmp, *m = 0;
-	if (m_) { mtmp = *m_; m = &mtmp; }
+	AlnView ptmp(list[which]), *p = &ptmp;
+	HAln none;
+	AlnView mtmp(m_ ? m_ : &none), *m = m_ ? &mtmp : 0;
 	p->flag |= m ? 0x1 : 0;
 	p->flag |= p->rid < 0 ? 0x4 : 0;
 	p->flag |= m && m->rid < 0 ? 0x8 : 0;
-	if (p->rid < 0 && m && m->rid >= 0) { p->rid = m->rid; p->pos = m->pos; p->is_rev = m->is_rev; p->cigar.clear(); }   // unmapped read placed at its mate
-	if (m && m->rid < 0 && p->rid >= 0) { m->rid = p->rid; m->pos = p->pos; m->is_rev = p->is_rev; m->cigar.clear(); }
+	if (p->rid < 0 && m && m->rid >= 0) { p->rid = m->rid; p->pos = m->pos; p->is_rev = m->is_rev; p->no_cigar = true; }   // unmapped read placed at its mate
+	if (m && m->rid < 0 && p->rid >= 0) { m->rid = p->rid; m->pos = p->pos; m->is_rev = p->is_rev; m->no_cigar = true; }
 	p->flag |= p->is_rev ? 0x10 : 0;
 	p->flag |= m && m->is_rev ? 0x20 : 0;
 
@@ -429,8 +447,8 @@ static void aln2sam(const mem_opt_t *opt, const bntseq_t *bns, std::string &str,
 		str.push_back('\t');
 		put_int(str, m->pos + 1); str.push_back('\t');
 		if (p->rid == m->rid) {
-			int64_t p0 = p->pos + (p->is_rev ? get_rlen(p->cigar) - 1 : 0);
-			int64_t p1 = m->pos + (m->is_rev ? get_rlen(m->cigar) - 1 : 0);
+			int64_t p0 = p->pos + (p->is_rev ? (p->no_cigar ? 0 : get_rlen(p->cigar())) - 1 : 0);
+			int64_t p1 = m->pos + (m->is_rev ? (m->no_cigar ? 0 : get_rlen(m->cigar())) - 1 : 0);
 			if (m->n_cigar() == 0 || p->n_cigar() == 0) str.push_back('0');
 			else put_int(str, -(p0 - p1 + (p0 > p1 ? 1 : p0 < p1 ? -1 : 0)));
 		} else str.push_back('0');
@@ -443,28 +461,35 @@ static void aln2sam(const mem_opt_t *opt, const bntseq_t *bns, std::string &str,
 		bool trim = p->n_cigar() && which && !(opt->flag & MEM_F_SOFTCLIP) && !p->is_alt;
 		if (!p->is_rev) {
 			if (trim) {
-				if ((p->cigar[0] & 0xf) == 4 || (p->cigar[0] & 0xf) == 3) qb += p->cigar[0] >> 4;
-				if ((p->cigar.back() & 0xf) == 4 || (p->cigar.back() & 0xf) == 3) qe -= p->cigar.back() >> 4;
+				if ((p->cigar()[0] & 0xf) == 4 || (p->cigar()[0] & 0xf) == 3) qb += p->cigar()[0] >> 4;
+				if ((p->cigar().back() & 0xf) == 4 || (p->cigar().back() & 0xf) == 3) qe -= p->cigar().back() >> 4;
 			}
-			for (int i = qb; i < qe; ++i) str.push_back("ACGTN"[(int)s->seq[i]]);
+			size_t at = str.size();
+			str.resize(at + (qe - qb));
+			for (int i = qb; i < qe; ++i) str[at++] = "ACGTN"[(int)s->seq[i]];
 			str.push_back('\t');
-			if (s->qual) for (int i = qb; i < qe; ++i) str.push_back(s->qual[i]);
+			if (s->qual) str.append(s->qual + qb, qe - qb);
 			else str.push_back('*');
 		} else {
 			if (trim) {
-				if ((p->cigar[0] & 0xf) == 4 || (p->cigar[0] & 0xf) == 3) qe -= p->cigar[0] >> 4;
-				if ((p->cigar.back() & 0xf) == 4 || (p->cigar.back() & 0xf) == 3) qb += p->cigar.back() >> 4;
+				if ((p->cigar()[0] & 0xf) == 4 || (p->cigar()[0] & 0xf) == 3) qe -= p->cigar()[0] >> 4;
+				if ((p->cigar().back() & 0xf) == 4 || (p->cigar().back() & 0xf) == 3) qb += p->cigar().back() >> 4;
 			}
-			for (int i = qe - 1; i >= qb; --i) str.push_back("TGCAN"[(int)s->seq[i]]);
+			size_t at = str.size();
+			str.resize(at + (qe - qb));
+			for (int i = qe - 1; i >= qb; --i) str[at++] = "TGCAN"[(int)s->seq[i]];
 			str.push_back('\t');
-			if (s->qual) for (int i = qe - 1; i >= qb; --i) str.push_back(s->qual[i]);
-			else str.push_back('*');
+			if (s->qual) {
+				at = str.size();
+				str.resize(at + (qe - qb));
+				for (int i = qe - 1; i >= qb; --i) str[at++] = s->qual[i];
+			} else str.push_back('*');
 		}
 	}
 
 	if (p->n_cigar()) {
 		str += "\tNM:i:"; put_int(str, p->NM);
-		str += "\tMD:Z:"; str += p->md;
+		str += "\tMD:Z:"; str += p->a->md;
 	}
 	if (m && m->n_cigar()) { str += "\tMC:Z:"; add_cigar(opt, m, str, which); }
 	if (p->score >= 0) { str += "\tAS:i:"; put_int(str, p->score); }
@@ -473,11 +498,11 @@ static void aln2sam(const mem_opt_t *opt, const bntseq_t *bns, std::string &str,
 	if (!(p->flag & 0x100)) {
 		int i;
 		for (i = 0; i < n; ++i)
-			if (i != which && !(list[i].flag & 0x100)) break;
+			if (i != which && !(list[i]->flag & 0x100)) break;
 		if (i < n) {   // other non-secondary lines of this read: SA tag
 			str += "\tSA:Z:";
 			for (i = 0; i < n; ++i) {
-				const HAln *r = &list[i];
+				const HAln *r = list[i];
 				if (i == which || (r->flag & 0x100)) continue;
 				str += bns->anns[r->rid].name; str.push_back(',');
 				put_int(str, r->pos + 1); str.push_back(',');
@@ -494,7 +519,7 @@ static void aln2sam(const mem_opt_t *opt, const bntseq_t *bns, std::string &str,
 			str += buf;
 		}
 	}
-	if (p->has_xa) { str += "\tXA:Z:"; str += p->xa; }
+	if (p->has_xa) { str += "\tXA:Z:"; str += p->a->xa; }
 	if (s->comment) { str.push_back('\t'); str += s->comment; }
 	if ((opt->flag & MEM_F_REF_HDR) && p->rid >= 0 && bns->anns[p->rid].anno != 0 && bns->anns[p->rid].anno[0] != 0) {
 		str += "\tXR:Z:";
@@ -506,7 +531,7 @@ static void aln2sam(const mem_opt_t *opt, const bntseq_t *bns, std::string &str,
 	str.push_back('\n');
 }
 
-void aln2sam_pub(const mem_opt_t *opt, const bntseq_t *bns, std::string &str, const bseq1_t *s, int n, const HAln *list, int which,
+void aln2sam_pub(const mem_opt_t *opt, const bntseq_t *bns, std::string &str, const bseq1_t *s, int n, const HAln *const *list, int which,
                  const HAln *m)
 {
 	aln2sam(opt, bns, str, s, n, list, which, m);
@@ -518,16 +543,19 @@ bool gen_alt(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, cons
 {
 	HProf hp_(HP_GENALT);
 	int n = (int)a.size(), tot = 0;
-	std::vector<int> cnt(n, 0);
-	std::vector<char> has_alt(n, 0);
-	xa.assign(n, std::string());
-	has.assign(n, 0);
 	const double ratio = opt->XA_drop_ratio;
 	auto pri_idx = [&](int i) {
 		int k = a[i].secondary_all;
 		if (k >= 0 && a[i].score >= a[k].score * ratio) return k;
 		return -1;
 	};
+	bool any = false;
+	for (int i = 0; i < n && !any; ++i) any = pri_idx(i) >= 0;
+	if (!any) return false;   // the usual case: no secondary hit close enough to its primary
+	std::vector<int> cnt(n, 0);
+	std::vector<char> has_alt(n, 0);
+	xa.assign(n, std::string());
+	has.assign(n, 0);
 	for (int i = 0; i < n; ++i) {
 		int r = pri_idx(i);
 		if (r >= 0) {
@@ -573,7 +601,8 @@ void reg2sam(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, bseq
 	bool have_xa = false;
 	if (!(opt->flag & MEM_F_ALL)) have_xa = gen_alt(opt, bns, pac, a, s->l_seq, s->seq, xa, has, ctx, read_idx);
 	std::vector<HAln> aa;
-	std::string str;
+	static thread_local std::string str;   // keeps its capacity from read to read
+	str.clear();
 	int l = 0;
 	for (size_t k = 0; k < a.size(); ++k) {
 		HReg *p = &a[k];
@@ -593,9 +622,15 @@ void reg2sam(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, bseq
 	if (aa.empty()) {
 		HAln t = reg2aln(opt, bns, pac, s->l_seq, s->seq, 0);
 		t.flag |= extra_flag;
-		aln2sam(opt, bns, str, s, 1, &t, 0, m);
+		const HAln *one = &t;
+		aln2sam(opt, bns, str, s, 1, &one, 0, m);
 	} else {
-		for (size_t k = 0; k < aa.size(); ++k) aln2sam(opt, bns, str, s, (int)aa.size(), aa.data(), (int)k, m);
+		const HAln *small[8];
+		std::vector<const HAln *> big;
+		const HAln **list = small;
+		if (aa.size() > 8) { big.resize(aa.size()); list = big.data(); }
+		for (size_t k = 0; k < aa.size(); ++k) list[k] = &aa[k];
+		for (size_t k = 0; k < aa.size(); ++k) aln2sam(opt, bns, str, s, (int)aa.size(), list, (int)k, m);
 	}
 	s->sam = to_c(str);
 }

@@ -113,11 +113,24 @@ static void parallel_blocks(int n_threads, int n, int chunk, F f)
 	for (auto &t : th) t.join();
 }
 
-static std::mutex g_smem_turn, g_c2a_turn;
+static std::mutex g_smem_turn, g_c2a_turn, g_host_turn;
+static bool g_host_turns = false;
 
 static double now_ms()
 {
 	return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static double sys_sec()
+{
+	struct rusage r;
+	getrusage(RUSAGE_SELF, &r);
+	return r.ru_stime.tv_sec + 1e-6 * r.ru_stime.tv_usec;
+}
+static long page_faults()
+{
+	struct rusage r;
+	getrusage(RUSAGE_SELF, &r);
+	return r.ru_minflt;
 }
 static double cpu_sec()
 {
@@ -157,13 +170,14 @@ struct PinBuf {
 };
 
 struct Workspace {
-	HostBuf reg_arena;
-	PinBuf h_flat, h_sa, h_qbl, h_chains, h_seeds, h_srt, h_regs, h_nregs, h_mreq[2], h_mres[2];
+	PinBuf h_flat, h_sa, h_qbl, h_chains, h_seeds, h_srt, h_regs, h_nregs, h_mreq[2], h_mres[2], h_ahdr[2], h_apool[2];
 	DevBuf mreq[2], mres[2], mrows[2];
 	DevBuf seq, off, len, intv, nintv, cnt, scratch, nseeds, lrep, seed_off, rows, qbl, sa;
 	DevBuf chain_off, chains, seeds, srt, reg_off, regs, nregs, tab, areq, ahdr, apool, agap, acnt, areq2, ahdr2, apool2, acnt2;
 };
-static Workspace g_ws[2];   // one per concurrent sub-batch
+static const int MAX_LANES = 4;
+static Workspace g_ws[MAX_LANES];   // one per concurrent sub-batch
+static HostBuf g_reg_arena[16];      // one per sub-batch: the regions live until the SAM stage
 static Workspace g_gws;     // batch-wide buffers (packed reads, CIGAR requests)
 static const void *g_host_bwt = nullptr;
 
@@ -200,7 +214,7 @@ extern "C" char *mi355x_collect_sam(bseq1_t *seqs, int n, size_t *total_len)
 extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const bntseq_t *bns, const uint8_t *pac,
                                  int64_t n_processed, int n, bseq1_t *seqs, const mem_pestat_t *pes0)
 {
-	const double t_begin = now_ms(), c_begin = cpu_sec();
+	const double t_begin = now_ms(), c_begin = cpu_sec(), s_begin = sys_sec();
 	DevIndex &ix = dev_index();
 	if (!ix.ready || g_host_bwt != (const void *)bwt->bwt) {
 		// first call with this index: make it resident (one rank per GPU; LOCAL_RANK as set by torchrun / mpirun wrappers)
@@ -243,6 +257,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	});
 	if ((size_t)max_len + 2 > 9000) die("read of %d bp exceeds the on-chip band buffers of this build (max 8998 bp)", max_len);
 	double t1 = now_ms();
+	const double c1 = cpu_sec();
 	uint8_t *d_seq = (uint8_t *)W.seq.ensure(flat_bytes);
 	int64_t *d_off = (int64_t *)W.off.ensure((size_t)(n + 1) * 8);
 	int *d_len = (int *)W.len.ensure((size_t)n * 4);
@@ -257,7 +272,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	// threads with their own HIP stream and workspace: the GPU work of one overlaps the host work of the other.
 	std::vector<HRegV> regs(n);
 	struct P1 { double k_smem = 0, k_sa = 0, k_ext = 0, smem = 0, sa = 0, chain = 0, ext = 0, regs = 0; uint64_t smem_bytes = 0, sa_bytes = 0, cells = 0, n_ext = 0, n_intv = 0, n_seeds = 0, n_chains = 0; };
-	auto phase1 = [&](int lo, int hi, Workspace &W, hipStream_t st, int n_thr, P1 &ps) {
+	auto phase1 = [&](int lo, int hi, Workspace &W, HostBuf &reg_arena, hipStream_t st, int n_thr, P1 &ps) {
 		const int n = hi - lo;
 		bseq1_t *seqs_r = seqs + lo;
 		const int64_t *d_off_r = d_off + lo;
@@ -335,6 +350,9 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			ps.k_sa = ev_sa.ms();
 			ps.sa_bytes = ix.fm.sa_full ? (uint64_t)S * 16 : cnt[1] * 64 + (uint64_t)S * 8;
 		}
+		// host stages also take turns (when enabled): each one then runs on all host threads instead of a share of them
+		std::unique_lock<std::mutex> host_turn(g_host_turn, std::defer_lock);
+		if (g_host_turns) host_turn.lock();
 		double t3 = now_ms();
 
 		// chaining and chain filters (host).  Each block of reads is chained by one thread with recycled scratch and packed
@@ -419,6 +437,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			BlockOut().ch.swap(o.ch); std::vector<DevSeed>().swap(o.sd); std::vector<unsigned int>().swap(o.srt);
 		});
 		double t4 = now_ms();
+		if (g_host_turns) host_turn.unlock();
 
 		// chain -> regions on the GPU
 		DevReg *hregs = (DevReg *)W.h_regs.ensure((size_t)NS * sizeof(DevReg) + 8);
@@ -467,6 +486,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			ps.k_ext = ev_ext.ms();
 			ps.cells = cnt[0]; ps.n_ext = cnt[1];
 		}
+		if (g_host_turns) host_turn.lock();
 		double t5 = now_ms();
 
 		// region post-processing (host); every read gets a slice of the batch-wide arena: its regions + room for rescued mates
@@ -474,7 +494,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		std::vector<int64_t> slice(n + 1);
 		slice[0] = 0;
 		for (int i = 0; i < n; ++i) slice[i + 1] = slice[i] + nregs[i] + SLACK;
-		HReg *arena = (HReg *)W.reg_arena.ensure((size_t)slice[n] * sizeof(HReg));
+		HReg *arena = (HReg *)reg_arena.ensure((size_t)slice[n] * sizeof(HReg));
 		parallel_for(n_thr, n, 256, [&](int i) {
 			HRegV &v = regs[lo + i];
 			int m = nregs[i];
@@ -494,35 +514,52 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		ps.smem = t2 - t1; ps.sa = t3 - t2; ps.chain = t4 - t3; ps.ext = t5 - t4; ps.regs = t6 - t5;
 	};
 
-	int n_sub = 2;
+	// K sub-batches are worked off by up to two host threads ("lanes"), each with its own HIP stream and workspace
+	int n_sub = 2, n_lanes = 2;
 	if (const char *e = getenv("MPIBWA_SUBBATCH")) n_sub = atoi(e);
-	if (n_sub < 1) n_sub = 1;
-	if (n_sub > 2) n_sub = 2;
+	if (const char *e = getenv("MPIBWA_LANES")) n_lanes = atoi(e);
+	n_sub = std::max(1, std::min(n_sub, 16));
+	n_lanes = std::max(1, std::min(n_lanes, std::min(n_sub, MAX_LANES)));
 	int min_sub = 40000;   // below this a chunk is not worth splitting
 	if (const char *e = getenv("MPIBWA_SUBBATCH_MIN")) min_sub = atoi(e);
-	if (n < min_sub) n_sub = 1;
-	P1 ps[2];
-	if (n_sub == 1) phase1(0, n, g_ws[0], st, n_thr, ps[0]);
+	if (n < min_sub) n_sub = n_lanes = 1;
+	std::vector<P1> ps(n_sub);
+	if (n_sub == 1) phase1(0, n, g_ws[0], g_reg_arena[0], st, n_thr, ps[0]);
 	else {
-		static hipStream_t s_streams[2] = {nullptr, nullptr};
-		if (!s_streams[0]) { HIP_OK(hipStreamCreateWithFlags(&s_streams[0], hipStreamNonBlocking)); HIP_OK(hipStreamCreateWithFlags(&s_streams[1], hipStreamNonBlocking)); }
-		int mid = (n / 2) & ~1;   // keep mates together
-		const int thr_each = std::max(1, (n_thr + 1) / 2);
-		std::thread other([&]() { phase1(mid, n, g_ws[1], s_streams[1], thr_each, ps[1]); });
-		phase1(0, mid, g_ws[0], s_streams[0], thr_each, ps[0]);
-		other.join();
+		static hipStream_t s_streams[MAX_LANES] = {nullptr};
+		for (int l = 0; l < n_lanes; ++l)
+			if (!s_streams[l]) HIP_OK(hipStreamCreateWithFlags(&s_streams[l], hipStreamNonBlocking));
+		std::vector<int> cut(n_sub + 1);
+		for (int k = 0; k <= n_sub; ++k) cut[k] = (int)((int64_t)n * k / n_sub) & ~1;   // keep mates together
+		cut[n_sub] = n;
+		g_host_turns = getenv("MPIBWA_HOST_TURNS") != nullptr;
+		int thr_each = g_host_turns ? n_thr : std::max(1, (n_thr + n_lanes - 1) / n_lanes);
+		if (const char *e = getenv("MPIBWA_P1_THREADS")) thr_each = std::max(1, atoi(e));
+		std::atomic<int> next(0);
+		auto lane = [&](int l) {
+			for (;;) {
+				int k = next.fetch_add(1);
+				if (k >= n_sub) break;
+				phase1(cut[k], cut[k + 1], g_ws[l], g_reg_arena[k], s_streams[l], thr_each, ps[k]);
+			}
+		};
+		std::vector<std::thread> th;
+		for (int l = 1; l < n_lanes; ++l) th.emplace_back(lane, l);
+		lane(0);
+		for (auto &t : th) t.join();
 	}
 	for (int k = 0; k < n_sub; ++k) {
 		g_stats.k_smem_ms += ps[k].k_smem; g_stats.k_sa_ms += ps[k].k_sa; g_stats.k_ext_ms += ps[k].k_ext;
 		g_stats.smem_bytes += ps[k].smem_bytes; g_stats.sa_bytes += ps[k].sa_bytes; g_stats.ext_cells += ps[k].cells; g_stats.n_ext += ps[k].n_ext;
 		g_stats.n_intv += ps[k].n_intv; g_stats.n_seeds += ps[k].n_seeds; g_stats.n_chains += ps[k].n_chains;
-		// per-stage wall times of the sub-batches overlap in time: report the longest of each
-		g_stats.smem_ms = std::max(g_stats.smem_ms, ps[k].smem); g_stats.sa_ms = std::max(g_stats.sa_ms, ps[k].sa);
-		g_stats.chain_ms = std::max(g_stats.chain_ms, ps[k].chain); g_stats.ext_ms = std::max(g_stats.ext_ms, ps[k].ext);
-		g_stats.regs_ms = std::max(g_stats.regs_ms, ps[k].regs);
+		// per-stage wall times: the sub-batches of a lane run back to back and the lanes side by side, so sum / lanes
+		g_stats.smem_ms += ps[k].smem / n_lanes; g_stats.sa_ms += ps[k].sa / n_lanes;
+		g_stats.chain_ms += ps[k].chain / n_lanes; g_stats.ext_ms += ps[k].ext / n_lanes;
+		g_stats.regs_ms += ps[k].regs / n_lanes;
 	}
 	double t6 = now_ms();
 	g_stats.phase1_ms = t6 - t1;
+	const double c6 = cpu_sec();
 
 	// ---- 7. insert-size statistics over the whole batch ----
 	mem_pestat_t pes[4];
@@ -544,8 +581,9 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		int lo = 0, hi = 0;
 		std::vector<AlnReqH> req;
 		std::vector<uint32_t> base;       // first request of every unit of the part
-		std::vector<AlnHdrH> hdr;
-		std::vector<uint8_t> pool;
+		AlnHdrH *hdr = nullptr;           // results, in page-locked staging buffers
+		uint8_t *pool = nullptr;
+		int slot = 0;
 		unsigned long long cnt[8] = {0};
 		// mate-rescue alignments of the part: requests of unit k are mreq[mbase[k] .. mbase[k+1])
 		MswReqH *mreq = nullptr; MswResH *mres = nullptr;
@@ -578,9 +616,12 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	const bool gpu_msw = pe && !(opt->flag & MEM_F_NO_RESCUE) && getenv("MPIBWA_HOST_MATESW") == nullptr && (int64_t)max_len * opt->a < 8192 &&
 	                     msw_lds_bytes(max_len) <= 160 * 1024;
 	double msw_ms = 0;
+	double cpu_msw = 0, cpu_collect = 0, cpu_emit = 0, sys_emit = 0;
+	long pf_emit = 0;
 	auto mcollect = [&](Part &P, int slot) {
 		if (!gpu_msw) return;
 		double ta = now_ms();
+		const double ca = cpu_sec();
 		const int nu = P.hi - P.lo, n_blk = (nu + 255) / 256;
 		std::vector<std::vector<MswReqH>> blk_req(n_blk);
 		std::vector<uint32_t> u_first(nu), u_cnt(nu);
@@ -603,6 +644,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			if (u_cnt[i]) memcpy(&P.mreq[P.mbase[i]], &blk_req[i >> 8][u_first[i]], (size_t)u_cnt[i] * sizeof(MswReqH));
 		});
 		msw_ms += now_ms() - ta;
+		cpu_msw += cpu_sec() - ca;
 	};
 	auto mlaunch = [&](Part &P, int slot) {   // asynchronous
 		if (!gpu_msw || P.n_mreq == 0) return;
@@ -638,6 +680,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 
 	auto collect = [&](Part &P) {   // A
 		double ta = now_ms();
+		const double ca = cpu_sec();
 		const int nu = P.hi - P.lo, n_blk = (nu + 255) / 256;
 		std::vector<std::vector<AlnReqH>> blk_req(n_blk);
 		std::vector<uint32_t> u_first(nu), u_cnt(nu);
@@ -670,10 +713,11 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			if (u_cnt[i]) memcpy(&P.req[P.base[i]], &blk_req[i >> 8][u_first[i]], (size_t)u_cnt[i] * sizeof(AlnReqH));
 		});
 		plan_ms += now_ms() - ta;
+		cpu_collect += cpu_sec() - ca;
 	};
 	auto launch = [&](Part &P, int slot) {   // B (asynchronous)
 		const size_t n_req = P.req.size();
-		P.hdr.resize(n_req);
+		P.slot = slot;
 		if (!gpu_aln || n_req == 0) return;
 		static_assert(sizeof(AlnReq) == sizeof(AlnReqH) && sizeof(AlnHdr) == sizeof(AlnHdrH), "host/device record layouts differ");
 		P.st = a_streams[slot];
@@ -701,30 +745,38 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		HIP_OK(hipStreamSynchronize(P.st));
 		HIP_OK(hipGetLastError());
 		HIP_OK(hipMemcpy(P.cnt, P.d_cnt, 64, hipMemcpyDeviceToHost));
-		HIP_OK(hipMemcpy(P.hdr.data(), P.d_hdr, n_req * sizeof(AlnHdr), hipMemcpyDeviceToHost));
 		g_stats.k_aln_ms += P.ev.ms();
 		size_t used = std::min<size_t>(P.cnt[0], P.pool_bytes);
-		P.pool.resize(used + 16);
-		if (used) HIP_OK(hipMemcpy(P.pool.data(), P.d_pool, used, hipMemcpyDeviceToHost));
+		P.hdr = (AlnHdrH *)W.h_ahdr[P.slot].ensure(n_req * sizeof(AlnHdr) + 64);
+		P.pool = (uint8_t *)W.h_apool[P.slot].ensure(used + 64);
+		HIP_OK(hipMemcpyAsync(P.hdr, P.d_hdr, n_req * sizeof(AlnHdr), hipMemcpyDeviceToHost, P.st));
+		if (used) HIP_OK(hipMemcpyAsync(P.pool, P.d_pool, used, hipMemcpyDeviceToHost, P.st));
+		HIP_OK(hipStreamSynchronize(P.st));
 		g_stats.n_aln += n_req;
 		aln_wait_ms += now_ms() - ta;
 	};
+	double emit_ms = 0;
 	auto replay = [&](Part &P) {   // C
+		const double ta = now_ms(), ca = cpu_sec(), sa_ = sys_sec();
+		const long pf = page_faults();
 		if (pe) {
 			parallel_for(n_thr, P.hi - P.lo, 128, [&](int k) {
 				const int i = P.lo + k;
 				AlnCtx ctx;
-				if (gpu_aln) { ctx.mode = AlnCtx::REPLAY; ctx.hdr = P.hdr.data(); ctx.pool = P.pool.data(); ctx.cursor = P.base[k]; }
+				if (gpu_aln) { ctx.mode = AlnCtx::REPLAY; ctx.hdr = P.hdr; ctx.pool = P.pool; ctx.cursor = P.base[k]; }
 				sam_pe_emit(opt, bns, pac, pes, &seqs[i << 1], &regs[i << 1], plans[i], gpu_aln ? &ctx : nullptr, i << 1);
 			});
 		} else {
 			parallel_for(n_thr, P.hi - P.lo, 256, [&](int k) {
 				const int i = P.lo + k;
 				AlnCtx ctx;
-				if (gpu_aln) { ctx.mode = AlnCtx::REPLAY; ctx.hdr = P.hdr.data(); ctx.pool = P.pool.data(); ctx.cursor = P.base[k]; }
+				if (gpu_aln) { ctx.mode = AlnCtx::REPLAY; ctx.hdr = P.hdr; ctx.pool = P.pool; ctx.cursor = P.base[k]; }
 				reg2sam(opt, bns, pac, &seqs[i], regs[i], 0, 0, gpu_aln ? &ctx : nullptr, i);
 			});
 		}
+		emit_ms += now_ms() - ta;
+		cpu_emit += cpu_sec() - ca;
+		sys_emit += sys_sec() - sa_; pf_emit += page_faults() - pf;
 	};
 	if (n_parts == 1) {
 		parts[0].lo = 0; parts[0].hi = n_units;
@@ -739,9 +791,13 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		finish(parts[0]); replay(parts[0]);
 		finish(parts[1]); replay(parts[1]);
 	}
-	g_stats.plan_ms = plan_ms; g_stats.aln_ms = aln_wait_ms; g_stats.msw_ms = msw_ms;
+	g_stats.plan_ms = plan_ms; g_stats.aln_ms = aln_wait_ms; g_stats.msw_ms = msw_ms; g_stats.emit_ms = emit_ms;
 	double t8 = now_ms();
 	hprof_report("sam stage");
+	static const bool s_cpusec = getenv("MPIBWA_CPUSEC") != nullptr;
+	if (g_hprof_on || s_cpusec)
+		fprintf(stderr, "[cpu-sec] encode+h2d %.3f  phase1 %.3f  pestat+sam %.3f (msw-collect %.3f, plan+collect %.3f, emit %.3f [sys %.3f, %ld page faults])  total %.3f  sys %.3f  wall %.3f\n",
+		        c1 - c_begin, c6 - c1, cpu_sec() - c6, cpu_msw, cpu_collect, cpu_emit, sys_emit, pf_emit, cpu_sec() - c_begin, sys_sec() - s_begin, (t8 - t_begin) * 1e-3);
 	// release the per-read containers in parallel (millions of small blocks: serial destruction costs ~0.2 s per chunk)
 	parallel_for(n_thr, n, 8192, [&](int i) { HRegV().swap(regs[i]); });   // only reads that outgrew their arena slice own memory
 	g_stats.n_reads = n;
