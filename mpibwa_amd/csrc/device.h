@@ -79,6 +79,7 @@ struct DevChain {
 	int32_t seed_beg, n_seeds;   // into the flat seed / order arrays
 	int32_t rid;
 	float frac_rep;
+	int64_t rmax0, rmax1;        // the reference window of mem_chain2aln (src/bwamem.c:642-661), already clamped
 };
 struct DevReg {                  // the fields of mem_alnreg_t that mem_chain2aln fills (src/bwamem.c:708-783)
 	int64_t rb, re;
@@ -94,6 +95,13 @@ void launch_c2a(void *stream, const C2aParams &P, const ExtParams &ep, int n_rea
                 const int *d_len, const int *d_chain_off, const DevChain *d_chains, const DevSeed *d_seeds, unsigned int *d_srt, const int *d_reg_off,
                 DevReg *d_regs, int *d_nregs, const int *d_tab, int tab_stride, const uint8_t *d_pac, unsigned long long *d_counters,
                 int max_len);
+
+// lane-per-read variant (c2a_lane.hip), same contract; needs counters[2] = 0 (next read) and scores below 2^13
+bool c2a_lane_fits(int max_len, int a);
+void launch_c2a_lane(void *stream, const C2aParams &P, const ExtParams &ep, int n_reads, const uint8_t *d_seq, const int64_t *d_off,
+                     const int *d_len, const int *d_chain_off, const DevChain *d_chains, const DevSeed *d_seeds, unsigned int *d_srt,
+                     const int *d_reg_off, DevReg *d_regs, int *d_nregs, const int *d_tab, int tab_stride, const uint8_t *d_pac,
+                     unsigned long long *d_counters, int max_len);
 
 // ---- final global re-alignment on the device (aln_kernel.hip) ----
 struct AlnReq {                  // one call of mem_reg2aln's DP loop (src/bwamem.c:1106-1122)

@@ -357,6 +357,8 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 
 		// chaining and chain filters (host).  Each block of reads is chained by one thread with recycled scratch and packed
 		// straight into the device layout (block-local offsets); the blocks are then concatenated after a prefix sum.
+		std::vector<int> gap_h(max_len + 2);
+		for (int l = 0; l < max_len + 2; ++l) gap_h[l] = cal_max_gap(opt, l);
 		const int CB = 256, n_cb = (n + CB - 1) / CB;
 		struct BlockOut { std::vector<DevChain> ch; std::vector<DevSeed> sd; std::vector<unsigned int> srt; };
 		std::vector<BlockOut> bo(n_cb);
@@ -401,17 +403,37 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 							if (is_rev) { int64_t t = fb; fb = (bns->l_pac << 1) - fe; fe = (bns->l_pac << 1) - t; }
 							d.far_beg = fb; d.far_end = fe;
 						}
-						o.ch.push_back(d);
-						// seeds are visited by decreasing score, ties by decreasing index (src/bwamem.c:662-667)
+						// Seeds are stored in the order of the reference's sort by (score, index) (src/bwamem.c:662-667) — keys are
+						// distinct, so any sort gives that order — and visited from the last one down; the order array the
+						// kernels use for their "seed skipped" marks therefore starts as the identity.
 						key.resize(cs);
+						for (int k = 0; k < cs; ++k) key[k] = (uint64_t)ch.seeds[k].score << 32 | (uint32_t)k;
+						if (cs > 1) std::sort(key.begin(), key.end());
+						int64_t lo = bns->l_pac << 1, hi = 0;
 						for (int k = 0; k < cs; ++k) {
+							const HSeed &t = ch.seeds[(uint32_t)key[k]];
 							DevSeed ds;
-							ds.rbeg = ch.seeds[k].rbeg; ds.qbeg = ch.seeds[k].qbeg; ds.len = ch.seeds[k].len;
+							ds.rbeg = t.rbeg; ds.qbeg = t.qbeg; ds.len = t.len;
 							o.sd.push_back(ds);
-							key[k] = (uint64_t)ch.seeds[k].score << 32 | (uint32_t)k;
+							o.srt.push_back((unsigned int)k);
+							// widest reference span any seed of the chain could reach (src/bwamem.c:642-658)
+							const int64_t b = t.rbeg - (t.qbeg + gap_h[t.qbeg]);
+							const int tail = seqs_r[i].l_seq - t.qbeg - t.len;
+							const int64_t e = t.rbeg + t.len + (tail + gap_h[tail]);
+							lo = b < lo ? b : lo;
+							hi = e > hi ? e : hi;
 						}
-						if (cs > 1) std::sort(key.begin(), key.end());   // keys are distinct, any sort gives the reference's order
-						for (int k = 0; k < cs; ++k) o.srt.push_back((unsigned int)key[k]);
+						d.rmax0 = lo > 0 ? lo : 0;
+						d.rmax1 = hi < bns->l_pac << 1 ? hi : bns->l_pac << 1;
+						if (cs) {
+							if (d.rmax0 < bns->l_pac && bns->l_pac < d.rmax1) {   // never cross the strand boundary
+								if (ch.seeds[0].rbeg < bns->l_pac) d.rmax1 = bns->l_pac;
+								else d.rmax0 = bns->l_pac;
+							}
+							d.rmax0 = d.rmax0 > d.far_beg ? d.rmax0 : d.far_beg;   // bns_fetch_seq clamps to the contig
+							d.rmax1 = d.rmax1 < d.far_end ? d.rmax1 : d.far_end;
+						}
+						o.ch.push_back(d);
 						tot += cs;
 					}
 					chain_off[i + 1] = (int)chains.size();
@@ -474,8 +496,14 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			ep.o_del = opt->o_del; ep.e_del = opt->e_del; ep.o_ins = opt->o_ins; ep.e_ins = opt->e_ins; ep.zdrop = opt->zdrop;
 			std::unique_lock<std::mutex> turn(g_c2a_turn);
 			ev_ext.start(st);
-			launch_c2a(st, cp, ep, n, d_seq, d_off_r, d_len_r, d_chain_off, d_chains, d_seeds, d_srt, d_reg_off, d_regs, d_nregs, d_tab, TS,
-			           (const uint8_t *)ix.d_pac, d_cnt, max_len);
+			const char *c2a_env = getenv("MPIBWA_C2A");
+			const bool lane_c2a = c2a_env && !strcmp(c2a_env, "lane");   // experimental mapping, slower so far
+			if (lane_c2a && c2a_lane_fits(max_len, opt->a))      // one lane per read
+				launch_c2a_lane(st, cp, ep, n, d_seq, d_off_r, d_len_r, d_chain_off, d_chains, d_seeds, d_srt, d_reg_off, d_regs, d_nregs, d_tab, TS,
+				                (const uint8_t *)ix.d_pac, d_cnt, max_len);
+			else                                                 // one wavefront per read (any read length)
+				launch_c2a(st, cp, ep, n, d_seq, d_off_r, d_len_r, d_chain_off, d_chains, d_seeds, d_srt, d_reg_off, d_regs, d_nregs, d_tab, TS,
+				           (const uint8_t *)ix.d_pac, d_cnt, max_len);
 			ev_ext.stop(st);
 			HIP_OK(hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, st));
 			HIP_OK(hipMemcpyAsync(hregs, d_regs, (size_t)NS * sizeof(DevReg), hipMemcpyDeviceToHost, st));
@@ -515,7 +543,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	};
 
 	// K sub-batches are worked off by up to two host threads ("lanes"), each with its own HIP stream and workspace
-	int n_sub = 2, n_lanes = 2;
+	int n_sub = 3, n_lanes = 3;
 	if (const char *e = getenv("MPIBWA_SUBBATCH")) n_sub = atoi(e);
 	if (const char *e = getenv("MPIBWA_LANES")) n_lanes = atoi(e);
 	n_sub = std::max(1, std::min(n_sub, 16));
@@ -533,7 +561,8 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		for (int k = 0; k <= n_sub; ++k) cut[k] = (int)((int64_t)n * k / n_sub) & ~1;   // keep mates together
 		cut[n_sub] = n;
 		g_host_turns = getenv("MPIBWA_HOST_TURNS") != nullptr;
-		int thr_each = g_host_turns ? n_thr : std::max(1, (n_thr + n_lanes - 1) / n_lanes);
+		// every lane may use all host threads: while one lane waits for a kernel the other one gets the whole CPU share
+		int thr_each = n_thr;
 		if (const char *e = getenv("MPIBWA_P1_THREADS")) thr_each = std::max(1, atoi(e));
 		std::atomic<int> next(0);
 		auto lane = [&](int l) {

@@ -164,6 +164,9 @@ def test_overlapped_sub_batches_and_host_cigar_paths(both, reads_pe, monkeypatch
     assert eng.process(eng.opt(flag=abi.MEM_F_PE), ra) == want
     monkeypatch.setenv("MPIBWA_SMEM", "lane")
     assert eng.process(eng.opt(flag=abi.MEM_F_PE), ra) == want
+    monkeypatch.setenv("MPIBWA_C2A", "lane")        # chain -> region kernel: the experimental one-lane-per-read mapping
+    assert eng.process(eng.opt(flag=abi.MEM_F_PE), ra) == want
+    monkeypatch.delenv("MPIBWA_C2A")
     monkeypatch.setenv("MPIBWA_HOST_MATESW", "1")   # mate rescue computed by the host's striped SW instead of msw_kernel
     assert eng.process(eng.opt(flag=abi.MEM_F_PE), ra) == want
     assert eng.stats()["n_msw"] == 0
