@@ -40,7 +40,8 @@ def main():
     ap.add_argument("--genome-mbp", type=float, default=float(os.environ.get("MPIBWA_BENCH_GENOME_MBP", "3100")))
     ap.add_argument("--pairs", type=int, default=int(os.environ.get("MPIBWA_BENCH_PAIRS", "333334")),
                     help="read pairs per step per GPU (mpiBWA -K 100000000 closes a chunk at 10^8 bases)")
-    ap.add_argument("--cpu-sample-pairs", type=int, default=int(os.environ.get("MPIBWA_BENCH_CPU_PAIRS", "60000")))
+    ap.add_argument("--cpu-sample-pairs", type=int, default=int(os.environ.get("MPIBWA_BENCH_CPU_PAIRS", "0")),
+                    help="pairs given to the reference for the CPU baseline and the parity check (0 = the whole step batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workdir", default=os.environ.get("MPIBWA_BENCH_DIR", "/tmp/mpibwa_bench"))
     args = ap.parse_args()
@@ -133,10 +134,23 @@ def main():
     value = n_reads_total / elapsed / 1e6
 
     # ---- roofline of the dominant kernel (rank 0's launches; every rank runs the same kernel on its own shard) ----
+    # A chunk is worked off as n_sub sub-batches, i.e. n_sub launches of the kernel per step: per-launch figures are the
+    # totals over the timed region divided by the number of launches (HIP events on the launching streams, pipeline.hip).
     ach = acc["smem_bytes"] / (acc["k_smem_ms"] * 1e-3) / 1e9 if acc.get("k_smem_ms") else 0.0
+    n_launch = max(1, int(acc.get("n_sub", args.steps)))
+    # HBM traffic per launch: PMC counters cannot be collected inside this run, so the per-read figure measured by
+    # tools/pmc_smem.sh on this workload (profiles/r01_pmc_smem.json) is scaled to the reads of one launch
+    traffic = None
+    try:
+        pj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_smem.json")))
+        if args.genome_mbp >= 3000:
+            traffic = int(pj["smem_kernel"]["traffic_bytes_per_read"] * 2 * args.pairs * args.steps / n_launch)
+    except Exception:
+        traffic = None
     roofline = {"kernel": "smem_kernel", "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(ach / 8000.0, 4), "traffic": None,
-                "launch_ms": round(acc["k_smem_ms"] / args.steps, 3), "algo_bytes_per_launch": int(acc["smem_bytes"] / args.steps)}
+                "frac": round(ach / 8000.0, 4), "traffic": traffic,
+                "launch_ms": round(acc["k_smem_ms"] / n_launch, 3), "algo_bytes_per_launch": int(acc["smem_bytes"] / n_launch),
+                "launches_per_step": n_launch // args.steps}
 
     out = {
         "metric": "Mreads/s (whole node) 2x150 bp PE vs GRCh38-size reference; SAM bit-match",
@@ -160,7 +174,7 @@ def main():
         try:
             from oracle import pyoracle as po
             if po.ref_available():
-                sample = reads[:min(args.cpu_sample_pairs, len(reads))]
+                sample = reads[:min(args.cpu_sample_pairs or len(reads), len(reads))]
                 ref = po.RefIndex(idx.prefix)
                 C.c_int.in_dll(ref.lib, "bwa_verbose").value = 1
                 ropt = ref.opt(flag=abi.MEM_F_PE, n_threads=cores)

@@ -225,6 +225,7 @@ typedef struct {
 	double msw_ms, k_msw_ms;                     /* mate rescue: listing the alignments + waiting for them, HIP-event kernel time */
 	uint64_t n_msw;                              /* local alignments computed by the mate-rescue kernel */
 	double emit_ms;                              /* SAM stage: the pass that formats the records */
+	uint64_t n_sub;                              /* sub-batches of the chunk = launches of each phase-1 kernel */
 } mi355x_stats_t;
 void mi355x_last_stats(mi355x_stats_t *st);
 

@@ -588,6 +588,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	}
 	double t6 = now_ms();
 	g_stats.phase1_ms = t6 - t1;
+	g_stats.n_sub = n_sub;
 	const double c6 = cpu_sec();
 
 	// ---- 7. insert-size statistics over the whole batch ----
