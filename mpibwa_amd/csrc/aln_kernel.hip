@@ -14,7 +14,7 @@
 
 namespace mbw {
 
-#define ALN_WAVES 4
+#define ALN_WAVES 1
 #define ALN_ZCAP 12288       // direction bytes per wavefront
 #define ALN_MDCAP 768
 #define ALN_CIGCAP 96

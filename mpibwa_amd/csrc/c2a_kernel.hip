@@ -47,7 +47,7 @@ __device__ __forceinline__ int ref_base(const uint8_t *pac, i64 l_pac, i64 p)
 	return (pac[p >> 2] >> ((~p & 3) << 1)) & 3;
 }
 
-#define C2A_WAVES 4
+#define C2A_WAVES 1
 #define SRT_MARK 0xFFFFFFFFu
 
 __global__ void __launch_bounds__(64 * C2A_WAVES)
