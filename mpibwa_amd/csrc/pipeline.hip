@@ -247,21 +247,13 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	}
 	const size_t flat_bytes = (size_t)off[n] + 16;
 	uint8_t *flat = (uint8_t *)W.h_flat.ensure(flat_bytes);
-	parallel_for(n_thr, n, 4096, [&](int i) {
-		char *s = seqs[i].seq;
-		uint8_t *d = flat + off[i];
-		for (int k = 0; k < seqs[i].l_seq; ++k) {
-			s[k] = s[k] < 4 ? s[k] : (char)nt4_table[(uint8_t)s[k]];
-			d[k] = (uint8_t)s[k];
-		}
-	});
 	if ((size_t)max_len + 2 > 9000) die("read of %d bp exceeds the on-chip band buffers of this build (max 8998 bp)", max_len);
 	double t1 = now_ms();
 	const double c1 = cpu_sec();
 	uint8_t *d_seq = (uint8_t *)W.seq.ensure(flat_bytes);
 	int64_t *d_off = (int64_t *)W.off.ensure((size_t)(n + 1) * 8);
 	int *d_len = (int *)W.len.ensure((size_t)n * 4);
-	HIP_OK(hipMemcpyAsync(d_seq, flat, flat_bytes, hipMemcpyHostToDevice, st));
+	// the bases themselves are encoded and uploaded per sub-batch, on the sub-batch's own stream (phase1 below)
 	HIP_OK(hipMemcpyAsync(d_off, off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
 	HIP_OK(hipMemcpyAsync(d_len, lens.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
 	HIP_OK(hipStreamSynchronize(st));
@@ -272,12 +264,23 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	// threads with their own HIP stream and workspace: the GPU work of one overlaps the host work of the other.
 	std::vector<HRegV> regs(n);
 	struct P1 { double k_smem = 0, k_sa = 0, k_ext = 0, smem = 0, sa = 0, chain = 0, ext = 0, regs = 0; uint64_t smem_bytes = 0, sa_bytes = 0, cells = 0, n_ext = 0, n_intv = 0, n_seeds = 0, n_chains = 0; };
+	const int n_all = n;
 	auto phase1 = [&](int lo, int hi, Workspace &W, HostBuf &reg_arena, hipStream_t st, int n_thr, P1 &ps) {
 		const int n = hi - lo;
 		bseq1_t *seqs_r = seqs + lo;
 		const int64_t *d_off_r = d_off + lo;
 		const int *d_len_r = d_len + lo;
 		HIP_OK(hipSetDevice(ix.device));
+		// nt4-encode this sub-batch in place (the caller sees the codes, src/bwamem.c:1057-1058) and into the staging buffer
+		parallel_for(n_thr, n, 4096, [&](int i) {
+			char *s = seqs_r[i].seq;
+			uint8_t *d = flat + off[lo + i];
+			for (int k = 0; k < seqs_r[i].l_seq; ++k) {
+				s[k] = s[k] < 4 ? s[k] : (char)nt4_table[(uint8_t)s[k]];
+				d[k] = (uint8_t)s[k];
+			}
+		});
+		HIP_OK(hipMemcpyAsync(d_seq + off[lo], flat + off[lo], (size_t)(off[hi] - off[lo]) + (hi == n_all ? 16 : 0), hipMemcpyHostToDevice, st));
 		EvTimer ev_smem, ev_sa, ev_ext;
 		unsigned long long *d_cnt = (unsigned long long *)W.cnt.ensure(256);
 		unsigned long long cnt[8];
@@ -621,6 +624,9 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		size_t n_mreq = 0;
 		EvTimer mev;
 		bool m_launched = false;
+		// CIGAR requests while they are being listed: per block of 256 units, and where each unit's run starts
+		std::vector<std::vector<AlnReqH>> blk_req;
+		std::vector<uint32_t> u_first, u_cnt;
 		AlnHdr *d_hdr = nullptr; uint8_t *d_pool = nullptr; unsigned long long *d_cnt = nullptr;
 		size_t pool_bytes = 0;
 		hipStream_t st = 0;
@@ -708,24 +714,28 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		msw_ms += now_ms() - ta;
 	};
 
-	auto collect = [&](Part &P) {   // A
+	// A: decisions + the list of CIGARs to compute.  Two rounds, so that the units that asked for no mate-rescue alignment
+	// (most of them) are done while msw_kernel is still running: round 0 = those units, round 1 = the rest + the flat list.
+	auto collect = [&](Part &P, int round) {
 		double ta = now_ms();
 		const double ca = cpu_sec();
 		const int nu = P.hi - P.lo, n_blk = (nu + 255) / 256;
-		std::vector<std::vector<AlnReqH>> blk_req(n_blk);
-		std::vector<uint32_t> u_first(nu), u_cnt(nu);
+		if (round == 0) { P.blk_req.assign(n_blk, std::vector<AlnReqH>()); P.u_first.assign(nu, 0); P.u_cnt.assign(nu, 0); }
 		parallel_for(n_thr, n_blk, 1, [&](int blk) {
-			std::vector<AlnReqH> &rq = blk_req[blk];
-			rq.reserve(256 * 3);
+			std::vector<AlnReqH> &rq = P.blk_req[blk];
+			if (round == 0) rq.reserve(256 * 3);
 			AlnCtx ctx;
 			ctx.mode = AlnCtx::COLLECT; ctx.reqs = &rq;
 			const int lo = P.lo + blk * 256, hi = std::min(P.hi, lo + 256);
 			for (int i = lo; i < hi; ++i) {
+				const int k = i - P.lo;
+				const bool waits = P.m_launched && P.mbase[k + 1] != P.mbase[k];   // needs results of the mate-rescue kernel
+				if (waits != (round == 1)) continue;
 				const size_t before = rq.size();
 				if (pe) {
 					MswCtx mc;
-					if (P.m_launched) { mc.req = P.mreq + P.mbase[i - P.lo]; mc.res = P.mres + P.mbase[i - P.lo]; mc.n = (int)(P.mbase[i - P.lo + 1] - P.mbase[i - P.lo]); }
-					sam_pe_plan(opt, bns, pac, pes, (uint64_t)((n_processed >> 1) + i), &seqs[i << 1], &regs[i << 1], plans[i], P.m_launched ? &mc : nullptr,
+					if (waits) { mc.req = P.mreq + P.mbase[k]; mc.res = P.mres + P.mbase[k]; mc.n = (int)(P.mbase[k + 1] - P.mbase[k]); }
+					sam_pe_plan(opt, bns, pac, pes, (uint64_t)((n_processed >> 1) + i), &seqs[i << 1], &regs[i << 1], plans[i], waits ? &mc : nullptr,
 					            i << 1);
 					if (gpu_aln) sam_pe_emit(opt, bns, pac, pes, &seqs[i << 1], &regs[i << 1], plans[i], &ctx, i << 1);
 				} else {
@@ -733,15 +743,17 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 					if (opt->flag & MEM_F_PRIMARY5) reorder_primary5(opt->T, regs[i]);
 					if (gpu_aln) reg2sam(opt, bns, pac, &seqs[i], regs[i], 0, 0, &ctx, i);
 				}
-				u_first[i - P.lo] = (uint32_t)before; u_cnt[i - P.lo] = (uint32_t)(rq.size() - before);
+				P.u_first[k] = (uint32_t)before; P.u_cnt[k] = (uint32_t)(rq.size() - before);
 			}
 		});
-		P.base.assign(nu + 1, 0);
-		for (int i = 0; i < nu; ++i) P.base[i + 1] = P.base[i] + u_cnt[i];
-		P.req.resize(P.base[nu]);
-		parallel_for(n_thr, nu, 4096, [&](int i) {
-			if (u_cnt[i]) memcpy(&P.req[P.base[i]], &blk_req[i >> 8][u_first[i]], (size_t)u_cnt[i] * sizeof(AlnReqH));
-		});
+		if (round == 1) {
+			P.base.assign(nu + 1, 0);
+			for (int i = 0; i < nu; ++i) P.base[i + 1] = P.base[i] + P.u_cnt[i];
+			P.req.resize(P.base[nu]);
+			parallel_for(n_thr, nu, 4096, [&](int i) {
+				if (P.u_cnt[i]) memcpy(&P.req[P.base[i]], &P.blk_req[i >> 8][P.u_first[i]], (size_t)P.u_cnt[i] * sizeof(AlnReqH));
+			});
+		}
 		plan_ms += now_ms() - ta;
 		cpu_collect += cpu_sec() - ca;
 	};
@@ -810,14 +822,15 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	};
 	if (n_parts == 1) {
 		parts[0].lo = 0; parts[0].hi = n_units;
-		mcollect(parts[0], 0); mlaunch(parts[0], 0); mfinish(parts[0]);
-		collect(parts[0]); launch(parts[0], 0); finish(parts[0]); replay(parts[0]);
+		mcollect(parts[0], 0); mlaunch(parts[0], 0);
+		collect(parts[0], 0); mfinish(parts[0]); collect(parts[0], 1);
+		launch(parts[0], 0); finish(parts[0]); replay(parts[0]);
 	} else {
 		parts[0].lo = 0; parts[0].hi = n_units / 2; parts[1].lo = n_units / 2; parts[1].hi = n_units;
 		mcollect(parts[0], 0); mlaunch(parts[0], 0);
 		mcollect(parts[1], 1); mlaunch(parts[1], 1);
-		mfinish(parts[0]); collect(parts[0]); launch(parts[0], 0);
-		mfinish(parts[1]); collect(parts[1]); launch(parts[1], 1);
+		collect(parts[0], 0); mfinish(parts[0]); collect(parts[0], 1); launch(parts[0], 0);
+		collect(parts[1], 0); mfinish(parts[1]); collect(parts[1], 1); launch(parts[1], 1);
 		finish(parts[0]); replay(parts[0]);
 		finish(parts[1]); replay(parts[1]);
 	}
