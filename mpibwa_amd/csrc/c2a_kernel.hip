@@ -70,6 +70,8 @@ c2a_kernel(C2aParams P, WxParams X, int n_reads, const uint8_t *__restrict__ seq
 	int nav = 0;
 	unsigned long long cells = 0, n_ext = 0;
 	const i64 l_pac = P.l_pac;
+	int max_sc = 1;   // largest entry of the scoring matrix: what one more column can add at most
+	for (int t = 0; t < 25; ++t) max_sc = X.mat[t] > max_sc ? X.mat[t] : max_sc;
 
 	for (int ci = chain_off[rd]; ci < chain_off[rd + 1]; ++ci) {
 		const DevChain C = chains[ci];
@@ -156,8 +158,8 @@ c2a_kernel(C2aParams P, WxParams X, int n_reads, const uint8_t *__restrict__ seq
 					int prev = a.score;
 					aw0 = P.w << i;
 					int wc = aw0 < bound5[qlen] ? aw0 : bound5[qlen];
-					r = wave_extend(qlen, [&](int j) { return q[s.qbeg - 1 - j]; }, tlen,
-					                [&](int t) { return ref_base(pac, l_pac, s.rbeg - 1 - t); }, X, wc, s.len * P.a, H, E, cells);
+					r = wave_extend<true>(qlen, [&](int j) { return q[s.qbeg - 1 - j]; }, tlen,
+					                      [&](int t) { return ref_base(pac, l_pac, s.rbeg - 1 - t); }, X, wc, s.len * P.a, H, E, cells, max_sc);
 					++n_ext;
 					a.score = r.score;
 					if (a.score == prev || r.max_off < (aw0 >> 1) + (aw0 >> 2)) break;
@@ -177,8 +179,8 @@ c2a_kernel(C2aParams P, WxParams X, int n_reads, const uint8_t *__restrict__ seq
 					int prev = a.score;
 					aw1 = P.w << i;
 					int wc = aw1 < bound3[qlen] ? aw1 : bound3[qlen];
-					r = wave_extend(qlen, [&](int j) { return q[qe + j]; }, tlen,
-					                [&](int t) { return ref_base(pac, l_pac, s.rbeg + s.len + t); }, X, wc, sc0, H, E, cells);
+					r = wave_extend<true>(qlen, [&](int j) { return q[qe + j]; }, tlen,
+					                      [&](int t) { return ref_base(pac, l_pac, s.rbeg + s.len + t); }, X, wc, sc0, H, E, cells, max_sc);
 					++n_ext;
 					a.score = r.score;
 					if (a.score == prev || r.max_off < (aw1 >> 1) + (aw1 >> 2)) break;

@@ -66,9 +66,18 @@ struct WxResult { int score, qle, tle, gtle, gscore, max_off; };
 // TF(i)  -> target base 0..4 at row i    (evaluated per lane for prefetching 64 rows at a time)
 // H, E   -> LDS (or global) arrays of qlen+1 ints owned by this wave
 // `w` must already be clamped like src/ksw.c:395-407 (see wx_clamp_band on the host side).
-template <typename QF, typename TF>
+//
+// EARLY: stop as soon as no later row can change any output.  Every alignment path that reaches a later row leaves row i
+// through one of the stored cells — diagonally from eh[j].h into column j, or vertically from eh[j].e in column j — and
+// gains at most max_sc per remaining column, so
+//     B = max_j max(eh[j].h + (qlen - j) * max_sc,  eh[j].e + (qlen - 1 - j) * max_sc)        (stale cells included)
+// bounds every later H, in particular every later row maximum and every later score at the query end.  When B <= max
+// and B < gscore the reference's remaining rows update neither (max, max_i, max_j, max_off) nor (gscore, max_ie); it only
+// goes on until the scores have decayed to zero, typically for as many rows again as the alignment itself.  The test
+// runs every 4th row once the query end has been reached.  Off: the row count (and the cell counter) match the reference.
+template <bool EARLY = false, typename QF, typename TF>
 __device__ __forceinline__ WxResult wave_extend(int qlen, QF qf, int tlen, TF tf, const WxParams &P, int w, int h0,
-                                                int *H, int *E, unsigned long long &cells)
+                                                int *H, int *E, unsigned long long &cells, int max_sc = 1)
 {
 	const int lane = threadIdx.x & 63;
 	const int oe_del = P.o_del + P.e_del, oe_ins = P.o_ins + P.e_ins, e_del = P.e_del, e_ins = P.e_ins;
@@ -175,6 +184,16 @@ __device__ __forceinline__ WxResult wave_extend(int qlen, QF qf, int tlen, TF tf
 		const int ne = last_nz >= nb ? last_nz : nb - 1;
 		beg = nb;
 		end = ne + 2 < qlen ? ne + 2 : qlen;
+		if (EARLY && gscore >= 0 && (i & 3) == 3) {
+			int b = WX_NEG;
+			for (int j = lane; j <= qlen; j += 64) {
+				const int hv = j < qlen ? H[j] + (qlen - j) * max_sc : WX_NEG;
+				const int ev = E[j] + (qlen - 1 - j) * max_sc;
+				b = max(b, max(hv, ev));
+			}
+			b = __builtin_amdgcn_readlane(wx_scan_max(b), 63);
+			if (b < gscore && b <= best) break;
+		}
 	}
 	WxResult r;
 	r.score = best; r.qle = best_j + 1; r.tle = best_i + 1; r.gtle = best_ie + 1; r.gscore = gscore; r.max_off = max_off;
