@@ -213,6 +213,21 @@ int mi355x_matesw_batch(const mem_opt_t *opt, int64_t l_pac, const uint8_t *pac,
                         const int64_t *off, int n_req, const int64_t *rb, const int64_t *re, const int *read,
                         const int *is_rev, int *out8, double *kernel_ms);
 
+/* ---- the caller's side of the boundary: FASTQ text -> mpiBWA's chunks -> bseq1_t[] ----
+ * Record scan (find_reads_size_and_offsets, src/parallel_aux.c:682-832): offsets of the record starts
+ * (rec_off[n] = end of data) and bases per record; returns the number of records or -(position+1) of a malformed one. */
+int64_t mi355x_fastq_scan(const char *buf, int64_t len, int64_t cap, int64_t *rec_off, int32_t *rec_bases);
+/* Chunk rule (find_chunks_info, src/parallel_aux.c:1510-1546): a chunk takes records until its base count EXCEEDS
+ * maxsiz (= K/2 per file for equal-size pairs, src/mainParallel.c:947; K over both files for trimmed pairs, :1874,
+ * pass bases2; K for single-end, :2773).  chunk_first[c] = first record of chunk c, chunk_first[n_chunks] = n. */
+int64_t mi355x_fastq_chunks(const int32_t *bases1, const int32_t *bases2, int64_t n, int64_t maxsiz, int64_t cap,
+                            int64_t *chunk_first);
+/* bseq1_t[] of records [first, first+count) as mpiBWA's main builds them (src/mainParallel.c:1257-1301, :2271-2345):
+ * strings NUL-terminated in place inside buf1 / buf2, mates interleaved, name cut at the first white space and a
+ * trailing "/digit" dropped.  lockstep: equal-size mode (R2 cut at R1's offsets).  Returns the bases of the chunk. */
+int64_t mi355x_fastq_fill(char *buf1, const int64_t *off1, char *buf2, const int64_t *off2, int64_t first, int64_t count,
+                          int copy_comment, int lockstep, bseq1_t *seqs);
+
 /* timing of the last mem_process_seqs() call, per stage (ms) */
 typedef struct {
 	double total_ms, h2d_ms, smem_ms, sa_ms, chain_ms, ext_ms, regs_ms, pestat_ms, sam_ms;

@@ -106,6 +106,15 @@ class SeqBatch:
 
     _DT = None
 
+    @staticmethod
+    def dtype():
+        """numpy view of bseq1_t (src/bwa.h:30-33)"""
+        import numpy as np
+        if SeqBatch._DT is None:
+            SeqBatch._DT = np.dtype([("l_seq", "<i4"), ("id", "<i4"), ("name", "<u8"), ("comment", "<u8"), ("seq", "<u8"),
+                                     ("qual", "<u8"), ("sam", "<u8")])
+        return SeqBatch._DT
+
     def __init__(self, libc, reads, with_qual=True, comment=None):
         # reads: list of (name:str, seq1:bytes, seq2:bytes|None)
         import numpy as np

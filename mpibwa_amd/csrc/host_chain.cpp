@@ -257,9 +257,23 @@ void chains_from_seeds(const mem_opt_t *opt, const bntseq_t *bns, int l_query, c
 	if ((int)W.pool.size() < n_seeds) W.pool.resize(n_seeds);   // at most one chain per seed; pointers stay valid during this read
 	W.used = 0;
 	BTree tree(W.pool, W.nodes);
+	// consecutive seeds mostly fall into the contig (and strand) of the previous one: remember its span in the doubled
+	// coordinate instead of two binary searches per seed
+	int64_t c_lo = 0, c_hi = -1;
+	int c_rid = -1;
 	for (int k = 0; k < n_seeds; ++k) {
 		const HSeed &s = seeds[k];
-		int rid = bns_intv2rid(bns, s.rbeg, s.rbeg + s.len);
+		int rid;
+		if (s.rbeg >= c_lo && s.rbeg + s.len <= c_hi && s.len > 0) rid = c_rid;
+		else {
+			rid = bns_intv2rid(bns, s.rbeg, s.rbeg + s.len);
+			if (rid >= 0) {
+				const int64_t o = bns->anns[rid].offset, l = bns->anns[rid].len;
+				if (s.rbeg < bns->l_pac) { c_lo = o; c_hi = o + l; }
+				else { c_lo = (bns->l_pac << 1) - o - l; c_hi = (bns->l_pac << 1) - o; }
+				c_rid = rid;
+			}
+		}
 		if (rid < 0) continue;   // bridges two contigs or the strand boundary
 		bool add = true;
 		if (tree.n_keys) {

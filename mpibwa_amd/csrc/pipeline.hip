@@ -372,6 +372,8 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			std::vector<std::vector<HSeed>> hsv(nt);
 			std::vector<std::vector<HChain *>> chv(nt);
 			std::vector<std::vector<uint64_t>> keyv(nt);
+			static const bool prof_chain = getenv("MPIBWA_CPUSEC") != nullptr;
+			std::vector<unsigned long long> tsc((size_t)nt * 8, 0);
 			parallel_blocks(nt, n, CB, [&](int tid, int b, int lo, int hi) {
 				if (!scr[tid]) scr[tid].reset(new ChainScratch());
 				std::vector<HSeed> &hs = hsv[tid];
@@ -384,14 +386,20 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 					int ns = nseeds[i];
 					chain_off[i + 1] = reg_off[i + 1] = 0;
 					if (ns == 0) continue;
+					const unsigned long long c0 = prof_chain ? __builtin_ia32_rdtsc() : 0;
 					hs.resize(ns);
 					for (int k = 0; k < ns; ++k) {
 						int64_t so = seed_off[i] + k;
 						hs[k].rbeg = (int64_t)sa[so]; hs[k].qbeg = qbl[2 * so]; hs[k].len = hs[k].score = qbl[2 * so + 1];
 					}
+					const unsigned long long c1 = prof_chain ? __builtin_ia32_rdtsc() : 0;
 					chains_from_seeds(opt, bns, seqs_r[i].l_seq, hs.data(), ns, lrep[i], *scr[tid], chains);
+					const unsigned long long c2 = prof_chain ? __builtin_ia32_rdtsc() : 0;
 					chain_filter(opt, *scr[tid], chains);
+					const unsigned long long c3 = prof_chain ? __builtin_ia32_rdtsc() : 0;
 					filter_chained_seeds(opt, bns, pac, seqs_r[i].l_seq, (const uint8_t *)seqs_r[i].seq, chains);
+					const unsigned long long c4 = prof_chain ? __builtin_ia32_rdtsc() : 0;
+					if (prof_chain) { tsc[tid * 8 + 0] += c1 - c0; tsc[tid * 8 + 1] += c2 - c1; tsc[tid * 8 + 2] += c3 - c2; tsc[tid * 8 + 3] += c4 - c3; tsc[tid * 8 + 5] += ns; tsc[tid * 8 + 6] += ns > 64; }
 					int tot = 0;
 					for (const HChain *cp_ : chains) {
 						const HChain &ch = *cp_;
@@ -410,18 +418,23 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 						// distinct, so any sort gives that order — and visited from the last one down; the order array the
 						// kernels use for their "seed skipped" marks therefore starts as the identity.
 						key.resize(cs);
-						for (int k = 0; k < cs; ++k) key[k] = (uint64_t)ch.seeds[k].score << 32 | (uint32_t)k;
-						if (cs > 1) std::sort(key.begin(), key.end());
+						const HSeed *hsd = ch.seeds.data();
+						for (int k = 0; k < cs; ++k) key[k] = (uint64_t)hsd[k].score << 32 | (uint32_t)k;
+						if (cs == 2) { if (key[1] < key[0]) std::swap(key[0], key[1]); }
+						else if (cs > 2) std::sort(key.begin(), key.end());
 						int64_t lo = bns->l_pac << 1, hi = 0;
+						const size_t at = o.sd.size();
+						o.sd.resize(at + cs); o.srt.resize(at + cs);
+						DevSeed *osd = o.sd.data() + at;
+						unsigned int *osr = o.srt.data() + at;
+						const int lq_i = seqs_r[i].l_seq;
 						for (int k = 0; k < cs; ++k) {
-							const HSeed &t = ch.seeds[(uint32_t)key[k]];
-							DevSeed ds;
-							ds.rbeg = t.rbeg; ds.qbeg = t.qbeg; ds.len = t.len;
-							o.sd.push_back(ds);
-							o.srt.push_back((unsigned int)k);
+							const HSeed &t = hsd[(uint32_t)key[k]];
+							osd[k].rbeg = t.rbeg; osd[k].qbeg = t.qbeg; osd[k].len = t.len;
+							osr[k] = (unsigned int)k;
 							// widest reference span any seed of the chain could reach (src/bwamem.c:642-658)
 							const int64_t b = t.rbeg - (t.qbeg + gap_h[t.qbeg]);
-							const int tail = seqs_r[i].l_seq - t.qbeg - t.len;
+							const int tail = lq_i - t.qbeg - t.len;
 							const int64_t e = t.rbeg + t.len + (tail + gap_h[tail]);
 							lo = b < lo ? b : lo;
 							hi = e > hi ? e : hi;
@@ -441,8 +454,15 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 					}
 					chain_off[i + 1] = (int)chains.size();
 					reg_off[i + 1] = tot;
+					if (prof_chain) tsc[tid * 8 + 4] += __builtin_ia32_rdtsc() - c4;
 				}
 			});
+			if (prof_chain) {
+				unsigned long long t[8] = {0};
+				for (int a = 0; a < nt; ++a) for (int b = 0; b < 8; ++b) t[b] += tsc[(size_t)a * 8 + b];
+				fprintf(stderr, "[chain Mcycles] seeds->HSeed %.0f  chaining %.0f  filter %.0f  flt_seeds %.0f  pack %.0f   (%llu seeds, %llu reads with >64 seeds, %d reads)\n",
+				        t[0] * 1e-6, t[1] * 1e-6, t[2] * 1e-6, t[3] * 1e-6, t[4] * 1e-6, t[5], t[6], n);
+			}
 		}
 		chain_off[0] = reg_off[0] = 0;
 		for (int i = 0; i < n; ++i) { chain_off[i + 1] += chain_off[i]; reg_off[i + 1] += reg_off[i]; }

@@ -1,0 +1,147 @@
+"""The caller's side of `mem_process_seqs`: FASTQ files -> mpiBWA's chunks -> bseq1_t[] -> SAM stream.
+
+Host-side mirror of what mpiBWA's `main` does around the hot path for one rank (src/mainParallel.c:730-1055 equal-size
+pairs, :1780-2400 trimmed pairs, :2700-3120 single end), on top of the C ABI (`mi355x_fastq_scan / _chunks / _fill`):
+the chunk boundaries, the strings behind every `bseq1_t` and the order of the SAM records are the reference's; the
+reference's chunk count is carried from rank to rank, so they do not depend on the number of ranks either.  Reading,
+aligning and writing overlap (the reference's docs/TODO:4): the SAM strings of chunk i are concatenated, written and freed
+by a writer thread while chunk i+1 is on the GPU (src/mainParallel.c:103-127 `copy_buffer_thr` does the same).
+"""
+import ctypes as C
+import gzip
+import queue
+import threading
+
+import numpy as np
+
+from . import abi
+
+_libc = C.CDLL("libc.so.6")
+_libc.free.argtypes = [C.c_void_p]
+
+
+def _load(path):
+    data = gzip.open(path, "rb").read() if str(path).endswith(".gz") else open(path, "rb").read()
+    # one spare byte: the last quality line is NUL-terminated in place even when the file has no final newline
+    buf = C.create_string_buffer(data, len(data) + 1)
+    return buf, len(data)
+
+
+class FastqFile:
+    """One FASTQ file in memory: record offsets and bases per record (find_reads_size_and_offsets, src/parallel_aux.c:682)."""
+
+    def __init__(self, lib, path):
+        self.lib = lib
+        self.buf, self.len = _load(path)
+        cap = max(16, self.len // 32)          # a record has at least 8 bytes; grow if the guess is short
+        while True:
+            off = np.zeros(cap + 1, dtype=np.int64)
+            bases = np.zeros(cap, dtype=np.int32)
+            n = lib.mi355x_fastq_scan(C.addressof(self.buf), self.len, cap, off.ctypes.data, bases.ctypes.data)
+            if n < 0:
+                raise ValueError("%s: malformed FASTQ record at byte %d" % (path, -n - 1))
+            if n <= cap:
+                break
+            cap = n
+        self.n = int(n)
+        self.off = off[:self.n + 1].copy()
+        self.bases = bases[:self.n].copy()
+
+    @property
+    def addr(self):
+        return C.addressof(self.buf)
+
+
+def chunk_starts(lib, bases1, bases2, maxsiz):
+    """mpiBWA's chunk rule (src/parallel_aux.c:1520-1546): first record of every chunk, plus n at the end."""
+    n = len(bases1)
+    cap = n + 1
+    first = np.zeros(cap + 1, dtype=np.int64)
+    b1 = np.ascontiguousarray(bases1, dtype=np.int32)
+    b2 = None if bases2 is None else np.ascontiguousarray(bases2, dtype=np.int32)
+    k = lib.mi355x_fastq_chunks(b1.ctypes.data, None if b2 is None else b2.ctypes.data, n, int(maxsiz), cap, first.ctypes.data)
+    return first[:k + 1].copy()
+
+
+class FastqSource:
+    """R1 (+R2) -> chunks of bseq1_t.  mode: 'pe' (equal-size pairs, K/2 per file), 'pe_trim' (K over both files), 'se'."""
+
+    def __init__(self, lib, r1, r2=None, K=10_000_000, copy_comment=False, mode=None):
+        self.lib = lib
+        self.f1 = FastqFile(lib, r1)
+        self.f2 = FastqFile(lib, r2) if r2 is not None else None
+        if self.f2 is not None and self.f1.n != self.f2.n:
+            raise ValueError("the two FASTQ files hold %d and %d reads" % (self.f1.n, self.f2.n))
+        if mode is None:
+            # mpiBWA takes the equal-size branch when both files have the same byte size (src/mainParallel.c:703-728)
+            mode = "se" if self.f2 is None else ("pe" if self.f1.len == self.f2.len else "pe_trim")
+        self.mode, self.copy_comment = mode, copy_comment
+        if mode == "pe":
+            self.starts = chunk_starts(lib, self.f1.bases, None, K // 2)
+        elif mode == "pe_trim":
+            self.starts = chunk_starts(lib, self.f1.bases, self.f2.bases, K)
+        else:
+            self.starts = chunk_starts(lib, self.f1.bases, None, K)
+
+    @property
+    def n_chunks(self):
+        return len(self.starts) - 1
+
+    def chunk(self, c):
+        """(bseq1_t array, n_reads, keepalive) for chunk c; the strings live inside the file buffers."""
+        first, count = int(self.starts[c]), int(self.starts[c + 1] - self.starts[c])
+        files = 1 if self.f2 is None else 2
+        rec = np.zeros(max(files * count, 1), dtype=abi.SeqBatch.dtype())
+        rc = self.lib.mi355x_fastq_fill(self.f1.addr, self.f1.off.ctypes.data, self.f2.addr if self.f2 else None,
+                                        self.f2.off.ctypes.data if self.f2 else None, first, count, int(self.copy_comment),
+                                        int(self.mode == "pe"), rec.ctypes.data)
+        if rc < 0:
+            raise ValueError("malformed FASTQ record %d" % (first - rc - 1))
+        return rec, files * count
+
+
+def align_files(engine, opt, r1, r2=None, out=None, K=10_000_000, copy_comment=False, mode=None, n_processed0=0):
+    """`mpiBWA mem` for one rank: every chunk through mem_process_seqs, SAM records in read order.
+
+    out: a binary file object (the SAM body is written to it) or None (the body is returned as bytes).
+    Returns (bytes or None, per-chunk read counts)."""
+    lib = engine.lib
+    src = FastqSource(lib, r1, r2, K=K, copy_comment=copy_comment, mode=mode)
+    pieces = [] if out is None else None
+    todo = queue.Queue(maxsize=2)
+    err = []
+
+    def writer():   # copy_buffer_thr: concatenate + free the chunk's SAM strings while the next chunk is being aligned
+        while True:
+            item = todo.get()
+            if item is None:
+                return
+            rec, n = item
+            try:
+                tot = C.c_size_t(0)
+                p = lib.mi355x_collect_sam(C.cast(rec.ctypes.data, C.POINTER(abi.bseq1_t)), n, C.byref(tot))
+                data = C.string_at(p, tot.value)
+                _libc.free(C.c_void_p(p))
+                if out is None:
+                    pieces.append(data)
+                else:
+                    out.write(data)
+            except Exception as e:  # pragma: no cover
+                err.append(e)
+
+    th = threading.Thread(target=writer, daemon=True)
+    th.start()
+    counts = []
+    for c in range(src.n_chunks):
+        rec, n = src.chunk(c)
+        # mpiBWA passes n_processed = 0 for equal-size pairs and single end, and the reads already done by the rank in
+        # the trimmed branch (src/mainParallel.c:1314, 2355-2357, 3093)
+        npz = n_processed0 + (sum(counts) if src.mode == "pe_trim" else 0)
+        lib.mem_process_seqs(opt, engine.bwt, engine.bns, engine.pac, npz, n, C.cast(rec.ctypes.data, C.POINTER(abi.bseq1_t)), None)
+        counts.append(n)
+        todo.put((rec, n))
+    todo.put(None)
+    th.join()
+    if err:
+        raise err[0]
+    return (b"".join(pieces) if out is None else None), counts
