@@ -30,6 +30,7 @@ static bool tune_allocator()
 	if (getenv("MPIBWA_MALLOC_DEFAULTS")) return false;
 	mallopt(M_TRIM_THRESHOLD, 1 << 30);
 	mallopt(M_TOP_PAD, 64 << 20);
+	mallopt(M_MMAP_THRESHOLD, 32 << 20);   // the per-chunk work arrays (tens of MB each) come from the heap too instead of mmap/munmap per chunk
 	return true;
 }
 static bool g_alloc_tuned = tune_allocator();

@@ -27,6 +27,7 @@
 #include <vector>
 #include <sys/resource.h>
 #include <sys/time.h>
+#include <unistd.h>
 
 #include "device.h"
 #include "host.h"
@@ -137,6 +138,23 @@ static double cpu_sec()
 	struct rusage r;
 	getrusage(RUSAGE_SELF, &r);
 	return r.ru_utime.tv_sec + r.ru_stime.tv_sec + 1e-6 * (r.ru_utime.tv_usec + r.ru_stime.tv_usec);
+}
+
+// Wait for a stream without burning a core: hipStreamSynchronize spins, and a spinning thread counts against the
+// container's CPU quota like a working one (the host stages are the other half of the bottleneck).  Polling with a short
+// sleep costs at most ~0.1 ms per wait.
+static void stream_wait(hipStream_t st)
+{
+	static const bool spin = getenv("MPIBWA_SPIN_WAIT") != nullptr;
+	if (!spin) {
+		for (;;) {
+			hipError_t e = hipStreamQuery(st);
+			if (e == hipSuccess) break;
+			if (e != hipErrorNotReady) HIP_OK(e);
+			usleep(60);
+		}
+	}
+	HIP_OK(hipStreamSynchronize(st));
 }
 
 struct EvTimer {
@@ -306,7 +324,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			else launch_smem(st, ix.fm, smem_params(opt), n, d_seq, d_off_r, d_len_r, cap, d_intv, d_nintv, max_len, d_cnt, d_scr, per_quad, n_quads);
 			ev_smem.stop(st);
 			HIP_OK(hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, st));
-			HIP_OK(hipStreamSynchronize(st));
+			stream_wait(st);
 			HIP_OK(hipGetLastError());
 			turn.unlock();
 			ps.k_smem += ev_smem.ms();
@@ -323,7 +341,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		HIP_OK(hipMemcpyAsync(nseeds.data(), d_nseeds, (size_t)n * 4, hipMemcpyDeviceToHost, st));
 		HIP_OK(hipMemcpyAsync(lrep.data(), d_lrep, (size_t)n * 4, hipMemcpyDeviceToHost, st));
 		HIP_OK(hipMemcpyAsync(nintv.data(), d_nintv, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-		HIP_OK(hipStreamSynchronize(st));
+		stream_wait(st);
 		std::vector<int64_t> seed_off(n + 1);
 		seed_off[0] = 0;
 		uint64_t n_intv = 0;
@@ -348,7 +366,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			HIP_OK(hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, st));
 			HIP_OK(hipMemcpyAsync(sa, d_sa, (size_t)S * 8, hipMemcpyDeviceToHost, st));
 			HIP_OK(hipMemcpyAsync(qbl, d_qbl, (size_t)S * 8, hipMemcpyDeviceToHost, st));
-			HIP_OK(hipStreamSynchronize(st));
+			stream_wait(st);
 			HIP_OK(hipGetLastError());
 			ps.k_sa = ev_sa.ms();
 			ps.sa_bytes = ix.fm.sa_full ? (uint64_t)S * 16 : cnt[1] * 64 + (uint64_t)S * 8;
@@ -531,7 +549,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			HIP_OK(hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, st));
 			HIP_OK(hipMemcpyAsync(hregs, d_regs, (size_t)NS * sizeof(DevReg), hipMemcpyDeviceToHost, st));
 			HIP_OK(hipMemcpyAsync(nregs, d_nregs, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-			HIP_OK(hipStreamSynchronize(st));
+			stream_wait(st);
 			HIP_OK(hipGetLastError());
 			turn.unlock();
 			ps.k_ext = ev_ext.ms();
@@ -727,7 +745,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	auto mfinish = [&](Part &P) {
 		if (!P.m_launched) return;
 		double ta = now_ms();
-		HIP_OK(hipStreamSynchronize(P.st));
+		stream_wait(P.st);
 		HIP_OK(hipGetLastError());
 		g_stats.k_msw_ms += P.mev.ms();
 		g_stats.n_msw += P.n_mreq;
@@ -804,7 +822,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		const size_t n_req = P.req.size();
 		if (!gpu_aln || n_req == 0) return;
 		double ta = now_ms();
-		HIP_OK(hipStreamSynchronize(P.st));
+		stream_wait(P.st);
 		HIP_OK(hipGetLastError());
 		HIP_OK(hipMemcpy(P.cnt, P.d_cnt, 64, hipMemcpyDeviceToHost));
 		g_stats.k_aln_ms += P.ev.ms();
