@@ -85,9 +85,17 @@ __global__ void bucket_count_kernel(const u64 *__restrict__ T, u64 N, int kb, u6
 	if (threadIdx.x < (1u << (2 * kb)) && loc[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (u64)loc[threadIdx.x]);
 }
 
-__global__ void bucket_fill_kernel(const u64 *__restrict__ T, u64 N, int kb, u32 bucket, u64 *__restrict__ keys, u64 *__restrict__ pos,
-                                   u64 *cursor)
+// Appends (key, position) of every suffix of one 2-symbol bucket.  The order inside the bucket is irrelevant (it is sorted
+// next), so the append is aggregated per workgroup: one atomic on the shared cursor per 1024 suffixes instead of one per
+// wavefront — with 6.2 G suffixes and 16 passes the single-address atomic was the whole cost of this kernel (18 s -> see
+// DESIGN.md §4.6).
+#define FILL_BS 1024
+__global__ void __launch_bounds__(FILL_BS)
+bucket_fill_kernel(const u64 *__restrict__ T, u64 N, int kb, u32 bucket, u64 *__restrict__ keys, u64 *__restrict__ pos, u64 *cursor)
 {
+	__shared__ u32 wcnt[FILL_BS / 64];
+	__shared__ u64 bbase;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	// grid-stride with a block-uniform trip count (HIP caps one launch at 2^32 work-items)
 	for (u64 p0 = (u64)blockIdx.x * blockDim.x; p0 < N; p0 += (u64)gridDim.x * blockDim.x) {
 		u64 p = p0 + threadIdx.x;
@@ -97,19 +105,20 @@ __global__ void bucket_fill_kernel(const u64 *__restrict__ T, u64 N, int kb, u32
 			key = kmer_key(T, p, N);
 			mine = (u32)(key >> (64 - 2 * kb)) == bucket;
 		}
-		// wave-aggregated append
-		u64 bal = __ballot(mine);
-		if (bal) {
-			int lane = threadIdx.x & 63;
-			int leader = __ffsll((long long)bal) - 1;
-			u64 base = 0;
-			if (lane == leader) base = atomicAdd(cursor, (u64)__popcll(bal));
-			base = __shfl(base, leader);
-			if (mine) {
-				u64 o = base + __popcll(bal & ((1ull << lane) - 1));
-				keys[o] = key; pos[o] = p;
-			}
+		const u64 bal = __ballot(mine);
+		if (lane == 0) wcnt[wave] = (u32)__popcll(bal);
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			u32 tot = 0;
+			for (int w = 0; w < FILL_BS / 64; ++w) { u32 c = wcnt[w]; wcnt[w] = tot; tot += c; }   // exclusive prefix in place
+			bbase = tot ? atomicAdd(cursor, (u64)tot) : 0;
 		}
+		__syncthreads();
+		if (mine) {
+			u64 o = bbase + wcnt[wave] + __popcll(bal & ((1ull << lane) - 1));
+			keys[o] = key; pos[o] = p;
+		}
+		__syncthreads();
 	}
 }
 
@@ -336,7 +345,7 @@ extern "C" int mi355x_index_build_gpu(int device, const uint8_t *pac, int64_t l_
 			const u64 n = counts[b];
 			if (n == 0) continue;
 			HIP_OK(hipMemset(d_cursor.p, 0, 8));
-			hipLaunchKernelGGL(bucket_fill_kernel, dim3(grid_strided(N, BS)), dim3(BS), 0, 0, T, N, kb, b, k_in.as<u64>(), v_in.as<u64>(), d_cursor.as<u64>());
+			hipLaunchKernelGGL(bucket_fill_kernel, dim3(grid_strided(N, FILL_BS)), dim3(FILL_BS), 0, 0, T, N, kb, b, k_in.as<u64>(), v_in.as<u64>(), d_cursor.as<u64>());
 			check_launch("bucket_fill_kernel");
 			size_t ts = tmp_sort;
 			HIP_OK(hipcub::DeviceRadixSort::SortPairs(tmp.p, ts, k_in.as<u64>(), k_out.as<u64>(), v_in.as<u64>(), v_out.as<u64>(), (int)n, 0, 64 - 2 * kb));
