@@ -52,8 +52,8 @@ __device__ __forceinline__ int ref_base(const uint8_t *pac, i64 l_pac, i64 p)
 
 __global__ void __launch_bounds__(64 * C2A_WAVES)
 c2a_kernel(C2aParams P, WxParams X, int n_reads, const uint8_t *__restrict__ seq, const int64_t *__restrict__ off,
-           const int *__restrict__ lens, const int *__restrict__ chain_off, const DevChain *__restrict__ chains, const DevSeed *__restrict__ seeds,
-           unsigned int *srt, const int *__restrict__ reg_off, DevReg *regs, int *n_regs, const int *__restrict__ tab,
+           const int *__restrict__ lens, const int *__restrict__ chain_beg, const int *__restrict__ chain_cnt, const DevChain *__restrict__ chains,
+           const DevSeed *__restrict__ seeds, unsigned int *srt, const int *__restrict__ reg_beg, DevReg *regs, int *n_regs, const int *__restrict__ tab,
            int tab_stride, const uint8_t *__restrict__ pac, unsigned long long *counters, int max_len)
 {
 	extern __shared__ int lds[];
@@ -66,14 +66,15 @@ c2a_kernel(C2aParams P, WxParams X, int n_reads, const uint8_t *__restrict__ seq
 	          *thr10 = tab + 4 * tab_stride;
 	const uint8_t *q = seq + off[rd];
 	const int lq = lens[rd];
-	DevReg *av = regs + reg_off[rd];
+	DevReg *av = regs + reg_beg[rd];
 	int nav = 0;
 	unsigned long long cells = 0, n_ext = 0;
 	const i64 l_pac = P.l_pac;
 	int max_sc = 1;   // largest entry of the scoring matrix: what one more column can add at most
 	for (int t = 0; t < 25; ++t) max_sc = X.mat[t] > max_sc ? X.mat[t] : max_sc;
 
-	for (int ci = chain_off[rd]; ci < chain_off[rd + 1]; ++ci) {
+	const int ci_end = chain_beg[rd] + (chain_cnt[rd] > 0 ? chain_cnt[rd] : 0);
+	for (int ci = chain_beg[rd]; ci < ci_end; ++ci) {
 		const DevChain C = chains[ci];
 		const int n = C.n_seeds;
 		if (n == 0) continue;
@@ -212,8 +213,8 @@ c2a_kernel(C2aParams P, WxParams X, int n_reads, const uint8_t *__restrict__ seq
 }
 
 void launch_c2a(void *stream, const C2aParams &P, const ExtParams &ep, int n_reads, const uint8_t *d_seq, const int64_t *d_off,
-                const int *d_len, const int *d_chain_off, const DevChain *d_chains, const DevSeed *d_seeds, unsigned int *d_srt, const int *d_reg_off,
-                DevReg *d_regs, int *d_nregs, const int *d_tab, int tab_stride, const uint8_t *d_pac, unsigned long long *d_counters,
+                const int *d_len, const int *d_chain_beg, const int *d_chain_cnt, const DevChain *d_chains, const DevSeed *d_seeds, unsigned int *d_srt,
+                const int *d_reg_beg, DevReg *d_regs, int *d_nregs, const int *d_tab, int tab_stride, const uint8_t *d_pac, unsigned long long *d_counters,
                 int max_len)
 {
 	WxParams X;
@@ -222,7 +223,7 @@ void launch_c2a(void *stream, const C2aParams &P, const ExtParams &ep, int n_rea
 	size_t shmem = (size_t)C2A_WAVES * 2 * (max_len + 2) * sizeof(int);
 	int n_blocks = (n_reads + C2A_WAVES - 1) / C2A_WAVES;
 	hipLaunchKernelGGL(c2a_kernel, dim3(n_blocks), dim3(64 * C2A_WAVES), shmem, (hipStream_t)stream, P, X, n_reads, d_seq, d_off,
-	                   d_len, d_chain_off, d_chains, d_seeds, d_srt, d_reg_off, d_regs, d_nregs, d_tab, tab_stride, d_pac, d_counters,
+	                   d_len, d_chain_beg, d_chain_cnt, d_chains, d_seeds, d_srt, d_reg_beg, d_regs, d_nregs, d_tab, tab_stride, d_pac, d_counters,
 	                   max_len);
 }
 

@@ -54,8 +54,8 @@ enum { ST_CHAIN = 0, ST_SEED, ST_RIGHT, ST_EXT_DONE, ST_FIN, ST_FETCH = 99, ST_R
 
 __global__ void __launch_bounds__(64)
 c2a_lane_kernel(C2aParams P, LxParams X, int n_reads, const uint8_t *__restrict__ seq, const int64_t *__restrict__ off,
-                const int *__restrict__ lens, const int *__restrict__ chain_off, const DevChain *__restrict__ chains,
-                const DevSeed *__restrict__ seeds, unsigned int *srt, const int *__restrict__ reg_off, DevReg *regs, int *n_regs,
+                const int *__restrict__ lens, const int *__restrict__ chain_beg, const int *__restrict__ chain_cnt, const DevChain *__restrict__ chains,
+                const DevSeed *__restrict__ seeds, unsigned int *srt, const int *__restrict__ reg_beg, DevReg *regs, int *n_regs,
                 const int *__restrict__ tab, int tab_stride, const uint8_t *__restrict__ pac, unsigned long long *counters)
 {
 	extern __shared__ uint32_t cell[];   // [max_len + 5][64]
@@ -191,9 +191,9 @@ c2a_lane_kernel(C2aParams P, LxParams X, int n_reads, const uint8_t *__restrict_
 			}
 			if (st == ST_FETCH) {
 				lq = lens[rd];
-				av = regs + reg_off[rd];
+				av = regs + reg_beg[rd];
 				nav = 0;
-				ci = chain_off[rd]; ci_end = chain_off[rd + 1];
+				ci = chain_beg[rd]; ci_end = ci + (chain_cnt[rd] > 0 ? chain_cnt[rd] : 0);
 				st = ST_CHAIN;
 			}
 		}
@@ -350,8 +350,8 @@ bool c2a_lane_fits(int max_len, int a)
 }
 
 void launch_c2a_lane(void *stream, const C2aParams &P, const ExtParams &ep, int n_reads, const uint8_t *d_seq, const int64_t *d_off,
-                     const int *d_len, const int *d_chain_off, const DevChain *d_chains, const DevSeed *d_seeds, unsigned int *d_srt,
-                     const int *d_reg_off, DevReg *d_regs, int *d_nregs, const int *d_tab, int tab_stride, const uint8_t *d_pac,
+                     const int *d_len, const int *d_chain_beg, const int *d_chain_cnt, const DevChain *d_chains, const DevSeed *d_seeds,
+                     unsigned int *d_srt, const int *d_reg_beg, DevReg *d_regs, int *d_nregs, const int *d_tab, int tab_stride, const uint8_t *d_pac,
                      unsigned long long *d_counters, int max_len)
 {
 	if (n_reads <= 0) return;
@@ -377,8 +377,8 @@ void launch_c2a_lane(void *stream, const C2aParams &P, const ExtParams &ep, int 
 	const int per_cu = (int)std::max<size_t>(1, (160 * 1024) / lds);
 	int blocks = s_cus * per_cu;                       // persistent: as many waves as fit at once
 	blocks = std::min(blocks, (n_reads + 63) / 64);
-	hipLaunchKernelGGL(c2a_lane_kernel, dim3(blocks), dim3(64), lds, (hipStream_t)stream, P, X, n_reads, d_seq, d_off, d_len, d_chain_off,
-	                   d_chains, d_seeds, d_srt, d_reg_off, d_regs, d_nregs, d_tab, tab_stride, d_pac, d_counters);
+	hipLaunchKernelGGL(c2a_lane_kernel, dim3(blocks), dim3(64), lds, (hipStream_t)stream, P, X, n_reads, d_seq, d_off, d_len, d_chain_beg, d_chain_cnt,
+	                   d_chains, d_seeds, d_srt, d_reg_beg, d_regs, d_nregs, d_tab, tab_stride, d_pac, d_counters);
 	HIP_OK(hipGetLastError());
 }
 

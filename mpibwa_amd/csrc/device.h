@@ -92,15 +92,32 @@ struct C2aParams {
 	int a, w, pen_clip5, pen_clip3;
 };
 void launch_c2a(void *stream, const C2aParams &P, const ExtParams &ep, int n_reads, const uint8_t *d_seq, const int64_t *d_off,
-                const int *d_len, const int *d_chain_off, const DevChain *d_chains, const DevSeed *d_seeds, unsigned int *d_srt, const int *d_reg_off,
-                DevReg *d_regs, int *d_nregs, const int *d_tab, int tab_stride, const uint8_t *d_pac, unsigned long long *d_counters,
+                const int *d_len, const int *d_chain_beg, const int *d_chain_cnt, const DevChain *d_chains, const DevSeed *d_seeds, unsigned int *d_srt,
+                const int *d_reg_beg, DevReg *d_regs, int *d_nregs, const int *d_tab, int tab_stride, const uint8_t *d_pac, unsigned long long *d_counters,
                 int max_len);
+
+// ---- seeds -> chains -> filtered chains on the device (chain_kernel.hip) ----
+struct ChainParams {
+	int64_t l_pac;
+	int w, max_chain_gap, min_chain_weight, min_seed_len, max_chain_extend;
+	float mask_level, drop_ratio;
+};
+// Per read r: chains / seeds / order are written at index seed_off[r] onwards (a read never keeps more seeds or chains
+// than it had seeds); n_chains[r] = number of kept chains, or -1 when the read needs the host path (more than 9 chains,
+// more than 64 seeds, or long enough for mem_flt_chained_seeds).  d_tab: the length tables of c2a + row 5 = "flt is a no-op".
+void launch_chain(void *stream, const ChainParams &P, int n_reads, const int *d_len, const int *d_nseeds, const int *d_lrep,
+                  const int64_t *d_seed_off, const uint64_t *d_sa, const int32_t *d_qbl, const int64_t *d_ann_off, const uint8_t *d_ann_alt,
+                  int n_seqs, const int *d_tab, int tab_stride, DevChain *d_chains, DevSeed *d_seeds, unsigned int *d_srt, int *d_nchains);
+
+size_t reg_pack_tmp_bytes(int n_reads);
+void launch_reg_pack(void *stream, int n_reads, const int *d_reg_beg, const int *d_nregs, int *d_reg_pos, const DevReg *d_regs, DevReg *d_packed,
+                     void *d_tmp, size_t tmp_bytes);
 
 // lane-per-read variant (c2a_lane.hip), same contract; needs counters[2] = 0 (next read) and scores below 2^13
 bool c2a_lane_fits(int max_len, int a);
 void launch_c2a_lane(void *stream, const C2aParams &P, const ExtParams &ep, int n_reads, const uint8_t *d_seq, const int64_t *d_off,
-                     const int *d_len, const int *d_chain_off, const DevChain *d_chains, const DevSeed *d_seeds, unsigned int *d_srt,
-                     const int *d_reg_off, DevReg *d_regs, int *d_nregs, const int *d_tab, int tab_stride, const uint8_t *d_pac,
+                     const int *d_len, const int *d_chain_beg, const int *d_chain_cnt, const DevChain *d_chains, const DevSeed *d_seeds,
+                     unsigned int *d_srt, const int *d_reg_beg, DevReg *d_regs, int *d_nregs, const int *d_tab, int tab_stride, const uint8_t *d_pac,
                      unsigned long long *d_counters, int max_len);
 
 // ---- final global re-alignment on the device (aln_kernel.hip) ----

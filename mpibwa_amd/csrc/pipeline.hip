@@ -188,6 +188,9 @@ struct PinBuf {
 };
 
 struct Workspace {
+	PinBuf h_nch, h_cbeg, h_ccnt, h_rbeg, h_nseeds, h_lrep, h_nintv;
+	DevBuf nch, chain_cnt, reg_pos, regs_packed, ann_off, ann_alt, pack_tmp;
+	PinBuf h_regs2;
 	PinBuf h_flat, h_sa, h_qbl, h_chains, h_seeds, h_srt, h_regs, h_nregs, h_mreq[2], h_mres[2], h_ahdr[2], h_apool[2];
 	DevBuf mreq[2], mres[2], mrows[2];
 	DevBuf seq, off, len, intv, nintv, cnt, scratch, nseeds, lrep, seed_off, rows, qbl, sa;
@@ -276,6 +279,15 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	HIP_OK(hipMemcpyAsync(d_len, lens.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
 	HIP_OK(hipStreamSynchronize(st));
 	unsigned long long *d_cnt = (unsigned long long *)W.cnt.ensure(256);
+	// contig table for the chaining kernel: start of every contig (+ l_pac) and its ALT flag
+	std::vector<int64_t> ann_off(bns->n_seqs + 1);
+	std::vector<uint8_t> ann_alt(bns->n_seqs + 1, 0);
+	for (int k = 0; k < bns->n_seqs; ++k) { ann_off[k] = bns->anns[k].offset; ann_alt[k] = bns->anns[k].is_alt ? 1 : 0; }
+	ann_off[bns->n_seqs] = bns->l_pac;
+	int64_t *d_ann_off = (int64_t *)W.ann_off.ensure(ann_off.size() * 8);
+	uint8_t *d_ann_alt = (uint8_t *)W.ann_alt.ensure(ann_alt.size());
+	HIP_OK(hipMemcpy(d_ann_off, ann_off.data(), ann_off.size() * 8, hipMemcpyHostToDevice));
+	HIP_OK(hipMemcpy(d_ann_alt, ann_alt.data(), ann_alt.size(), hipMemcpyHostToDevice));
 
 	// ---- 2-6. seeding -> SA -> chaining -> extension -> region clean-up, on one or two sub-batches ----
 	// The stages of one sub-batch are strictly dependent (GPU, host, GPU, host), so two sub-batches run on two host
@@ -302,6 +314,24 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		EvTimer ev_smem, ev_sa, ev_ext;
 		unsigned long long *d_cnt = (unsigned long long *)W.cnt.ensure(256);
 		unsigned long long cnt[8];
+		std::vector<int> gap_h(max_len + 2);
+		for (int l = 0; l < max_len + 2; ++l) gap_h[l] = cal_max_gap(opt, l);
+		// length tables for the device (the floating-point decisions of the reference, resolved per length on the host)
+		const int TS = max_len + 2;
+		std::vector<int> tab(6 * TS);
+		for (int l = 0; l < TS; ++l) {
+			tab[l] = gap_h[l];
+			tab[TS + l] = clamp_band(opt, l, 1 << 28, opt->pen_clip5);
+			tab[2 * TS + l] = clamp_band(opt, l, 1 << 28, opt->pen_clip3);
+			tab[3 * TS + l] = (int)ceil(l * .95);
+			tab[4 * TS + l] = (int)floor(.1 * l);
+			// mem_flt_chained_seeds returns at once for this length (src/bwamem.c:600-602)
+			const double min_l = opt->min_chain_weight ? 1.1f * opt->min_chain_weight : 5.5f * log(l > 0 ? l : 1);
+			tab[5 * TS + l] = (l > 0 && min_l > 0.05f * l) ? 1 : 0;
+		}
+		int *d_tab = (int *)W.tab.ensure(tab.size() * 4);
+		HIP_OK(hipMemcpyAsync(d_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, st));
+
 		double t1 = now_ms();
 		uint64_t range_bases = 0;
 		for (int i = 0; i < n; ++i) range_bases += lens[lo + i];
@@ -312,6 +342,9 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		const bool lane_k = smem_use_lane();
 		int n_quads = lane_k ? smem_lane_grid(max_len, &per_quad) : smem_grid_quads(max_len, &per_quad);
 		void *d_scr = W.scratch.ensure(per_quad * n_quads);
+		int *d_nseeds = (int *)W.nseeds.ensure((size_t)n * 4), *d_lrep = (int *)W.lrep.ensure((size_t)n * 4);
+		int *nseeds = (int *)W.h_nseeds.ensure((size_t)n * 4 + 8), *lrep = (int *)W.h_lrep.ensure((size_t)n * 4 + 8);
+		int *nintv = (int *)W.h_nintv.ensure((size_t)n * 4 + 8);
 		for (;;) {
 			d_intv = (uint64_t *)W.intv.ensure((size_t)n * cap * 32);
 			d_nintv = (int *)W.nintv.ensure((size_t)n * 4);
@@ -323,7 +356,12 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			if (lane_k) launch_smem_lane(st, ix.fm, smem_params(opt), n, d_seq, d_off_r, d_len_r, cap, d_intv, d_nintv, d_cnt, d_scr, per_quad, n_quads);
 			else launch_smem(st, ix.fm, smem_params(opt), n, d_seq, d_off_r, d_len_r, cap, d_intv, d_nintv, max_len, d_cnt, d_scr, per_quad, n_quads);
 			ev_smem.stop(st);
+			// seed bookkeeping queued right behind it (src/bwamem.c:265-283): one host round trip for both
+			launch_seed_prep(st, n, cap, d_intv, d_nintv, opt->max_occ, d_nseeds, d_lrep);
 			HIP_OK(hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, st));
+			HIP_OK(hipMemcpyAsync(nseeds, d_nseeds, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+			HIP_OK(hipMemcpyAsync(lrep, d_lrep, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+			HIP_OK(hipMemcpyAsync(nintv, d_nintv, (size_t)n * 4, hipMemcpyDeviceToHost, st));
 			stream_wait(st);
 			HIP_OK(hipGetLastError());
 			turn.unlock();
@@ -334,14 +372,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		ps.smem_bytes = cnt[1] * 64 + range_bases;
 		double t2 = now_ms();
 
-		// seed enumeration + SA lookup
-		int *d_nseeds = (int *)W.nseeds.ensure((size_t)n * 4), *d_lrep = (int *)W.lrep.ensure((size_t)n * 4);
-		launch_seed_prep(st, n, cap, d_intv, d_nintv, opt->max_occ, d_nseeds, d_lrep);
-		std::vector<int> nseeds(n), lrep(n), nintv(n);
-		HIP_OK(hipMemcpyAsync(nseeds.data(), d_nseeds, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-		HIP_OK(hipMemcpyAsync(lrep.data(), d_lrep, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-		HIP_OK(hipMemcpyAsync(nintv.data(), d_nintv, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-		stream_wait(st);
+		// seed enumeration + SA lookup (+ chaining on the device)
 		std::vector<int64_t> seed_off(n + 1);
 		seed_off[0] = 0;
 		uint64_t n_intv = 0;
@@ -351,6 +382,12 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		ps.n_intv = n_intv; ps.n_seeds = S;
 		uint64_t *sa = (uint64_t *)W.h_sa.ensure((size_t)S * 8 + 8);
 		int32_t *qbl = (int32_t *)W.h_qbl.ensure((size_t)S * 8 + 8);
+		// Chaining on the device for the reads whose ordered map stays a single B-tree node (chain_kernel.hip); the
+		// others (n_chains = -1: ~2 % on 2x150 bp) and, with MPIBWA_HOST_CHAIN=1, all reads are chained by the host below.
+		const bool host_chain_all = getenv("MPIBWA_HOST_CHAIN") != nullptr;
+		const bool dev_chain = !host_chain_all && S > 0;
+		int *nch = nullptr;               // device mode: chains kept per read (-1 = host)
+		DevChain *d_chains = nullptr; DevSeed *d_seeds = nullptr; unsigned int *d_srt = nullptr;
 		if (S > 0) {
 			int64_t *d_seed_off = (int64_t *)W.seed_off.ensure((size_t)(n + 1) * 8);
 			uint64_t *d_rows = (uint64_t *)W.rows.ensure((size_t)S * 8), *d_sa = (uint64_t *)W.sa.ensure((size_t)S * 8);
@@ -363,6 +400,21 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			if (ix.fm.sa_full) launch_sa_dense(st, ix.fm, (int)S, d_rows, d_sa);   // one 8-byte load per row
 			else launch_sa(st, ix.fm, (int)S, d_rows, d_sa, d_cnt);                // LF walk on the sampled SA
 			ev_sa.stop(st);
+			if (dev_chain) {   // queued right behind the SA lookup: one host round trip for both
+				// (room for the tail the host appends: its reads cannot keep more seeds than the S they had)
+				d_chains = (DevChain *)W.chains.ensure((size_t)2 * S * sizeof(DevChain));
+				d_seeds = (DevSeed *)W.seeds.ensure((size_t)2 * S * sizeof(DevSeed));
+				d_srt = (unsigned int *)W.srt.ensure((size_t)2 * S * 4);
+				int *d_nch = (int *)W.nch.ensure((size_t)n * 4);
+				ChainParams kp;
+				kp.l_pac = bns->l_pac; kp.w = opt->w; kp.max_chain_gap = opt->max_chain_gap; kp.min_chain_weight = opt->min_chain_weight;
+				kp.min_seed_len = opt->min_seed_len; kp.max_chain_extend = opt->max_chain_extend;
+				kp.mask_level = opt->mask_level; kp.drop_ratio = opt->drop_ratio;
+				launch_chain(st, kp, n, d_len_r, d_nseeds, d_lrep, d_seed_off, d_sa, d_qbl, d_ann_off, d_ann_alt, bns->n_seqs, d_tab, TS, d_chains, d_seeds,
+				             d_srt, d_nch);
+				nch = (int *)W.h_nch.ensure((size_t)n * 4 + 8);
+				HIP_OK(hipMemcpyAsync(nch, d_nch, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+			}
 			HIP_OK(hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, st));
 			HIP_OK(hipMemcpyAsync(sa, d_sa, (size_t)S * 8, hipMemcpyDeviceToHost, st));
 			HIP_OK(hipMemcpyAsync(qbl, d_qbl, (size_t)S * 8, hipMemcpyDeviceToHost, st));
@@ -378,12 +430,19 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 
 		// chaining and chain filters (host).  Each block of reads is chained by one thread with recycled scratch and packed
 		// straight into the device layout (block-local offsets); the blocks are then concatenated after a prefix sum.
-		std::vector<int> gap_h(max_len + 2);
-		for (int l = 0; l < max_len + 2; ++l) gap_h[l] = cal_max_gap(opt, l);
-		const int CB = 256, n_cb = (n + CB - 1) / CB;
+		std::vector<int> todo;            // reads chained by the host
+		if (dev_chain) {
+			for (int i = 0; i < n; ++i)
+				if (nch[i] < 0) todo.push_back(i);
+		} else {
+			todo.resize(n);
+			for (int i = 0; i < n; ++i) todo[i] = i;
+		}
+		const int n_todo = (int)todo.size();
+		const int CB = 256, n_cb = (n_todo + CB - 1) / CB;
 		struct BlockOut { std::vector<DevChain> ch; std::vector<DevSeed> sd; std::vector<unsigned int> srt; };
 		std::vector<BlockOut> bo(n_cb);
-		std::vector<int> chain_off(n + 1), reg_off(n + 1);
+		std::vector<int> chain_off(n_todo + 1), reg_off(n_todo + 1);   // per entry of `todo`
 		{
 			const int nt = std::max(1, n_thr);
 			std::vector<std::unique_ptr<ChainScratch>> scr(nt);
@@ -392,17 +451,19 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			std::vector<std::vector<uint64_t>> keyv(nt);
 			static const bool prof_chain = getenv("MPIBWA_CPUSEC") != nullptr;
 			std::vector<unsigned long long> tsc((size_t)nt * 8, 0);
-			parallel_blocks(nt, n, CB, [&](int tid, int b, int lo, int hi) {
+			parallel_blocks(nt, n_todo, CB, [&](int tid, int b, int lo, int hi) {
 				if (!scr[tid]) scr[tid].reset(new ChainScratch());
 				std::vector<HSeed> &hs = hsv[tid];
 				std::vector<HChain *> &chains = chv[tid];
 				std::vector<uint64_t> &key = keyv[tid];
 				BlockOut &o = bo[b];
-				int64_t est = seed_off[hi] - seed_off[lo];
+				int64_t est = 0;
+				for (int t = lo; t < hi; ++t) est += nseeds[todo[t]];
 				o.sd.reserve(est); o.srt.reserve(est); o.ch.reserve((hi - lo) * 2);
-				for (int i = lo; i < hi; ++i) {
+				for (int t = lo; t < hi; ++t) {
+					const int i = todo[t];
 					int ns = nseeds[i];
-					chain_off[i + 1] = reg_off[i + 1] = 0;
+					chain_off[t + 1] = reg_off[t + 1] = 0;
 					if (ns == 0) continue;
 					const unsigned long long c0 = prof_chain ? __builtin_ia32_rdtsc() : 0;
 					hs.resize(ns);
@@ -470,8 +531,8 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 						o.ch.push_back(d);
 						tot += cs;
 					}
-					chain_off[i + 1] = (int)chains.size();
-					reg_off[i + 1] = tot;
+					chain_off[t + 1] = (int)chains.size();
+					reg_off[t + 1] = tot;
 					if (prof_chain) tsc[tid * 8 + 4] += __builtin_ia32_rdtsc() - c4;
 				}
 			});
@@ -483,52 +544,60 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			}
 		}
 		chain_off[0] = reg_off[0] = 0;
-		for (int i = 0; i < n; ++i) { chain_off[i + 1] += chain_off[i]; reg_off[i + 1] += reg_off[i]; }
-		const int NC = chain_off[n], NS = reg_off[n];
-		ps.n_chains = NC;
+		for (int t = 0; t < n_todo; ++t) { chain_off[t + 1] += chain_off[t]; reg_off[t + 1] += reg_off[t]; }
+		const int NC = chain_off[n_todo], NS = reg_off[n_todo];   // chains / kept seeds of the host-chained reads
+		// Device layout.  Host mode: dense arrays.  Device mode: read r owns slots seed_off[r].. of all three arrays, and what
+		// the host chained is appended behind the S seed slots.
+		const int64_t base = dev_chain ? S : 0;
 		DevChain *hchains = (DevChain *)W.h_chains.ensure((size_t)NC * sizeof(DevChain) + 8);
 		DevSeed *hseeds = (DevSeed *)W.h_seeds.ensure((size_t)NS * sizeof(DevSeed) + 8);
 		unsigned int *hsrt = (unsigned int *)W.h_srt.ensure((size_t)NS * 4 + 8);
-		parallel_blocks(n_thr, n, CB, [&](int, int b, int lo, int) {
+		parallel_blocks(n_thr, n_todo, CB, [&](int, int b, int lo, int) {
 			BlockOut &o = bo[b];
 			const int c0 = chain_off[lo], s0 = reg_off[lo];
-			for (size_t c = 0; c < o.ch.size(); ++c) { hchains[c0 + c] = o.ch[c]; hchains[c0 + c].seed_beg += s0; }
+			for (size_t c = 0; c < o.ch.size(); ++c) { hchains[c0 + c] = o.ch[c]; hchains[c0 + c].seed_beg += (int)(base + s0); }
 			if (!o.sd.empty()) {
 				memcpy((void *)(hseeds + s0), (const void *)o.sd.data(), o.sd.size() * sizeof(DevSeed));
 				memcpy(hsrt + s0, o.srt.data(), o.srt.size() * 4);
 			}
 			BlockOut().ch.swap(o.ch); std::vector<DevSeed>().swap(o.sd); std::vector<unsigned int>().swap(o.srt);
 		});
+		if (base + NS > 0x7fffffff || base + NC > 0x7fffffff) die("too many seeds in one batch");
+		int *chain_beg = (int *)W.h_cbeg.ensure((size_t)n * 4 + 8), *chain_cnt = (int *)W.h_ccnt.ensure((size_t)n * 4 + 8);
+		int *reg_beg = (int *)W.h_rbeg.ensure((size_t)n * 4 + 8);
+		uint64_t n_chains_total = NC;
+		if (dev_chain) {
+			for (int i = 0; i < n; ++i) { chain_beg[i] = reg_beg[i] = (int)seed_off[i]; chain_cnt[i] = nch[i] > 0 ? nch[i] : 0; n_chains_total += chain_cnt[i]; }
+		} else memset(chain_cnt, 0, (size_t)n * 4);
+		for (int t = 0; t < n_todo; ++t) {
+			const int i = todo[t];
+			chain_beg[i] = (int)(base + chain_off[t]); chain_cnt[i] = chain_off[t + 1] - chain_off[t]; reg_beg[i] = (int)(base + reg_off[t]);
+		}
+		ps.n_chains = n_chains_total;
+		const int64_t n_slots = base + NS;    // size of the seed / order / region arrays on the device
 		double t4 = now_ms();
 		if (g_host_turns) host_turn.unlock();
 
 		// chain -> regions on the GPU
-		DevReg *hregs = (DevReg *)W.h_regs.ensure((size_t)NS * sizeof(DevReg) + 8);
 		int *nregs = (int *)W.h_nregs.ensure((size_t)n * 4 + 8);
-		if (NS == 0) memset(nregs, 0, (size_t)n * 4);
-		if (NS > 0) {
-			const int TS = max_len + 2;
-			std::vector<int> tab(5 * TS);
-			for (int l = 0; l < TS; ++l) {
-				tab[l] = cal_max_gap(opt, l);
-				tab[TS + l] = clamp_band(opt, l, 1 << 28, opt->pen_clip5);
-				tab[2 * TS + l] = clamp_band(opt, l, 1 << 28, opt->pen_clip3);
-				tab[3 * TS + l] = (int)ceil(l * .95);
-				tab[4 * TS + l] = (int)floor(.1 * l);
-			}
-			int *d_tab = (int *)W.tab.ensure(tab.size() * 4);
-			int *d_chain_off = (int *)W.chain_off.ensure((size_t)(n + 1) * 4), *d_reg_off = (int *)W.reg_off.ensure((size_t)(n + 1) * 4);
-			DevChain *d_chains = (DevChain *)W.chains.ensure((size_t)std::max(NC, 1) * sizeof(DevChain));
-			DevSeed *d_seeds = (DevSeed *)W.seeds.ensure((size_t)NS * sizeof(DevSeed));
-			unsigned int *d_srt = (unsigned int *)W.srt.ensure((size_t)NS * 4);
-			DevReg *d_regs = (DevReg *)W.regs.ensure((size_t)NS * sizeof(DevReg));
-			int *d_nregs = (int *)W.nregs.ensure((size_t)n * 4);
-			HIP_OK(hipMemcpyAsync(d_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, st));
-			HIP_OK(hipMemcpyAsync(d_chain_off, chain_off.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, st));
-			HIP_OK(hipMemcpyAsync(d_reg_off, reg_off.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, st));
-			HIP_OK(hipMemcpyAsync(d_chains, hchains, (size_t)NC * sizeof(DevChain), hipMemcpyHostToDevice, st));
-			HIP_OK(hipMemcpyAsync(d_seeds, hseeds, (size_t)NS * sizeof(DevSeed), hipMemcpyHostToDevice, st));
-			HIP_OK(hipMemcpyAsync(d_srt, hsrt, (size_t)NS * 4, hipMemcpyHostToDevice, st));
+		std::vector<int> reg_pos(n + 1, 0);   // where the regions of read i start in hregs
+		DevReg *hregs = nullptr;
+		if (n_slots == 0) memset(nregs, 0, (size_t)n * 4);
+		else {
+			int *d_chain_beg = (int *)W.chain_off.ensure((size_t)n * 4), *d_chain_cnt = (int *)W.chain_cnt.ensure((size_t)n * 4);
+			int *d_reg_beg = (int *)W.reg_off.ensure((size_t)n * 4);
+			// (device mode: already sized 2 S above, so these calls never move what chain_kernel wrote)
+			d_chains = (DevChain *)W.chains.ensure((size_t)std::max<int64_t>(base + NC, 1) * sizeof(DevChain));
+			d_seeds = (DevSeed *)W.seeds.ensure((size_t)n_slots * sizeof(DevSeed));
+			d_srt = (unsigned int *)W.srt.ensure((size_t)n_slots * 4);
+			DevReg *d_regs = (DevReg *)W.regs.ensure((size_t)n_slots * sizeof(DevReg));
+			int *d_nregs = (int *)W.nregs.ensure((size_t)(n + 1) * 4);
+			HIP_OK(hipMemcpyAsync(d_chain_beg, chain_beg, (size_t)n * 4, hipMemcpyHostToDevice, st));
+			HIP_OK(hipMemcpyAsync(d_chain_cnt, chain_cnt, (size_t)n * 4, hipMemcpyHostToDevice, st));
+			HIP_OK(hipMemcpyAsync(d_reg_beg, reg_beg, (size_t)n * 4, hipMemcpyHostToDevice, st));
+			if (NC) HIP_OK(hipMemcpyAsync(d_chains + base, hchains, (size_t)NC * sizeof(DevChain), hipMemcpyHostToDevice, st));
+			if (NS) HIP_OK(hipMemcpyAsync(d_seeds + base, hseeds, (size_t)NS * sizeof(DevSeed), hipMemcpyHostToDevice, st));
+			if (NS) HIP_OK(hipMemcpyAsync(d_srt + base, hsrt, (size_t)NS * 4, hipMemcpyHostToDevice, st));
 			HIP_OK(hipMemsetAsync(d_cnt, 0, 256, st));
 			C2aParams cp;
 			cp.l_pac = bns->l_pac; cp.a = opt->a; cp.w = opt->w; cp.pen_clip5 = opt->pen_clip5; cp.pen_clip3 = opt->pen_clip3;
@@ -540,20 +609,37 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			const char *c2a_env = getenv("MPIBWA_C2A");
 			const bool lane_c2a = c2a_env && !strcmp(c2a_env, "lane");   // experimental mapping, slower so far
 			if (lane_c2a && c2a_lane_fits(max_len, opt->a))      // one lane per read
-				launch_c2a_lane(st, cp, ep, n, d_seq, d_off_r, d_len_r, d_chain_off, d_chains, d_seeds, d_srt, d_reg_off, d_regs, d_nregs, d_tab, TS,
-				                (const uint8_t *)ix.d_pac, d_cnt, max_len);
+				launch_c2a_lane(st, cp, ep, n, d_seq, d_off_r, d_len_r, d_chain_beg, d_chain_cnt, d_chains, d_seeds, d_srt, d_reg_beg, d_regs, d_nregs,
+				                d_tab, TS, (const uint8_t *)ix.d_pac, d_cnt, max_len);
 			else                                                 // one wavefront per read (any read length)
-				launch_c2a(st, cp, ep, n, d_seq, d_off_r, d_len_r, d_chain_off, d_chains, d_seeds, d_srt, d_reg_off, d_regs, d_nregs, d_tab, TS,
-				           (const uint8_t *)ix.d_pac, d_cnt, max_len);
+				launch_c2a(st, cp, ep, n, d_seq, d_off_r, d_len_r, d_chain_beg, d_chain_cnt, d_chains, d_seeds, d_srt, d_reg_beg, d_regs, d_nregs,
+				           d_tab, TS, (const uint8_t *)ix.d_pac, d_cnt, max_len);
 			ev_ext.stop(st);
+			// the regions sit in sparse per-read slots: prefix-sum + pack on the device, queued behind the kernel, then one
+			// copy of what is usually enough (2 regions per read); the rare rest follows once the total is known
+			int *d_reg_pos = (int *)W.reg_pos.ensure((size_t)(n + 1) * 4);
+			const int64_t guess = std::min<int64_t>(n_slots, (int64_t)2 * n + 1024);
+			DevReg *d_packed = (DevReg *)W.regs_packed.ensure((size_t)n_slots * sizeof(DevReg));
+			const size_t tmp_bytes = reg_pack_tmp_bytes(n);
+			void *d_tmp = W.pack_tmp.ensure(tmp_bytes);
+			launch_reg_pack(st, n, d_reg_beg, d_nregs, d_reg_pos, d_regs, d_packed, d_tmp, tmp_bytes);
+			hregs = (DevReg *)W.h_regs.ensure((size_t)guess * sizeof(DevReg) + 8);
 			HIP_OK(hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, st));
-			HIP_OK(hipMemcpyAsync(hregs, d_regs, (size_t)NS * sizeof(DevReg), hipMemcpyDeviceToHost, st));
 			HIP_OK(hipMemcpyAsync(nregs, d_nregs, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+			HIP_OK(hipMemcpyAsync(hregs, d_packed, (size_t)guess * sizeof(DevReg), hipMemcpyDeviceToHost, st));
 			stream_wait(st);
 			HIP_OK(hipGetLastError());
 			turn.unlock();
 			ps.k_ext = ev_ext.ms();
 			ps.cells = cnt[0]; ps.n_ext = cnt[1];
+			for (int i = 0; i < n; ++i) reg_pos[i + 1] = reg_pos[i] + nregs[i];
+			const int64_t NR = reg_pos[n];
+			if (NR > guess) {
+				DevReg *all = (DevReg *)W.h_regs2.ensure((size_t)NR * sizeof(DevReg) + 8);
+				HIP_OK(hipMemcpyAsync(all, d_packed, (size_t)NR * sizeof(DevReg), hipMemcpyDeviceToHost, st));
+				stream_wait(st);
+				hregs = all;
+			}
 		}
 		if (g_host_turns) host_turn.lock();
 		double t5 = now_ms();
@@ -570,7 +656,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			v.attach(arena + slice[i], (uint32_t)(m + SLACK));
 			v.resize(m);
 			for (int k = 0; k < m; ++k) {
-				const DevReg &d = hregs[reg_off[i] + k];
+				const DevReg &d = hregs[reg_pos[i] + k];
 				HReg &r = v[k];
 				r.rb = d.rb; r.re = d.re; r.qb = d.qb; r.qe = d.qe; r.rid = d.rid; r.score = d.score; r.truesc = d.truesc;
 				r.w = d.w; r.seedcov = d.seedcov; r.seedlen0 = d.seedlen0; r.frac_rep = d.frac_rep;

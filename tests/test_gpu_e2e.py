@@ -164,6 +164,9 @@ def test_overlapped_sub_batches_and_host_cigar_paths(both, reads_pe, monkeypatch
     assert eng.process(eng.opt(flag=abi.MEM_F_PE), ra) == want
     monkeypatch.setenv("MPIBWA_SMEM", "lane")
     assert eng.process(eng.opt(flag=abi.MEM_F_PE), ra) == want
+    monkeypatch.setenv("MPIBWA_HOST_CHAIN", "1")    # chaining of every read on the host instead of chain_kernel
+    assert eng.process(eng.opt(flag=abi.MEM_F_PE), ra) == want
+    monkeypatch.delenv("MPIBWA_HOST_CHAIN")
     monkeypatch.setenv("MPIBWA_C2A", "lane")        # chain -> region kernel: the experimental one-lane-per-read mapping
     assert eng.process(eng.opt(flag=abi.MEM_F_PE), ra) == want
     monkeypatch.delenv("MPIBWA_C2A")
