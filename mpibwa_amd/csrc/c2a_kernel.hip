@@ -54,12 +54,14 @@ __global__ void __launch_bounds__(64 * C2A_WAVES)
 c2a_kernel(C2aParams P, WxParams X, int n_reads, const uint8_t *__restrict__ seq, const int64_t *__restrict__ off,
            const int *__restrict__ lens, const int *__restrict__ chain_beg, const int *__restrict__ chain_cnt, const DevChain *__restrict__ chains,
            const DevSeed *__restrict__ seeds, unsigned int *srt, const int *__restrict__ reg_beg, DevReg *regs, int *n_regs, const int *__restrict__ tab,
-           int tab_stride, const uint8_t *__restrict__ pac, unsigned long long *counters, int max_len)
+           int tab_stride, const uint8_t *__restrict__ pac, unsigned long long *counters, int max_len, const int *__restrict__ order)
 {
 	extern __shared__ int lds[];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const int rd = blockIdx.x * C2A_WAVES + wave;
-	if (rd >= n_reads) return;
+	const int slot = blockIdx.x * C2A_WAVES + wave;
+	if (slot >= n_reads) return;
+	// reads with the most seeds are started first, so that the kernel does not end on a few long-running reads
+	const int rd = order ? order[slot] : slot;
 	int *H = lds + (size_t)wave * 2 * (max_len + 2);
 	int *E = H + (max_len + 2);
 	const int *gap = tab, *bound5 = tab + tab_stride, *bound3 = tab + 2 * tab_stride, *ceil95 = tab + 3 * tab_stride,
@@ -215,7 +217,7 @@ c2a_kernel(C2aParams P, WxParams X, int n_reads, const uint8_t *__restrict__ seq
 void launch_c2a(void *stream, const C2aParams &P, const ExtParams &ep, int n_reads, const uint8_t *d_seq, const int64_t *d_off,
                 const int *d_len, const int *d_chain_beg, const int *d_chain_cnt, const DevChain *d_chains, const DevSeed *d_seeds, unsigned int *d_srt,
                 const int *d_reg_beg, DevReg *d_regs, int *d_nregs, const int *d_tab, int tab_stride, const uint8_t *d_pac, unsigned long long *d_counters,
-                int max_len)
+                int max_len, const int *d_order)
 {
 	WxParams X;
 	for (int i = 0; i < 25; ++i) X.mat[i] = ep.mat[i];
@@ -224,7 +226,7 @@ void launch_c2a(void *stream, const C2aParams &P, const ExtParams &ep, int n_rea
 	int n_blocks = (n_reads + C2A_WAVES - 1) / C2A_WAVES;
 	hipLaunchKernelGGL(c2a_kernel, dim3(n_blocks), dim3(64 * C2A_WAVES), shmem, (hipStream_t)stream, P, X, n_reads, d_seq, d_off,
 	                   d_len, d_chain_beg, d_chain_cnt, d_chains, d_seeds, d_srt, d_reg_beg, d_regs, d_nregs, d_tab, tab_stride, d_pac, d_counters,
-	                   max_len);
+	                   max_len, d_order);
 }
 
 } // namespace mbw

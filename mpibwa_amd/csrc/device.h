@@ -94,7 +94,7 @@ struct C2aParams {
 void launch_c2a(void *stream, const C2aParams &P, const ExtParams &ep, int n_reads, const uint8_t *d_seq, const int64_t *d_off,
                 const int *d_len, const int *d_chain_beg, const int *d_chain_cnt, const DevChain *d_chains, const DevSeed *d_seeds, unsigned int *d_srt,
                 const int *d_reg_beg, DevReg *d_regs, int *d_nregs, const int *d_tab, int tab_stride, const uint8_t *d_pac, unsigned long long *d_counters,
-                int max_len);
+                int max_len, const int *d_order = nullptr);
 
 // ---- seeds -> chains -> filtered chains on the device (chain_kernel.hip) ----
 struct ChainParams {

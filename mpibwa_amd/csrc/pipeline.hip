@@ -116,6 +116,7 @@ static void parallel_blocks(int n_threads, int n, int chunk, F f)
 
 static std::mutex g_smem_turn, g_c2a_turn, g_host_turn;
 static bool g_host_turns = false;
+static bool g_one_turn = getenv("MPIBWA_ONE_TURN") != nullptr;   // experiment: big kernels never overlap each other
 
 static double now_ms()
 {
@@ -189,7 +190,8 @@ struct PinBuf {
 
 struct Workspace {
 	PinBuf h_nch, h_cbeg, h_ccnt, h_rbeg, h_nseeds, h_lrep, h_nintv;
-	DevBuf nch, chain_cnt, reg_pos, regs_packed, ann_off, ann_alt, pack_tmp;
+	DevBuf nch, chain_cnt, reg_pos, regs_packed, ann_off, ann_alt, pack_tmp, order;
+	PinBuf h_order;
 	PinBuf h_regs2;
 	PinBuf h_flat, h_sa, h_qbl, h_chains, h_seeds, h_srt, h_regs, h_nregs, h_mreq[2], h_mres[2], h_ahdr[2], h_apool[2];
 	DevBuf mreq[2], mres[2], mrows[2];
@@ -351,7 +353,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			HIP_OK(hipMemsetAsync(d_cnt, 0, 256, st));
 			// the two sub-batches take turns on the big kernels: each one fills the chip by itself, and running them one
 			// after the other staggers the sub-batches so that the host stages of one fall under the kernels of the other
-			std::unique_lock<std::mutex> turn(g_smem_turn);
+			std::unique_lock<std::mutex> turn(g_one_turn ? g_c2a_turn : g_smem_turn);
 			ev_smem.start(st);
 			if (lane_k) launch_smem_lane(st, ix.fm, smem_params(opt), n, d_seq, d_off_r, d_len_r, cap, d_intv, d_nintv, d_cnt, d_scr, per_quad, n_quads);
 			else launch_smem(st, ix.fm, smem_params(opt), n, d_seq, d_off_r, d_len_r, cap, d_intv, d_nintv, max_len, d_cnt, d_scr, per_quad, n_quads);
@@ -599,6 +601,17 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			if (NS) HIP_OK(hipMemcpyAsync(d_seeds + base, hseeds, (size_t)NS * sizeof(DevSeed), hipMemcpyHostToDevice, st));
 			if (NS) HIP_OK(hipMemcpyAsync(d_srt + base, hsrt, (size_t)NS * 4, hipMemcpyHostToDevice, st));
 			HIP_OK(hipMemsetAsync(d_cnt, 0, 256, st));
+			// launch order: reads by decreasing number of seeds (counting sort), the long-running ones first
+			int *order = (int *)W.h_order.ensure((size_t)n * 4 + 8);
+			{
+				const int NB = 1024;
+				std::vector<int> start(NB + 1, 0);
+				for (int i = 0; i < n; ++i) ++start[NB - 1 - std::min(nseeds[i], NB - 1) + 1];
+				for (int b = 0; b < NB; ++b) start[b + 1] += start[b];
+				for (int i = 0; i < n; ++i) order[start[NB - 1 - std::min(nseeds[i], NB - 1)]++] = i;
+			}
+			int *d_order = (int *)W.order.ensure((size_t)n * 4);
+			HIP_OK(hipMemcpyAsync(d_order, order, (size_t)n * 4, hipMemcpyHostToDevice, st));
 			C2aParams cp;
 			cp.l_pac = bns->l_pac; cp.a = opt->a; cp.w = opt->w; cp.pen_clip5 = opt->pen_clip5; cp.pen_clip3 = opt->pen_clip3;
 			ExtParams ep;
@@ -613,7 +626,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 				                d_tab, TS, (const uint8_t *)ix.d_pac, d_cnt, max_len);
 			else                                                 // one wavefront per read (any read length)
 				launch_c2a(st, cp, ep, n, d_seq, d_off_r, d_len_r, d_chain_beg, d_chain_cnt, d_chains, d_seeds, d_srt, d_reg_beg, d_regs, d_nregs,
-				           d_tab, TS, (const uint8_t *)ix.d_pac, d_cnt, max_len);
+				           d_tab, TS, (const uint8_t *)ix.d_pac, d_cnt, max_len, d_order);
 			ev_ext.stop(st);
 			// the regions sit in sparse per-read slots: prefix-sum + pack on the device, queued behind the kernel, then one
 			// copy of what is usually enough (2 regions per read); the rare rest follows once the total is known
