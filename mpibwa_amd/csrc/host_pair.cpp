@@ -279,7 +279,8 @@ static int pair_hits(const mem_opt_t *opt, const bntseq_t *bns, const mem_pestat
                      int z[2], int n_pri[2])
 {
 	HProf hp_(HP_PAIR);
-	std::vector<Pair64> v, u;
+	static thread_local std::vector<Pair64> v, u;   // recycled from pair to pair
+	v.clear(); u.clear();
 	int y[4], ret;
 	int64_t l_pac = bns->l_pac;
 	for (int r = 0; r < 2; ++r)
@@ -342,6 +343,8 @@ void sam_pe_plan(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, 
 	P = PairPlan();
 	if (!(opt->flag & MEM_F_NO_RESCUE)) {   // mate rescue from the best hits of each end
 		HRegV b[2];
+		HReg bbuf[2][6];   // the copies usually fit here (one or two candidates per end): no heap block per pair
+		b[0].attach(bbuf[0], 6); b[1].attach(bbuf[1], 6);
 		for (int i = 0; i < 2; ++i)
 			for (size_t j = 0; j < a[i].size(); ++j)
 				if (a[i][j].score >= a[i][0].score - opt->pen_unpaired) b[i].push_back(a[i][j]);

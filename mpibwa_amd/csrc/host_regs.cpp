@@ -135,7 +135,7 @@ int mark_primary_se(const mem_opt_t *opt, HRegV &v, int64_t id)
 	if (n == 0) return 0;
 	HProf hp_(HP_MARK);
 	HReg *a = v.data();
-	std::vector<int> z;
+	static thread_local std::vector<int> z;   // recycled from read to read
 	for (int i = 0; i < n; ++i) {
 		a[i].sub = a[i].alt_sc = 0; a[i].secondary = a[i].secondary_all = -1; a[i].hash = hash_64(id + i);
 		if (!a[i].is_alt) ++n_pri;

@@ -48,9 +48,17 @@ inline void ks_introsort(size_t n, T *a, Less lt)
 	}
 	int d = 2;
 	while ((1ul << d) < n) ++d;
+	// the reference mallocs a stack of 8 d + 2 frames; only partitions of more than 16 elements are ever pushed and the
+	// smaller side is always worked on first, so a few dozen frames cover any n — no heap traffic per sort
 	struct Frame { T *left, *right; int depth; };
-	std::vector<Frame> stack;
-	stack.reserve(sizeof(size_t) * d + 2);
+	struct FixedStack {
+		Frame f[192];
+		int n = 0;
+		void push_back(const Frame &x) { f[n++] = x; }
+		bool empty() const { return n == 0; }
+		const Frame &back() const { return f[n - 1]; }
+		void pop_back() { --n; }
+	} stack;
 	T *s = a, *t = a + (n - 1);
 	d <<= 1;
 	for (;;) {
