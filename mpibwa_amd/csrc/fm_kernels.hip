@@ -319,7 +319,11 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 
 int smem_grid_quads(int max_len, size_t *scratch_per_quad)
 {
-	int n_blocks = 256 * 4;    // 4 workgroups (40 KB LDS, 4 waves each) per CU
+	// 4 workgroups (40 KB LDS, 4 waves each) per CU fill its LDS: nothing else that needs LDS can start next to a running
+	// SMEM launch.  MPIBWA_SMEM_WG_PER_CU=3 leaves room for the small kernels of the other sub-batches.
+	static int per_cu = getenv("MPIBWA_SMEM_WG_PER_CU") ? atoi(getenv("MPIBWA_SMEM_WG_PER_CU")) : 4;
+	if (per_cu < 1 || per_cu > 4) per_cu = 4;
+	int n_blocks = 256 * per_cu;
 	size_t ent = max_len + 1 > LCAP ? (size_t)(max_len + 1 - LCAP) : 0;
 	*scratch_per_quad = (ent + 1) * sizeof(uint4);
 	return n_blocks * (SMEM_BLOCK / 4);
