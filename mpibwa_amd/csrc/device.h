@@ -17,6 +17,10 @@ struct FmDev {
 	uint64_t primary, seq_len;
 	uint64_t L2[5];
 	int sa_shift;           // log2(sa_intv)
+	// optional jump table of the third seeding pass: bi-interval after the first p3_k forward extensions of every
+	// (p3_k + 1)-mer, 32 B per entry {x0, x1, x2, blocks touched}; null if absent
+	const void *p3tab;
+	int p3_k;
 };
 
 struct DevIndex {
@@ -27,6 +31,7 @@ struct DevIndex {
 	void *d_sa = nullptr;  size_t sa_bytes = 0;
 	void *d_pac = nullptr; size_t pac_bytes = 0;
 	void *d_sa_full = nullptr; size_t sa_full_bytes = 0; double sa_expand_ms = 0;
+	void *d_p3tab = nullptr;
 	int64_t l_pac = 0;
 };
 DevIndex &dev_index();
@@ -50,6 +55,8 @@ void launch_smem(void *stream, const FmDev &fm, const SmemParams &sp, int n_read
                  unsigned long long *d_counters /* [0]=next read, [1]=blocks, [2]=overflow */,
                  void *d_scratch, size_t scratch_bytes_per_quad, int n_quads);
 int  smem_grid_quads(int max_len, size_t *scratch_per_quad);
+// fills tab (4^(k+1) entries of 32 B) with the state of bwt_seed_strategy1 after k forward extensions of every (k+1)-mer
+void launch_p3_build(void *stream, const FmDev &fm, int k, void *d_tab);
 // lane-per-read variant (smem_lane.hip); same contract
 void launch_smem_lane(void *stream, const FmDev &fm, const SmemParams &sp, int n_reads, const uint8_t *d_seq,
                       const int64_t *d_off, const int *d_len, int cap, uint64_t *d_out, int *d_nout,

@@ -68,6 +68,8 @@ static void alloc_index(const bwt_t *bwt, const bntseq_t *bns)
 	HIP_OK(hipMemset(g_idx.d_pac, 0, g_idx.pac_bytes));
 	FmDev &fm = g_idx.fm;
 	fm.blk = g_idx.d_blk; fm.sa = (const uint64_t *)g_idx.d_sa; fm.sa_full = nullptr;
+	fm.p3tab = nullptr; fm.p3_k = 0;
+	if (g_idx.d_p3tab) { (void)hipFree(g_idx.d_p3tab); g_idx.d_p3tab = nullptr; }
 	if (g_idx.d_sa_full) { (void)hipFree(g_idx.d_sa_full); g_idx.d_sa_full = nullptr; g_idx.sa_full_bytes = 0; }
 	fm.primary = bwt->primary; fm.seq_len = bwt->seq_len;
 	for (int i = 0; i < 5; ++i) fm.L2[i] = bwt->L2[i];
@@ -85,6 +87,25 @@ static void alloc_index(const bwt_t *bwt, const bntseq_t *bns)
 using namespace mbw;
 
 // Expand the sampled SA into a dense one when HBM allows it (MPIBWA_SA_DENSE=0 disables it).
+// Jump table of the third seeding pass (fm_kernels.hip): 4^13 entries x 32 B = 2.1 GB, built in a few tens of ms.
+// MPIBWA_P3TAB=0 disables it, MPIBWA_P3TAB=<k> chooses the number of extensions folded into it (default 12).
+static void maybe_build_p3()
+{
+	int k = 12;
+	if (const char *e = getenv("MPIBWA_P3TAB")) k = atoi(e);
+	if (g_idx.d_p3tab) { (void)hipFree(g_idx.d_p3tab); g_idx.d_p3tab = nullptr; g_idx.fm.p3tab = nullptr; }
+	if (k < 4 || k > 14) return;
+	const size_t bytes = ((size_t)1 << (2 * (k + 1))) * 32;
+	size_t free_b = 0, total_b = 0;
+	if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + ((size_t)16 << 30)) return;
+	HIP_OK(hipMalloc(&g_idx.d_p3tab, bytes));
+	launch_p3_build(0, g_idx.fm, k, g_idx.d_p3tab);
+	HIP_OK(hipDeviceSynchronize());
+	HIP_OK(hipGetLastError());
+	g_idx.fm.p3tab = g_idx.d_p3tab;
+	g_idx.fm.p3_k = k;
+}
+
 static void maybe_expand_sa()
 {
 	const char *e = getenv("MPIBWA_SA_DENSE");
@@ -125,6 +146,7 @@ extern "C" int mi355x_index_upload(int local_rank, const bwt_t *bwt, const bntse
 	HIP_OK(hipMemcpy(g_idx.d_sa, bwt->sa, g_idx.sa_bytes, hipMemcpyHostToDevice));
 	HIP_OK(hipMemcpy(g_idx.d_pac, pac, (size_t)bns->l_pac / 4 + 1, hipMemcpyHostToDevice));
 	maybe_expand_sa();
+	maybe_build_p3();
 	g_idx.ready = true;
 	return 0;
 }
@@ -156,6 +178,7 @@ extern "C" int mi355x_index_commit(void)
 {
 	if (!g_idx.d_blk) return -1;
 	maybe_expand_sa();
+	maybe_build_p3();
 	g_idx.ready = true;
 	return 0;
 }
@@ -164,6 +187,7 @@ extern "C" void mi355x_finalize(void)
 {
 	if (g_idx.d_blk) { (void)hipFree(g_idx.d_blk); (void)hipFree(g_idx.d_sa); (void)hipFree(g_idx.d_pac); }
 	if (g_idx.d_sa_full) (void)hipFree(g_idx.d_sa_full);
+	if (g_idx.d_p3tab) (void)hipFree(g_idx.d_p3tab);
 	g_idx = DevIndex();
 }
 

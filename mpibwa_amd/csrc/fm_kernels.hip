@@ -287,9 +287,27 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 					while (x < len && Q(x) > 3) ++x;
 					if (x >= len) pass = 4;
 					else {
-						int b = Q(x);
-						ik0 = fm.L2[b] + 1; ik2 = fm.L2[b + 1] - fm.L2[b]; ik1 = fm.L2[3 - b] + 1;
-						i = x + 1; st = ST_P3;
+						// The first min_seed_len - 1 extensions of bwt_seed_strategy1 can never emit (src/bwt.c:369: i - x >=
+						// min_len), so when the next p3_k + 1 bases are unambiguous their outcome comes from the jump table
+						// (same device function, evaluated once per k-mer at upload), blocks-touched count included.
+						bool jumped = false;
+						if (fm.p3tab && fm.p3_k < sp.min_seed_len && x + fm.p3_k < len) {
+							u32 idx = 0;
+							bool ok = true;
+							for (int t = 0; t <= fm.p3_k; ++t) { const int bt = Q(x + t); ok = ok && bt < 4; idx = idx << 2 | (u32)(bt & 3); }
+							if (ok) {
+								const u64 v = ((const u64 *)fm.p3tab)[(size_t)idx * 4 + c];   // lane c: dword pair c of the 32-byte entry
+								ik0 = __shfl(v, qlead | 0); ik1 = __shfl(v, qlead | 1); ik2 = __shfl(v, qlead | 2);
+								nblk += (u32)__shfl(v, qlead | 3);
+								i = x + fm.p3_k + 1; st = ST_P3;
+								jumped = true;
+							}
+						}
+						if (!jumped) {
+							int b = Q(x);
+							ik0 = fm.L2[b] + 1; ik2 = fm.L2[b + 1] - fm.L2[b]; ik1 = fm.L2[3 - b] + 1;
+							i = x + 1; st = ST_P3;
+						}
 					}
 				}
 			} else if (pass == 4) {   // read finished
@@ -315,6 +333,34 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 		if (__ballot(st != ST_DONE) == 0) break;
 		if (need) nblk += quad_extend(fm, back ? p0 : ik0, back ? p1 : ik1, back ? p2 : ik2, back, c, o0, o1, o2);
 	}
+}
+
+// One quad per (k+1)-mer: the forward extensions of bwt_seed_strategy1 (src/bwt.c:358-379) with the very function the
+// seeding kernel uses, so a table hit is indistinguishable from doing the steps.
+__global__ void __launch_bounds__(256) p3_build_kernel(FmDev fm, int k, u64 n_kmers, u64 *__restrict__ tab)
+{
+	const int lane = threadIdx.x & 63, c = lane & 3, qlead = lane & ~3;
+	const u64 q = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+	const bool live = q < n_kmers;
+	const u64 kmer = live ? q : 0;
+	int b = (int)(kmer >> (2 * k)) & 3;
+	u64 ik0 = fm.L2[b] + 1, ik2 = fm.L2[b + 1] - fm.L2[b], ik1 = fm.L2[3 - b] + 1;
+	u32 nblk = 0;
+	for (int t = 1; t <= k; ++t) {   // uniform trip count: DPP inside quad_extend needs all lanes of the quad
+		const int qi = (int)(kmer >> (2 * (k - t))) & 3;
+		u64 o0, o1, o2;
+		nblk += quad_extend(fm, ik0, ik1, ik2, false, c, o0, o1, o2);
+		const int csel = 3 - qi;
+		ik0 = __shfl(o0, qlead | csel); ik1 = __shfl(o1, qlead | csel); ik2 = __shfl(o2, qlead | csel);
+	}
+	if (live) tab[q * 4 + c] = c == 0 ? ik0 : c == 1 ? ik1 : c == 2 ? ik2 : (u64)nblk;
+}
+
+void launch_p3_build(void *stream, const FmDev &fm, int k, void *d_tab)
+{
+	const u64 n_kmers = 1ull << (2 * (k + 1));
+	const u64 threads = n_kmers * 4;
+	hipLaunchKernelGGL(p3_build_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fm, k, n_kmers, (u64 *)d_tab);
 }
 
 int smem_grid_quads(int max_len, size_t *scratch_per_quad)
