@@ -42,6 +42,8 @@ def main():
                     help="read pairs per step per GPU (mpiBWA -K 100000000 closes a chunk at 10^8 bases)")
     ap.add_argument("--cpu-sample-pairs", type=int, default=int(os.environ.get("MPIBWA_BENCH_CPU_PAIRS", "0")),
                     help="pairs given to the reference for the CPU baseline and the parity check (0 = the whole step batch)")
+    ap.add_argument("--read-len", type=int, default=int(os.environ.get("MPIBWA_BENCH_READ_LEN", "150")),
+                    help="read length (150 = the headline config; 250 = BASELINE config 4's shape, a parity case)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workdir", default=os.environ.get("MPIBWA_BENCH_DIR", "/tmp/mpibwa_bench"))
     args = ap.parse_args()
@@ -81,7 +83,7 @@ def main():
             (time.time() - t0, idx.l_pac, idx.blk_bytes / 1e9, idx.sa_bytes / 1e9))
 
     # ---- reads: seeded per rank, same generator as the tests (2 % unmappable, 1 % subst., 0.1 % indel) ----
-    reads = idx.simulate_pairs(args.pairs, seed=1000 + rank)
+    reads = idx.simulate_pairs(args.pairs, seed=1000 + rank, read_len=args.read_len, frag_mean=max(400.0, 2.2 * args.read_len))
     batch = abi.SeqBatch(api.libc, reads)
     cores = int(lib.mi355x_host_cpus())
     opt = eng.opt(flag=abi.MEM_F_PE, n_threads=cores)
@@ -157,7 +159,7 @@ def main():
         "value": round(value, 4), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-        "config": {"workload": "2x150 bp PE reads vs seeded synthetic %.0f Mbp reference (GRCh38 absent on the box)" % (idx.l_pac / 1e6),
+        "config": {"workload": "2x%d bp PE reads vs seeded synthetic %.0f Mbp reference (GRCh38 absent on the box)" % (args.read_len, idx.l_pac / 1e6),
                    "pairs_per_step_per_gpu": args.pairs, "reference_mbp": round(idx.l_pac / 1e6, 1),
                    "chunking": "one mem_process_seqs chunk per step (mpiBWA -K 1e8 semantics)", "parallelism": "reads sharded, 1 rank/GPU"},
         "sam_bytes_per_step": int(sam_bytes / args.steps),

@@ -15,7 +15,8 @@
 namespace mbw {
 
 #define ALN_WAVES 1
-#define ALN_ZCAP 12288       // direction bytes per wavefront
+// direction bytes per wavefront: grows with the read length (a band of ~40 columns at every row), at least 12 KB
+__host__ __device__ inline int aln_zcap(int max_len) { int z = 80 * (max_len + 32); z = (z + 255) & ~255; return z < 12288 ? 12288 : z; }
 #define ALN_MDCAP 768
 #define ALN_CIGCAP 96
 #define ALN_NEG (-0x40000000)
@@ -55,6 +56,7 @@ aln_kernel(AlnParams P, WxParams X, int n_req, const AlnReq *__restrict__ reqs, 
 	const int rq = blockIdx.x * ALN_WAVES + wave;
 	if (rq >= n_req) return;
 	// carve this wavefront's LDS
+	const int ALN_ZCAP = aln_zcap(max_len);
 	const size_t per_wave = (size_t)2 * (max_len + 2) * 4 + ((max_len + 3) & ~3) + ((tcap + 3) & ~3) + ALN_ZCAP + ALN_MDCAP + ALN_CIGCAP * 4;
 	uint8_t *base = (uint8_t *)lds_raw + (size_t)wave * per_wave;
 	AlnLds L;
@@ -264,6 +266,7 @@ aln_kernel(AlnParams P, WxParams X, int n_req, const AlnReq *__restrict__ reqs, 
 
 size_t aln_lds_per_block(int max_len, int tcap)
 {
+	const int ALN_ZCAP = aln_zcap(max_len);
 	size_t per_wave = (size_t)2 * (max_len + 2) * 4 + ((max_len + 3) & ~3) + ((tcap + 3) & ~3) + ALN_ZCAP + ALN_MDCAP + ALN_CIGCAP * 4;
 	return per_wave * ALN_WAVES;
 }
