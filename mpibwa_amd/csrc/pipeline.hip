@@ -116,7 +116,6 @@ static void parallel_blocks(int n_threads, int n, int chunk, F f)
 
 static std::mutex g_smem_turn, g_c2a_turn, g_host_turn;
 static bool g_host_turns = false;
-static bool g_one_turn = getenv("MPIBWA_ONE_TURN") != nullptr;   // experiment: big kernels never overlap each other
 
 static double now_ms()
 {
@@ -353,7 +352,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			HIP_OK(hipMemsetAsync(d_cnt, 0, 256, st));
 			// the two sub-batches take turns on the big kernels: each one fills the chip by itself, and running them one
 			// after the other staggers the sub-batches so that the host stages of one fall under the kernels of the other
-			std::unique_lock<std::mutex> turn(g_one_turn ? g_c2a_turn : g_smem_turn);
+			std::unique_lock<std::mutex> turn(g_smem_turn);
 			ev_smem.start(st);
 			if (lane_k) launch_smem_lane(st, ix.fm, smem_params(opt), n, d_seq, d_off_r, d_len_r, cap, d_intv, d_nintv, d_cnt, d_scr, per_quad, n_quads);
 			else launch_smem(st, ix.fm, smem_params(opt), n, d_seq, d_off_r, d_len_r, cap, d_intv, d_nintv, max_len, d_cnt, d_scr, per_quad, n_quads);
