@@ -136,6 +136,9 @@ __device__ __forceinline__ void list_load(const QuadList &L, int e, u64 &x0, u64
 
 enum { ST_PICK = 0, ST_FWD = 1, ST_BWD = 2, ST_P3 = 3, ST_DONE = 4 };
 
+// QLDS: every read of the launch fits its quad's LDS slot, so a base is always a plain LDS byte (otherwise the
+// accessor needs a generic pointer and every base costs a flat load)
+template <bool QLDS>
 __global__ void __launch_bounds__(SMEM_BLOCK)
 smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ seq, const int64_t *__restrict__ off,
             const int *__restrict__ lens, int cap, u64 *__restrict__ out, int *__restrict__ nout_arr, u64 *counters, uint4 *scratch,
@@ -158,7 +161,7 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 	const uint8_t *gq = seq;
 	bool q_lds = false;
 	// read base i: from the quad's LDS copy when the read fits, else from HBM
-	auto Q = [&](int i_) -> int { return q_lds ? lq[i_] : gq[i_]; };
+	auto Q = [&](int i_) -> int { return (QLDS || q_lds) ? lq[i_] : gq[i_]; };
 	u64 ik0 = 0, ik1 = 0, ik2 = 0, ik_end = 0, lastc_x2 = 0;
 	u64 p0 = 0, p1 = 0, p2 = 0, p_end = 0;   // backward: the list entry being extended
 	u64 *myout = out;
@@ -256,7 +259,7 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 				r = __shfl(r, qlead);
 				if (r >= n_reads) { st = ST_DONE; break; }
 				rd = r; gq = seq + off[r]; len = lens[r];
-				q_lds = len <= QSLOT;
+				q_lds = QLDS || len <= QSLOT;
 				if (q_lds) {   // off[] is 16-byte aligned: the quad copies the read with 16-B loads
 					const uint4 *src = (const uint4 *)gq;
 					for (int k = c; k * 16 < len; k += 4) myread[k] = src[k];
@@ -379,14 +382,18 @@ void launch_smem(void *stream, const FmDev &fm, const SmemParams &sp, int n_read
                  const int64_t *d_off, const int *d_len, int cap, uint64_t *d_out, int *d_nout, int max_len,
                  unsigned long long *d_counters, void *d_scratch, size_t scratch_bytes_per_quad, int n_quads)
 {
-	(void)max_len;
 	int n_blocks = n_quads / (SMEM_BLOCK / 4);
 	int want = (n_reads + SMEM_BLOCK / 4 - 1) / (SMEM_BLOCK / 4);
 	if (want < 1) want = 1;
 	if (n_blocks > want) n_blocks = want;
-	hipLaunchKernelGGL(smem_kernel, dim3(n_blocks), dim3(SMEM_BLOCK), 0, (hipStream_t)stream, fm, sp, n_reads, d_seq,
-	                   d_off, d_len, cap, (u64 *)d_out, d_nout, (u64 *)d_counters, (uint4 *)d_scratch,
-	                   scratch_bytes_per_quad / sizeof(uint4));
+	if (max_len <= QSLOT)
+		hipLaunchKernelGGL(smem_kernel<true>, dim3(n_blocks), dim3(SMEM_BLOCK), 0, (hipStream_t)stream, fm, sp, n_reads, d_seq,
+		                   d_off, d_len, cap, (u64 *)d_out, d_nout, (u64 *)d_counters, (uint4 *)d_scratch,
+		                   scratch_bytes_per_quad / sizeof(uint4));
+	else
+		hipLaunchKernelGGL(smem_kernel<false>, dim3(n_blocks), dim3(SMEM_BLOCK), 0, (hipStream_t)stream, fm, sp, n_reads, d_seq,
+		                   d_off, d_len, cap, (u64 *)d_out, d_nout, (u64 *)d_counters, (uint4 *)d_scratch,
+		                   scratch_bytes_per_quad / sizeof(uint4));
 }
 
 // ---------------------------------------------------------------------------
