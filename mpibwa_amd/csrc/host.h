@@ -215,7 +215,7 @@ int  approx_mapq_se(const mem_opt_t *opt, const HReg *a);
 bool gen_cigar2(const int8_t mat[25], int o_del, int e_del, int o_ins, int e_ins, int w_, int64_t l_pac, const uint8_t *pac,
                 int l_query, uint8_t *query, int64_t rb, int64_t re, int *score, std::vector<uint32_t> *cigar, std::string *md, int *NM);
 HAln reg2aln(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, int l_query, const char *query, const HReg *ar,
-             AlnCtx *ctx = nullptr, int read_idx = 0);
+             AlnCtx *ctx = nullptr, int read_idx = 0, bool need_mapq = true);
 void reg2sam(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, bseq1_t *s, HRegV &a, int extra_flag, const HAln *m,
              AlnCtx *ctx = nullptr, int read_idx = 0);
 

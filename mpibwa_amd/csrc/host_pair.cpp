@@ -422,7 +422,7 @@ void sam_pe_emit(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, 
 		int n_aa[2] = {0, 0};
 		HAln g[2];
 		for (int i = 0; i < 2; ++i) {
-			h[i] = reg2aln(opt, bns, pac, s[i].l_seq, s[i].seq, &a[i][z[i]], ctx, read0 + i);
+			h[i] = reg2aln(opt, bns, pac, s[i].l_seq, s[i].seq, &a[i][z[i]], ctx, read0 + i, false);   // MAPQ comes from the pairing
 			h[i].mapq = P.q_se[i] & 0xff;
 			h[i].flag |= 0x40 << i | P.extra_flag;
 			if (text && have_xa[i] && has[i][z[i]]) { h[i].has_xa = true; h[i].xa = xa[i][z[i]]; }

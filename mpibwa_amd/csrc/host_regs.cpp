@@ -305,7 +305,7 @@ static inline int infer_bw(int l1, int l2, int score, int a, int q, int r)
 }
 
 HAln reg2aln(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, int l_query, const char *query_, const HReg *ar,
-             AlnCtx *ctx, int read_idx)
+             AlnCtx *ctx, int read_idx, bool need_mapq)
 {
 	HProf hp_(HP_REG2ALN);
 	HAln a;
@@ -315,13 +315,14 @@ HAln reg2aln(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, int 
 	}
 	int qb = ar->qb, qe = ar->qe, is_rev, NM = -1, score = 0, last_sc = -(1 << 30);
 	int64_t rb = ar->rb, re = ar->re;
-	a.mapq = (ar->secondary < 0 ? approx_mapq_se(opt, ar) : 0) & 0xff;
+	const bool collecting = ctx && ctx->mode == AlnCtx::COLLECT;
+	if (!collecting && need_mapq) a.mapq = (ar->secondary < 0 ? approx_mapq_se(opt, ar) : 0) & 0xff;   // (logs: not needed to list the request)
 	if (ar->secondary >= 0) a.flag |= 0x100;
 	int tmp = infer_bw(qe - qb, (int)(re - rb), ar->truesc, opt->a, opt->o_del, opt->e_del);
 	int w2 = infer_bw(qe - qb, (int)(re - rb), ar->truesc, opt->a, opt->o_ins, opt->e_ins);
 	w2 = w2 > tmp ? w2 : tmp;
 	if (w2 > opt->w) w2 = w2 < ar->w ? w2 : ar->w;
-	if (ctx && ctx->mode == AlnCtx::COLLECT) {   // only note that this region needs its CIGAR; decisions do not depend on it
+	if (collecting) {   // only note that this region needs its CIGAR; decisions do not depend on it
 		AlnReqH rq;
 		rq.rb = rb; rq.re = re; rq.read = read_idx; rq.qb = qb; rq.qe = qe; rq.w2 = w2; rq.truesc = ar->truesc; rq.pad = 0;
 		ctx->reqs->push_back(rq);
@@ -568,7 +569,7 @@ bool gen_alt(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, cons
 		int r = pri_idx(i);
 		if (r < 0) continue;
 		if (cnt[r] > opt->max_XA_hits_alt || (!has_alt[r] && cnt[r] > opt->max_XA_hits)) continue;
-		HAln t = reg2aln(opt, bns, pac, l_query, query, &a[i], ctx, read_idx);
+		HAln t = reg2aln(opt, bns, pac, l_query, query, &a[i], ctx, read_idx, false);   // XA entries carry no MAPQ
 		has[r] = 1;
 		if (ctx && !ctx->text()) continue;
 		std::string &s = xa[r];

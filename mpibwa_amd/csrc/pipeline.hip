@@ -788,6 +788,8 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	const bool gpu_msw = pe && !(opt->flag & MEM_F_NO_RESCUE) && getenv("MPIBWA_HOST_MATESW") == nullptr && (int64_t)max_len * opt->a < 8192 &&
 	                     msw_lds_bytes(max_len) <= 160 * 1024;
 	double msw_ms = 0;
+	static const bool s_cpusec = getenv("MPIBWA_CPUSEC") != nullptr;
+	std::atomic<unsigned long long> tsc_plan(0), tsc_emitc(0);
 	double cpu_msw = 0, cpu_collect = 0, cpu_emit = 0, sys_emit = 0;
 	long pf_emit = 0;
 	auto mcollect = [&](Part &P, int slot) {
@@ -863,6 +865,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			AlnCtx ctx;
 			ctx.mode = AlnCtx::COLLECT; ctx.reqs = &rq;
 			const int lo = P.lo + blk * 256, hi = std::min(P.hi, lo + 256);
+			unsigned long long tsc_plan_blk = 0, tsc_emitc_blk = 0;
 			for (int i = lo; i < hi; ++i) {
 				const int k = i - P.lo;
 				const bool waits = P.m_launched && P.mbase[k + 1] != P.mbase[k];   // needs results of the mate-rescue kernel
@@ -871,9 +874,12 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 				if (pe) {
 					MswCtx mc;
 					if (waits) { mc.req = P.mreq + P.mbase[k]; mc.res = P.mres + P.mbase[k]; mc.n = (int)(P.mbase[k + 1] - P.mbase[k]); }
+					const unsigned long long c0 = s_cpusec ? __builtin_ia32_rdtsc() : 0;
 					sam_pe_plan(opt, bns, pac, pes, (uint64_t)((n_processed >> 1) + i), &seqs[i << 1], &regs[i << 1], plans[i], waits ? &mc : nullptr,
 					            i << 1);
+					const unsigned long long c1 = s_cpusec ? __builtin_ia32_rdtsc() : 0;
 					if (gpu_aln) sam_pe_emit(opt, bns, pac, pes, &seqs[i << 1], &regs[i << 1], plans[i], &ctx, i << 1);
+					if (s_cpusec) { tsc_plan_blk += c1 - c0; tsc_emitc_blk += __builtin_ia32_rdtsc() - c1; }
 				} else {
 					mark_primary_se(opt, regs[i], n_processed + i);
 					if (opt->flag & MEM_F_PRIMARY5) reorder_primary5(opt->T, regs[i]);
@@ -881,6 +887,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 				}
 				P.u_first[k] = (uint32_t)before; P.u_cnt[k] = (uint32_t)(rq.size() - before);
 			}
+			if (s_cpusec) { tsc_plan += tsc_plan_blk; tsc_emitc += tsc_emitc_blk; }
 		});
 		if (round == 1) {
 			P.base.assign(nu + 1, 0);
@@ -973,7 +980,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	g_stats.plan_ms = plan_ms; g_stats.aln_ms = aln_wait_ms; g_stats.msw_ms = msw_ms; g_stats.emit_ms = emit_ms;
 	double t8 = now_ms();
 	hprof_report("sam stage");
-	static const bool s_cpusec = getenv("MPIBWA_CPUSEC") != nullptr;
+	if (s_cpusec) fprintf(stderr, "[plan Mcycles] sam_pe_plan %.0f  emit(collect) %.0f\n", tsc_plan.load() * 1e-6, tsc_emitc.load() * 1e-6);
 	if (g_hprof_on || s_cpusec)
 		fprintf(stderr, "[cpu-sec] encode+h2d %.3f  phase1 %.3f  pestat+sam %.3f (msw-collect %.3f, plan+collect %.3f, emit %.3f [sys %.3f, %ld page faults])  total %.3f  sys %.3f  wall %.3f\n",
 		        c1 - c_begin, c6 - c1, cpu_sec() - c6, cpu_msw, cpu_collect, cpu_emit, sys_emit, pf_emit, cpu_sec() - c_begin, sys_sec() - s_begin, (t8 - t_begin) * 1e-3);
