@@ -205,6 +205,16 @@ int mi355x_extend_batch(const mem_opt_t *opt, int n, const uint8_t *q, const int
                         const uint8_t *t, const int64_t *toff, const int *w, const int *h0,
                         const int *end_bonus, int *out6, double *kernel_ms, uint64_t *cells);
 
+/* Chaining stage (mem_chain + mem_chain_flt, src/bwamem.c:251-385) for n_reads reads given by their seeds
+ * (read r owns seeds seed_off[r] .. seed_off[r+1]: rbeg[], and qbeg/len interleaved in qbeg_len[]), computed by
+ * chain_kernel (which = 0) or by the library's host path (which = 1).  Output per read from out[out_off[r]]:
+ * n_chains (-1 = the kernel leaves the read to the host), then per kept chain rid, n_seeds, far_beg, far_end,
+ * rmax0, rmax1, frac_rep (float bits) and n_seeds x (rbeg, qbeg, len) in the order mem_chain2aln visits them.
+ * Returns the number of int64 written, or -1 if out_cap is too small. */
+int64_t mi355x_chain_batch(const mem_opt_t *opt, const bntseq_t *bns, int n_reads, const int *lens, const int *l_rep,
+                           const int64_t *seed_off, const uint64_t *rbeg, const int32_t *qbeg_len, int which,
+                           int64_t *out, int64_t out_cap, int64_t *out_off);
+
 /* Mate-rescue local alignment: ksw_align2() exactly as mem_matesw() calls it (src/bwamem_pair.c:150-177,
  * src/ksw.c:321-356), for n_req windows [rb,re) of a 2-bit packed reference (doubled coordinate) against reads
  * given as nt4 codes (read r = reads[off[r]..off[r+1]) ).  out8 per request: score, te, qe, score2, te2, tb, qb

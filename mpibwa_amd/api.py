@@ -17,7 +17,7 @@ EXPORTS = [
     "mem_process_seqs", "mem_opt_init", "bwa_fill_scmat", "bwa_idx_load_from_disk", "bwa_mem2idx", "bwa_idx_destroy",
     "mi355x_index_upload", "mi355x_index_alloc", "mi355x_index_buffers", "mi355x_index_d2d", "mi355x_index_commit",
     "mi355x_finalize", "mi355x_index_build", "mi355x_index_build_gpu",
-    "mi355x_smem_batch", "mi355x_sa_batch", "mi355x_sa_batch2", "mi355x_sa_dense_info", "mi355x_extend_batch", "mi355x_matesw_batch", "mi355x_fastq_scan", "mi355x_fastq_chunks", "mi355x_fastq_fill", "mi355x_last_stats", "mi355x_host_cpus", "mi355x_collect_sam", "mi355x_host_ksw_align2",
+    "mi355x_smem_batch", "mi355x_sa_batch", "mi355x_sa_batch2", "mi355x_sa_dense_info", "mi355x_extend_batch", "mi355x_matesw_batch", "mi355x_chain_batch", "mi355x_fastq_scan", "mi355x_fastq_chunks", "mi355x_fastq_fill", "mi355x_last_stats", "mi355x_host_cpus", "mi355x_collect_sam", "mi355x_host_ksw_align2",
 ]
 
 
@@ -57,6 +57,7 @@ def load_library(build_if_missing=True):
     sig("mi355x_sa_batch2", C.c_int, [C.c_int, C.c_void_p, C.c_void_p, P(C.c_double), C.c_int])
     sig("mi355x_sa_dense_info", C.c_double, [P(C.c_size_t)])
     sig("mi355x_extend_batch", C.c_int, [P(abi.mem_opt_t), C.c_int] + [C.c_void_p] * 8 + [P(C.c_double), P(C.c_uint64)])
+    sig("mi355x_chain_batch", C.c_int64, [P(abi.mem_opt_t), C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_int64, C.c_void_p])
     sig("mi355x_fastq_scan", C.c_int64, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p])
     sig("mi355x_fastq_chunks", C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p])
     sig("mi355x_fastq_fill", C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p])
@@ -205,6 +206,44 @@ class Engine:
         ms = C.c_double(0)
         rc = self.lib.mi355x_sa_batch2(len(ks), ks.ctypes.data, out.ctypes.data, C.byref(ms), 1)
         return (out, ms.value) if rc == 0 else None
+
+    def chains(self, opt, lens, l_rep, seeds_per_read, which):
+        """Chaining stage for reads given by their seeds [(rbeg, qbeg, len), ...]; which = 0 device kernel, 1 host path.
+        Returns per read None (device declines) or a list of chains (rid, far_beg, far_end, rmax0, rmax1, frac_bits, [(rbeg, qbeg, len)...])."""
+        n = len(seeds_per_read)
+        off = np.zeros(n + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(s) for s in seeds_per_read])
+        S = int(off[n])
+        rbeg = np.zeros(max(S, 1), dtype=np.uint64)
+        ql = np.zeros(2 * max(S, 1), dtype=np.int32)
+        k = 0
+        for s in seeds_per_read:
+            for rb, qb, ln in s:
+                rbeg[k] = rb; ql[2 * k] = qb; ql[2 * k + 1] = ln
+                k += 1
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        l_rep = np.ascontiguousarray(l_rep, dtype=np.int32)
+        cap = n + 16 * S + 64 * n + 64
+        out = np.zeros(cap, dtype=np.int64)
+        out_off = np.zeros(n + 1, dtype=np.int64)
+        rc = self.lib.mi355x_chain_batch(opt, C.cast(self.bns, C.c_void_p), n, lens.ctypes.data, l_rep.ctypes.data, off.ctypes.data, rbeg.ctypes.data,
+                                         ql.ctypes.data, which, out.ctypes.data, cap, out_off.ctypes.data)
+        assert rc >= 0
+        res = []
+        for r in range(n):
+            p = int(out_off[r])
+            nc = int(out[p]); p += 1
+            if nc < 0:
+                res.append(None)
+                continue
+            chs = []
+            for _ in range(nc):
+                rid, ns, fb, fe, r0, r1, fr = (int(x) for x in out[p:p + 7]); p += 7
+                sd = [tuple(int(x) for x in out[p + 3 * j:p + 3 * j + 3]) for j in range(ns)]
+                p += 3 * ns
+                chs.append((rid, fb, fe, r0, r1, fr, sd))
+            res.append(chs)
+        return res
 
     def matesw(self, opt, l_pac, pac, reads, rb, re, read, is_rev):
         """mem_matesw's ksw_align2 for windows of `pac`; returns (n_req x 8 int32, kernel ms)."""

@@ -6,6 +6,8 @@
 #include <cstring>
 #include <vector>
 #include "device.h"
+#include "host.h"
+#include <cmath>
 
 namespace mbw {
 
@@ -464,4 +466,107 @@ extern "C" int mi355x_matesw_batch(const mem_opt_t *opt, int64_t l_pac, const ui
 	(void)hipFree(d_rows);
 	if (kernel_ms) *kernel_ms = ms;
 	return 0;
+}
+
+// Stage-level entry point of the chaining stage (tests): seeds of n_reads reads -> filtered chains, computed by
+// chain_kernel (which = 0) or by the host path (which = 1).  Per read r the output is a run of int64 starting at
+// out[out_off[r]]: n_chains (-1 = the device declines the read), then per chain
+//   rid, n_seeds, far_beg, far_end, rmax0, rmax1, frac_rep (float bits), and n_seeds x (rbeg, qbeg, len) in visiting order.
+// out must hold 1 + 7 * 9... entries per read in the worst case; the caller sizes it as n_reads + 8 * total_seeds + ...
+extern "C" int64_t mi355x_chain_batch(const mem_opt_t *opt, const bntseq_t *bns, int n_reads, const int *lens, const int *l_rep,
+                                      const int64_t *seed_off, const uint64_t *rbeg, const int32_t *qbeg_len, int which, int64_t *out,
+                                      int64_t out_cap, int64_t *out_off)
+{
+	using namespace mbw;
+	const int64_t S = seed_off[n_reads];
+	int max_len = 0;
+	for (int i = 0; i < n_reads; ++i) max_len = std::max(max_len, lens[i]);
+	const int TS = max_len + 2;
+	std::vector<int> tab(6 * TS);
+	for (int l = 0; l < TS; ++l) {
+		tab[l] = cal_max_gap(opt, l);
+		tab[TS + l] = tab[2 * TS + l] = tab[3 * TS + l] = tab[4 * TS + l] = 0;
+		const double min_l = opt->min_chain_weight ? 1.1f * opt->min_chain_weight : 5.5f * log(l > 0 ? l : 1);
+		tab[5 * TS + l] = (l > 0 && min_l > 0.05f * l) ? 1 : 0;
+	}
+	std::vector<int> nseeds(n_reads);
+	for (int i = 0; i < n_reads; ++i) nseeds[i] = (int)(seed_off[i + 1] - seed_off[i]);
+	std::vector<int> nch(n_reads, 0);
+	std::vector<DevChain> chains(std::max<int64_t>(S, 1));
+	std::vector<DevSeed> seeds(std::max<int64_t>(S, 1));
+	if (which == 0) {
+		int nd = 0;
+		if (hipGetDeviceCount(&nd) != hipSuccess || nd == 0) die("no HIP device visible (no CPU fallback)");
+		std::vector<int64_t> ann_off(bns->n_seqs + 1);
+		std::vector<uint8_t> ann_alt(bns->n_seqs + 1, 0);
+		for (int k = 0; k < bns->n_seqs; ++k) { ann_off[k] = bns->anns[k].offset; ann_alt[k] = bns->anns[k].is_alt ? 1 : 0; }
+		ann_off[bns->n_seqs] = bns->l_pac;
+		int *d_len, *d_ns, *d_lrep, *d_tab, *d_nch; int64_t *d_so, *d_ao; uint64_t *d_sa; int32_t *d_qbl; uint8_t *d_aa;
+		DevChain *d_ch; DevSeed *d_sd; unsigned int *d_srt;
+		HIP_OK(hipMalloc(&d_len, n_reads * 4 + 4)); HIP_OK(hipMalloc(&d_ns, n_reads * 4 + 4)); HIP_OK(hipMalloc(&d_lrep, n_reads * 4 + 4));
+		HIP_OK(hipMalloc(&d_tab, tab.size() * 4)); HIP_OK(hipMalloc(&d_nch, n_reads * 4 + 4)); HIP_OK(hipMalloc(&d_so, (n_reads + 1) * 8));
+		HIP_OK(hipMalloc(&d_ao, ann_off.size() * 8)); HIP_OK(hipMalloc(&d_aa, ann_alt.size())); HIP_OK(hipMalloc(&d_sa, S * 8 + 8));
+		HIP_OK(hipMalloc(&d_qbl, S * 8 + 8)); HIP_OK(hipMalloc(&d_ch, (S + 1) * sizeof(DevChain))); HIP_OK(hipMalloc(&d_sd, (S + 1) * sizeof(DevSeed)));
+		HIP_OK(hipMalloc(&d_srt, (S + 1) * 4));
+		HIP_OK(hipMemcpy(d_len, lens, n_reads * 4, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(d_ns, nseeds.data(), n_reads * 4, hipMemcpyHostToDevice));
+		HIP_OK(hipMemcpy(d_lrep, l_rep, n_reads * 4, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(d_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+		HIP_OK(hipMemcpy(d_so, seed_off, (n_reads + 1) * 8, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(d_ao, ann_off.data(), ann_off.size() * 8, hipMemcpyHostToDevice));
+		HIP_OK(hipMemcpy(d_aa, ann_alt.data(), ann_alt.size(), hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(d_sa, rbeg, S * 8, hipMemcpyHostToDevice));
+		HIP_OK(hipMemcpy(d_qbl, qbeg_len, S * 8, hipMemcpyHostToDevice));
+		ChainParams kp;
+		kp.l_pac = bns->l_pac; kp.w = opt->w; kp.max_chain_gap = opt->max_chain_gap; kp.min_chain_weight = opt->min_chain_weight;
+		kp.min_seed_len = opt->min_seed_len; kp.max_chain_extend = opt->max_chain_extend; kp.mask_level = opt->mask_level; kp.drop_ratio = opt->drop_ratio;
+		launch_chain(0, kp, n_reads, d_len, d_ns, d_lrep, d_so, d_sa, d_qbl, d_ao, d_aa, bns->n_seqs, d_tab, TS, d_ch, d_sd, d_srt, d_nch);
+		HIP_OK(hipDeviceSynchronize());
+		HIP_OK(hipMemcpy(nch.data(), d_nch, n_reads * 4, hipMemcpyDeviceToHost));
+		HIP_OK(hipMemcpy((void *)chains.data(), d_ch, S * sizeof(DevChain), hipMemcpyDeviceToHost));
+		HIP_OK(hipMemcpy((void *)seeds.data(), d_sd, S * sizeof(DevSeed), hipMemcpyDeviceToHost));
+		(void)hipFree(d_len); (void)hipFree(d_ns); (void)hipFree(d_lrep); (void)hipFree(d_tab); (void)hipFree(d_nch); (void)hipFree(d_so); (void)hipFree(d_ao);
+		(void)hipFree(d_aa); (void)hipFree(d_sa); (void)hipFree(d_qbl); (void)hipFree(d_ch); (void)hipFree(d_sd); (void)hipFree(d_srt);
+	} else {
+		ChainScratch scr;
+		std::vector<HSeed> hs;
+		std::vector<HChain *> ch;
+		std::vector<uint64_t> key;
+		for (int i = 0; i < n_reads; ++i) {
+			const int ns = nseeds[i];
+			if (ns == 0) continue;
+			hs.resize(ns);
+			for (int k = 0; k < ns; ++k) {
+				const int64_t so = seed_off[i] + k;
+				hs[k].rbeg = (int64_t)rbeg[so]; hs[k].qbeg = qbeg_len[2 * so]; hs[k].len = hs[k].score = qbeg_len[2 * so + 1];
+			}
+			chains_from_seeds(opt, bns, lens[i], hs.data(), ns, l_rep[i], scr, ch);
+			chain_filter(opt, scr, ch);
+			int64_t cur = seed_off[i];
+			int c = 0;
+			for (const HChain *cp : ch) {
+				DevChain &d = chains[seed_off[i] + c];
+				pack_chain_for_device(bns, *cp, lens[i], tab.data(), key, d, seeds.data() + cur);
+				d.seed_beg = (int)cur;
+				cur += d.n_seeds;
+				++c;
+			}
+			nch[i] = c;
+		}
+	}
+	int64_t at = 0;
+	for (int i = 0; i < n_reads; ++i) {
+		out_off[i] = at;
+		if (at + 1 > out_cap) return -1;
+		out[at++] = nch[i];
+		for (int c = 0; c < nch[i]; ++c) {
+			const DevChain &d = chains[seed_off[i] + c];
+			if (at + 7 + 3 * (int64_t)d.n_seeds > out_cap) return -1;
+			uint32_t fb;
+			memcpy(&fb, &d.frac_rep, 4);
+			out[at++] = d.rid; out[at++] = d.n_seeds; out[at++] = d.far_beg; out[at++] = d.far_end; out[at++] = d.rmax0; out[at++] = d.rmax1; out[at++] = fb;
+			for (int k = 0; k < d.n_seeds; ++k) {
+				const DevSeed &s = seeds[d.seed_beg + k];
+				out[at++] = s.rbeg; out[at++] = s.qbeg; out[at++] = s.len;
+			}
+		}
+	}
+	out_off[n_reads] = at;
+	return at;
 }

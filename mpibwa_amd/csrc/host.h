@@ -208,6 +208,9 @@ void chains_from_seeds(const mem_opt_t *opt, const bntseq_t *bns, int l_query, c
 void chain_filter(const mem_opt_t *opt, ChainScratch &S, std::vector<HChain *> &chains);
 void filter_chained_seeds(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, int l_query, const uint8_t *query,
                           std::vector<HChain *> &chains);
+struct DevChain;
+struct DevSeed;
+void pack_chain_for_device(const bntseq_t *bns, const HChain &ch, int l_query, const int *gap_h, std::vector<uint64_t> &key, DevChain &d, DevSeed *osd);
 int  sort_dedup_patch(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, uint8_t *query, HRegV &regs);
 int  mark_primary_se(const mem_opt_t *opt, HRegV &a, int64_t id);
 void reorder_primary5(int T, HRegV &a);

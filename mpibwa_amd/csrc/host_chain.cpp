@@ -12,8 +12,10 @@
 // B-tree insertion / search rules are restated here rather than substituting
 // std::map.
 #include "host.h"
+#include "device.h"
 #include "sortutil.h"
 
+#include <algorithm>
 #include <cassert>
 #include <cmath>
 #include <cstring>
@@ -404,6 +406,49 @@ void filter_chained_seeds(const mem_opt_t *opt, const bntseq_t *bns, const uint8
 			}
 		}
 		c.seeds.resize(k);
+	}
+}
+
+// One filtered chain in the layout the extension kernels read: the chain's contig bounds and reference window
+// (src/bwamem.c:642-661) and its seeds in the order mem_chain2aln visits them — the reference sorts (score << 32 | index)
+// ascending and walks from the end (src/bwamem.c:662-667); keys are distinct, so any sort gives that order.
+void pack_chain_for_device(const bntseq_t *bns, const HChain &ch, int l_query, const int *gap_h, std::vector<uint64_t> &key, DevChain &d, DevSeed *osd)
+{
+	const int cs = (int)ch.seeds.size();
+	d.n_seeds = cs; d.rid = ch.rid; d.frac_rep = ch.frac_rep;
+	d.far_beg = d.far_end = 0;
+	if (cs) {
+		int is_rev;
+		bns_depos(bns, ch.seeds[0].rbeg, &is_rev);
+		int64_t fb = bns->anns[ch.rid].offset, fe = fb + bns->anns[ch.rid].len;
+		if (is_rev) { int64_t t = fb; fb = (bns->l_pac << 1) - fe; fe = (bns->l_pac << 1) - t; }
+		d.far_beg = fb; d.far_end = fe;
+	}
+	key.resize(cs);
+	const HSeed *hsd = ch.seeds.data();
+	for (int k = 0; k < cs; ++k) key[k] = (uint64_t)hsd[k].score << 32 | (uint32_t)k;
+	if (cs == 2) { if (key[1] < key[0]) std::swap(key[0], key[1]); }
+	else if (cs > 2) std::sort(key.begin(), key.end());
+	int64_t lo = bns->l_pac << 1, hi = 0;
+	for (int k = 0; k < cs; ++k) {
+		const HSeed &t = hsd[(uint32_t)key[k]];
+		osd[k].rbeg = t.rbeg; osd[k].qbeg = t.qbeg; osd[k].len = t.len;
+		// widest reference span any seed of the chain could reach (src/bwamem.c:642-658)
+		const int64_t b = t.rbeg - (t.qbeg + gap_h[t.qbeg]);
+		const int tail = l_query - t.qbeg - t.len;
+		const int64_t e = t.rbeg + t.len + (tail + gap_h[tail]);
+		lo = b < lo ? b : lo;
+		hi = e > hi ? e : hi;
+	}
+	d.rmax0 = lo > 0 ? lo : 0;
+	d.rmax1 = hi < bns->l_pac << 1 ? hi : bns->l_pac << 1;
+	if (cs) {
+		if (d.rmax0 < bns->l_pac && bns->l_pac < d.rmax1) {   // never cross the strand boundary
+			if (ch.seeds[0].rbeg < bns->l_pac) d.rmax1 = bns->l_pac;
+			else d.rmax0 = bns->l_pac;
+		}
+		d.rmax0 = d.rmax0 > d.far_beg ? d.rmax0 : d.far_beg;   // bns_fetch_seq clamps to the contig
+		d.rmax1 = d.rmax1 < d.far_end ? d.rmax1 : d.far_end;
 	}
 }
 

@@ -485,50 +485,11 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 						const HChain &ch = *cp_;
 						const int cs = (int)ch.seeds.size();
 						DevChain d;
-						d.seed_beg = (int)o.sd.size(); d.n_seeds = cs; d.rid = ch.rid; d.frac_rep = ch.frac_rep;   // block-local for now
-						d.far_beg = d.far_end = 0;
-						if (cs) {
-							int is_rev;
-							bns_depos(bns, ch.seeds[0].rbeg, &is_rev);
-							int64_t fb = bns->anns[ch.rid].offset, fe = fb + bns->anns[ch.rid].len;
-							if (is_rev) { int64_t t = fb; fb = (bns->l_pac << 1) - fe; fe = (bns->l_pac << 1) - t; }
-							d.far_beg = fb; d.far_end = fe;
-						}
-						// Seeds are stored in the order of the reference's sort by (score, index) (src/bwamem.c:662-667) — keys are
-						// distinct, so any sort gives that order — and visited from the last one down; the order array the
-						// kernels use for their "seed skipped" marks therefore starts as the identity.
-						key.resize(cs);
-						const HSeed *hsd = ch.seeds.data();
-						for (int k = 0; k < cs; ++k) key[k] = (uint64_t)hsd[k].score << 32 | (uint32_t)k;
-						if (cs == 2) { if (key[1] < key[0]) std::swap(key[0], key[1]); }
-						else if (cs > 2) std::sort(key.begin(), key.end());
-						int64_t lo = bns->l_pac << 1, hi = 0;
 						const size_t at = o.sd.size();
 						o.sd.resize(at + cs); o.srt.resize(at + cs);
-						DevSeed *osd = o.sd.data() + at;
-						unsigned int *osr = o.srt.data() + at;
-						const int lq_i = seqs_r[i].l_seq;
-						for (int k = 0; k < cs; ++k) {
-							const HSeed &t = hsd[(uint32_t)key[k]];
-							osd[k].rbeg = t.rbeg; osd[k].qbeg = t.qbeg; osd[k].len = t.len;
-							osr[k] = (unsigned int)k;
-							// widest reference span any seed of the chain could reach (src/bwamem.c:642-658)
-							const int64_t b = t.rbeg - (t.qbeg + gap_h[t.qbeg]);
-							const int tail = lq_i - t.qbeg - t.len;
-							const int64_t e = t.rbeg + t.len + (tail + gap_h[tail]);
-							lo = b < lo ? b : lo;
-							hi = e > hi ? e : hi;
-						}
-						d.rmax0 = lo > 0 ? lo : 0;
-						d.rmax1 = hi < bns->l_pac << 1 ? hi : bns->l_pac << 1;
-						if (cs) {
-							if (d.rmax0 < bns->l_pac && bns->l_pac < d.rmax1) {   // never cross the strand boundary
-								if (ch.seeds[0].rbeg < bns->l_pac) d.rmax1 = bns->l_pac;
-								else d.rmax0 = bns->l_pac;
-							}
-							d.rmax0 = d.rmax0 > d.far_beg ? d.rmax0 : d.far_beg;   // bns_fetch_seq clamps to the contig
-							d.rmax1 = d.rmax1 < d.far_end ? d.rmax1 : d.far_end;
-						}
+						pack_chain_for_device(bns, ch, seqs_r[i].l_seq, gap_h.data(), key, d, o.sd.data() + at);
+						d.seed_beg = (int)at;   // block-local for now
+						for (int k = 0; k < cs; ++k) o.srt[at + k] = (unsigned int)k;   // the order array only carries "skipped" marks
 						o.ch.push_back(d);
 						tot += cs;
 					}

@@ -226,3 +226,56 @@ def test_matesw_kernel_matches_reference_ksw_align2(engine):
             n_hit += 1
             n_second += want[3] > 0
     assert n_hit > 1500 and n_second > 50
+
+
+def test_chain_kernel_matches_host_chaining(engine, genome):
+    """chain_kernel == the host's restatement of mem_chain + mem_chain_flt (kbtree rules for equal keys, the introsort's
+    partition pass, float compares) on adversarial seed sets: equal positions, equal weights, up to 9 chains, > 9 chains and
+    > 64 seeds (which the kernel must decline), both strands, seeds bridging contigs."""
+    rng = np.random.default_rng(77)
+    opt = engine.opt()
+    l_pac = int(engine.bns.contents.l_pac)
+    n_seqs = int(engine.bns.contents.n_seqs)
+    offs = [int(engine.bns.contents.anns[k].offset) for k in range(n_seqs)] + [l_pac]
+    lens, lrep, seedsets = [], [], []
+    for it in range(4000):
+        lq = int(rng.choice([100, 150, 151, 250]))
+        mode = rng.random()
+        n_anchor = int(rng.integers(1, 4)) if mode < 0.6 else int(rng.integers(3, 14))
+        anchors = []
+        for _ in range(n_anchor):
+            k = int(rng.integers(0, n_seqs))
+            p = int(rng.integers(offs[k], max(offs[k] + 1, offs[k + 1] - lq - 1)))
+            if rng.random() < 0.5:
+                p = 2 * l_pac - 1 - p - lq      # reverse strand
+                p = max(p, l_pac)
+            anchors.append(p)
+        if rng.random() < 0.15 and len(anchors) > 1:
+            anchors[1] = anchors[0]               # two chains anchored at the same position
+        if rng.random() < 0.05:
+            anchors[0] = offs[int(rng.integers(1, n_seqs))] - 10 if n_seqs > 1 else anchors[0]   # seeds bridging two contigs
+        ns = int(rng.integers(1, 30)) if mode < 0.9 else int(rng.integers(60, 90))
+        sd = []
+        for _ in range(ns):
+            a = anchors[int(rng.integers(0, len(anchors)))]
+            qb = int(rng.integers(0, lq - 19))
+            ln = int(rng.integers(19, min(lq - qb, 80) + 1))
+            shift = int(rng.choice([0, 0, 0, 1, -1, 3, 120, 20000]))
+            sd.append((min(max(a + qb + shift, 0), 2 * l_pac - ln - 1), qb, ln))
+        if rng.random() < 0.3:                    # equal weights: several disjoint seeds of the same length
+            ln = 25
+            sd = [(min(max(anchors[j % len(anchors)] + 30 * j + (0 if j % 2 else 7), 0), 2 * l_pac - ln - 1), (30 * j) % (lq - 25), ln)
+                  for j in range(int(rng.integers(3, 9)))]
+        # mem_chain visits seeds interval by interval: keep the generated order (arbitrary) — both paths see the same
+        lens.append(lq); lrep.append(int(rng.integers(0, lq))); seedsets.append(sd)
+    dev = engine.chains(opt, lens, lrep, seedsets, 0)
+    host = engine.chains(opt, lens, lrep, seedsets, 1)
+    n_dev = n_declined = n_multi = 0
+    for d, h, sd in zip(dev, host, seedsets):
+        if d is None:
+            n_declined += 1
+            continue
+        assert d == h, (sd, d, h)
+        n_dev += 1
+        n_multi += len(h) >= 3
+    assert n_dev > 2500 and n_declined > 100 and n_multi > 200
