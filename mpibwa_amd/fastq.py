@@ -100,11 +100,15 @@ class FastqSource:
         return rec, files * count
 
 
-def align_files(engine, opt, r1, r2=None, out=None, K=10_000_000, copy_comment=False, mode=None, n_processed0=0):
-    """`mpiBWA mem` for one rank: every chunk through mem_process_seqs, SAM records in read order.
+def align_files(engine, opt, r1, r2=None, out=None, K=10_000_000, copy_comment=False, mode=None, n_processed0=0, rank=0, world=1):
+    """`mpiBWA mem` for one rank: its chunks through mem_process_seqs, SAM records in read order.
 
+    The chunk list is the same on every rank (it does not depend on the number of ranks); rank r of `world` takes chunks
+    r, r + world, ... — the reference hands chunks out with a fetch-and-add counter (src/mainParallel.c:1112-1119), which
+    balances better on uneven data but yields the same set of records.  With world > 1 the trimmed branch's running
+    n_processed (reads this rank has already done, :2355-2357) is counted over this rank's chunks, as in the reference.
     out: a binary file object (the SAM body is written to it) or None (the body is returned as bytes).
-    Returns (bytes or None, per-chunk read counts)."""
+    Returns (bytes or None, per-chunk read counts of this rank)."""
     lib = engine.lib
     src = FastqSource(lib, r1, r2, K=K, copy_comment=copy_comment, mode=mode)
     pieces = [] if out is None else None
@@ -132,7 +136,7 @@ def align_files(engine, opt, r1, r2=None, out=None, K=10_000_000, copy_comment=F
     th = threading.Thread(target=writer, daemon=True)
     th.start()
     counts = []
-    for c in range(src.n_chunks):
+    for c in range(rank, src.n_chunks, world):
         rec, n = src.chunk(c)
         # mpiBWA passes n_processed = 0 for equal-size pairs and single end, and the reads already done by the rank in
         # the trimmed branch (src/mainParallel.c:1314, 2355-2357, 3093)

@@ -61,3 +61,16 @@ def test_example_multi_chunk_matches_reference_per_chunk(engine, hg19_small):
             po.libc.free(C.c_void_p(p))
     assert body == b"".join(want)
     assert hashlib.md5(body).hexdigest() != KNOWN_MD5   # per-chunk insert-size statistics: -K changes the output
+
+
+def test_example_chunks_spread_over_ranks_give_the_same_records(engine):
+    """Chunks handed to 3 ranks (one after the other on this GPU): the union of their SAM records is the single-rank output —
+    chunk boundaries, hence mem_pestat and every record, do not depend on the number of ranks."""
+    from mpibwa_amd import abi, fastq
+    r1, r2 = (os.path.join(HERE, "HCC1187C_R%d_10K.fastq.gz" % k) for k in (1, 2))
+    opt = engine.opt(flag=abi.MEM_F_PE)
+    whole, counts = fastq.align_files(engine, opt, r1, r2, K=200_000)
+    assert len(counts) >= 8
+    parts = [fastq.align_files(engine, opt, r1, r2, K=200_000, rank=r, world=3) for r in range(3)]
+    assert sum(len(c) for _, c in parts) == len(counts)
+    assert sorted(whole.splitlines()) == sorted(b"".join(b for b, _ in parts).splitlines())
