@@ -18,6 +18,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 namespace mbw {
 
@@ -390,6 +393,51 @@ static inline int get_rlen(const CigarV &cigar)
 	return l;
 }
 
+// SEQ / QUAL columns: nt4 codes -> letters (complemented and reversed for reverse-strand records), 16 bases at a time
+#if defined(__SSE2__)
+static inline __m128i rev16(__m128i x)
+{
+	x = _mm_shuffle_epi32(x, 0x1B);
+	x = _mm_shufflelo_epi16(x, 0xB1);
+	x = _mm_shufflehi_epi16(x, 0xB1);
+	return _mm_or_si128(_mm_srli_epi16(x, 8), _mm_slli_epi16(x, 8));
+}
+static inline __m128i letters16(__m128i c, const char *lut)
+{
+	__m128i r = _mm_set1_epi8(lut[4]);
+	for (int k = 0; k < 4; ++k) {
+		const __m128i m = _mm_cmpeq_epi8(c, _mm_set1_epi8((char)k));
+		r = _mm_or_si128(_mm_andnot_si128(m, r), _mm_and_si128(m, _mm_set1_epi8(lut[k])));
+	}
+	return r;
+}
+#endif
+static inline void put_seq_fwd(char *dst, const char *codes, int n)
+{
+	int i = 0;
+#if defined(__SSE2__)
+	for (; i + 16 <= n; i += 16) _mm_storeu_si128((__m128i *)(dst + i), letters16(_mm_loadu_si128((const __m128i *)(codes + i)), "ACGTN"));
+#endif
+	for (; i < n; ++i) dst[i] = "ACGTN"[(int)codes[i]];
+}
+static inline void put_seq_rev(char *dst, const char *codes, int n)   // dst[k] = comp(codes[n-1-k])
+{
+	int i = 0;
+#if defined(__SSE2__)
+	for (; i + 16 <= n; i += 16)
+		_mm_storeu_si128((__m128i *)(dst + i), letters16(rev16(_mm_loadu_si128((const __m128i *)(codes + n - 16 - i))), "TGCAN"));
+#endif
+	for (; i < n; ++i) dst[i] = "TGCAN"[(int)codes[n - 1 - i]];
+}
+static inline void put_rev_bytes(char *dst, const char *src, int n)    // dst[k] = src[n-1-k]
+{
+	int i = 0;
+#if defined(__SSE2__)
+	for (; i + 16 <= n; i += 16) _mm_storeu_si128((__m128i *)(dst + i), rev16(_mm_loadu_si128((const __m128i *)(src + n - 16 - i))));
+#endif
+	for (; i < n; ++i) dst[i] = src[n - 1 - i];
+}
+
 // the fields of a record that mem_aln2sam adjusts on its private copies of the read's and the mate's alignment
 struct AlnView {
 	const HAln *a;
@@ -467,7 +515,7 @@ static void aln2sam(const mem_opt_t *opt, const bntseq_t *bns, std::string &str,
 			}
 			size_t at = str.size();
 			str.resize(at + (qe - qb));
-			for (int i = qb; i < qe; ++i) str[at++] = "ACGTN"[(int)s->seq[i]];
+			put_seq_fwd(&str[at], s->seq + qb, qe - qb);
 			str.push_back('\t');
 			if (s->qual) str.append(s->qual + qb, qe - qb);
 			else str.push_back('*');
@@ -478,12 +526,12 @@ static void aln2sam(const mem_opt_t *opt, const bntseq_t *bns, std::string &str,
 			}
 			size_t at = str.size();
 			str.resize(at + (qe - qb));
-			for (int i = qe - 1; i >= qb; --i) str[at++] = "TGCAN"[(int)s->seq[i]];
+			put_seq_rev(&str[at], s->seq + qb, qe - qb);
 			str.push_back('\t');
 			if (s->qual) {
 				at = str.size();
 				str.resize(at + (qe - qb));
-				for (int i = qe - 1; i >= qb; --i) str[at++] = s->qual[i];
+				put_rev_bytes(&str[at], s->qual + qb, qe - qb);
 			} else str.push_back('*');
 		}
 	}
