@@ -224,6 +224,10 @@ void reg2sam(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, bseq
 
 // ---- per-batch / per-pair stages (src/bwamem_pair.c) ----
 void pestat(const mem_opt_t *opt, int64_t l_pac, int n, const HRegV *regs, mem_pestat_t pes[4], int n_threads = 1);
+// the same in pieces: votes of pairs [lo, hi) into 4 x (max_ins + 1) counters, then the statistics from the counters
+bool pestat_can_count(const mem_opt_t *opt);
+void pestat_gather(const mem_opt_t *opt, int64_t l_pac, int lo, int hi, const HRegV *regs, uint64_t *hist);
+void pestat_from_hist(const mem_opt_t *opt, const uint64_t *hist, mem_pestat_t pes[4]);
 int  sam_pe(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, const mem_pestat_t pes[4], uint64_t id, bseq1_t s[2],
             HRegV a[2]);
 // the same in two halves: decisions (mutates a[]), then emission (pure; honours ctx, read0 = index of s[0] in the batch)

@@ -46,20 +46,69 @@ static int cal_sub(const mem_opt_t *opt, const HRegV &r)
 	return j < r.size() ? r[j].score : opt->min_seed_len * opt->a;
 }
 
+// Votes of the pairs [lo, hi) (pair index) for the insert-size statistics, as histograms over the insert size per
+// orientation (4 x (max_ins + 1) counters) — usable when max_ins is small enough to count (pestat_can_count).  The votes
+// are only ever used sorted, so they can be gathered in any order, by any number of threads, sub-batch by sub-batch.
+bool pestat_can_count(const mem_opt_t *opt) { return opt->max_ins > 0 && opt->max_ins <= (1 << 20); }
+
+void pestat_gather(const mem_opt_t *opt, int64_t l_pac, int lo, int hi, const HRegV *regs, uint64_t *hist)
+{
+	const size_t stride = (size_t)opt->max_ins + 1;
+	for (int i = lo; i < hi; ++i) {
+		const HRegV &r0 = regs[i << 1 | 0], &r1 = regs[i << 1 | 1];
+		if (r0.empty() || r1.empty()) continue;
+		if (cal_sub(opt, r0) > 0.8 * r0[0].score) continue;   // only unique hits vote
+		if (cal_sub(opt, r1) > 0.8 * r1[0].score) continue;
+		if (r0[0].rid != r1[0].rid) continue;
+		int64_t is;
+		int dir = infer_dir(l_pac, r0[0].rb, r1[0].rb, &is);
+		if (is && is <= opt->max_ins) ++hist[dir * stride + is];
+	}
+}
+
+static void pestat_from_sorted(const mem_opt_t *opt, std::vector<uint64_t> isize[4], mem_pestat_t pes[4]);
+
+void pestat_from_hist(const mem_opt_t *opt, const uint64_t *hist, mem_pestat_t pes[4])
+{
+	const size_t stride = (size_t)opt->max_ins + 1;
+	std::vector<uint64_t> isize[4];
+	for (int d = 0; d < 4; ++d) {
+		size_t tot = 0;
+		for (size_t v = 0; v < stride; ++v) tot += hist[d * stride + v];
+		isize[d].reserve(tot);
+		for (size_t v = 0; v < stride; ++v) isize[d].insert(isize[d].end(), hist[d * stride + v], (uint64_t)v);
+	}
+	pestat_from_sorted(opt, isize, pes);
+}
+
 void pestat(const mem_opt_t *opt, int64_t l_pac, int n, const HRegV *regs, mem_pestat_t pes[4], int n_threads)
 {
 	std::vector<uint64_t> isize[4];
-	memset(pes, 0, 4 * sizeof(mem_pestat_t));
 	// The votes are only ever used sorted, so they can be gathered by several threads in any order; with the usual
 	// max_ins (10 000) sorting is a counting sort over the insert sizes.
 	const int np = n >> 1;
-	const bool counting = opt->max_ins > 0 && opt->max_ins <= (1 << 20);
+	const bool counting = pestat_can_count(opt);
 	int nt = std::max(1, std::min(n_threads, np / 4096));
+	if (counting) {
+		const size_t stride = (size_t)opt->max_ins + 1;
+		std::vector<std::vector<uint64_t>> part(nt, std::vector<uint64_t>());
+		auto gather = [&](int t) {
+			part[t].assign(4 * stride, 0);
+			pestat_gather(opt, l_pac, (int)((int64_t)np * t / nt), (int)((int64_t)np * (t + 1) / nt), regs, part[t].data());
+		};
+		std::vector<std::thread> th;
+		for (int t = 1; t < nt; ++t) th.emplace_back(gather, t);
+		gather(0);
+		for (auto &t : th) t.join();
+		for (int t = 1; t < nt; ++t)
+			for (size_t v = 0; v < 4 * stride; ++v) part[0][v] += part[t][v];
+		pestat_from_hist(opt, part[0].data(), pes);
+		return;
+	}
 	std::vector<std::vector<uint64_t>> part(nt * 4);
 	auto gather = [&](int t) {
 		int lo = (int)((int64_t)np * t / nt), hi = (int)((int64_t)np * (t + 1) / nt);
 		std::vector<uint64_t> *out = &part[t * 4];
-		if (counting) for (int d = 0; d < 4; ++d) out[d].assign((size_t)opt->max_ins + 1, 0);
 		for (int i = lo; i < hi; ++i) {
 			const HRegV &r0 = regs[i << 1 | 0], &r1 = regs[i << 1 | 1];
 			if (r0.empty() || r1.empty()) continue;
@@ -68,10 +117,7 @@ void pestat(const mem_opt_t *opt, int64_t l_pac, int n, const HRegV *regs, mem_p
 			if (r0[0].rid != r1[0].rid) continue;
 			int64_t is;
 			int dir = infer_dir(l_pac, r0[0].rb, r1[0].rb, &is);
-			if (is && is <= opt->max_ins) {
-				if (counting) ++out[dir][is];
-				else out[dir].push_back(is);
-			}
+			if (is && is <= opt->max_ins) out[dir].push_back(is);
 		}
 	};
 	{
@@ -81,19 +127,15 @@ void pestat(const mem_opt_t *opt, int64_t l_pac, int n, const HRegV *regs, mem_p
 		for (auto &t : th) t.join();
 	}
 	for (int d = 0; d < 4; ++d) {
-		if (counting) {
-			std::vector<uint64_t> &h = part[d];
-			for (int t = 1; t < nt; ++t)
-				for (size_t v = 0; v < h.size(); ++v) h[v] += part[t * 4 + d][v];
-			size_t tot = 0;
-			for (uint64_t c : h) tot += c;
-			isize[d].reserve(tot);
-			for (size_t v = 0; v < h.size(); ++v) isize[d].insert(isize[d].end(), h[v], (uint64_t)v);
-		} else {
-			for (int t = 0; t < nt; ++t) isize[d].insert(isize[d].end(), part[t * 4 + d].begin(), part[t * 4 + d].end());
-			std::sort(isize[d].begin(), isize[d].end());   // plain integers: every sort gives the same array
-		}
+		for (int t = 0; t < nt; ++t) isize[d].insert(isize[d].end(), part[t * 4 + d].begin(), part[t * 4 + d].end());
+		std::sort(isize[d].begin(), isize[d].end());   // plain integers: every sort gives the same array
 	}
+	pestat_from_sorted(opt, isize, pes);
+}
+
+static void pestat_from_sorted(const mem_opt_t *opt, std::vector<uint64_t> isize[4], mem_pestat_t pes[4])
+{
+	memset(pes, 0, 4 * sizeof(mem_pestat_t));
 	if (bwa_verbose >= 3)
 		fprintf(stderr, "[M::%s] # candidate unique pairs for (FF, FR, RF, RR): (%ld, %ld, %ld, %ld)\n", "mem_pestat",
 		        (long)isize[0].size(), (long)isize[1].size(), (long)isize[2].size(), (long)isize[3].size());

@@ -114,7 +114,7 @@ static void parallel_blocks(int n_threads, int n, int chunk, F f)
 	for (auto &t : th) t.join();
 }
 
-static std::mutex g_smem_turn, g_c2a_turn, g_host_turn;
+static std::mutex g_smem_turn, g_c2a_turn, g_host_turn, g_pes_lock;
 static bool g_host_turns = false;
 
 static double now_ms()
@@ -294,6 +294,10 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	// The stages of one sub-batch are strictly dependent (GPU, host, GPU, host), so two sub-batches run on two host
 	// threads with their own HIP stream and workspace: the GPU work of one overlaps the host work of the other.
 	std::vector<HRegV> regs(n);
+	// insert-size votes are gathered sub-batch by sub-batch (when they will be needed and can be counted)
+	std::vector<uint64_t> pes_hist_v;
+	if (pe && !pes0 && pestat_can_count(opt)) pes_hist_v.assign(4 * ((size_t)opt->max_ins + 1), 0);
+	uint64_t *pes_hist = pes_hist_v.empty() ? nullptr : pes_hist_v.data();
 	struct P1 { double k_smem = 0, k_sa = 0, k_ext = 0, smem = 0, sa = 0, chain = 0, ext = 0, regs = 0; uint64_t smem_bytes = 0, sa_bytes = 0, cells = 0, n_ext = 0, n_intv = 0, n_seeds = 0, n_chains = 0; };
 	const int n_all = n;
 	auto phase1 = [&](int lo, int hi, Workspace &W, HostBuf &reg_arena, hipStream_t st, int n_thr, P1 &ps) {
@@ -638,6 +642,19 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			for (HReg &r : v)
 				if (r.rid >= 0 && bns->anns[r.rid].is_alt) r.is_alt = 1;
 		});
+		// insert-size votes of this sub-batch (src/bwamem_pair.c:52-63), so that the barrier only has to add histograms up
+		if (pes_hist) {
+			const int plo = lo >> 1, np_ = n >> 1, nt = std::max(1, std::min(n_thr, np_ / 4096));
+			const size_t hsz = 4 * ((size_t)opt->max_ins + 1);
+			std::vector<std::vector<uint64_t>> part(nt);
+			parallel_blocks(nt, nt, 1, [&](int, int b, int, int) {
+				part[b].assign(hsz, 0);
+				pestat_gather(opt, bns->l_pac, plo + (int)((int64_t)np_ * b / nt), plo + (int)((int64_t)np_ * (b + 1) / nt), regs.data(), part[b].data());
+			});
+			std::lock_guard<std::mutex> g(g_pes_lock);
+			for (int b = 0; b < nt; ++b)
+				for (size_t v = 0; v < hsz; ++v) pes_hist[v] += part[b][v];
+		}
 		double t6 = now_ms();
 		ps.smem = t2 - t1; ps.sa = t3 - t2; ps.chain = t4 - t3; ps.ext = t5 - t4; ps.regs = t6 - t5;
 	};
@@ -695,6 +712,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	mem_pestat_t pes[4];
 	if (pe) {
 		if (pes0) memcpy(pes, pes0, 4 * sizeof(mem_pestat_t));
+		else if (pes_hist) pestat_from_hist(opt, pes_hist, pes);
 		else pestat(opt, bns->l_pac, n, regs.data(), pes, n_thr);
 	}
 	double t7 = now_ms();
