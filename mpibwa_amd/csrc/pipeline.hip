@@ -114,8 +114,7 @@ static void parallel_blocks(int n_threads, int n, int chunk, F f)
 	for (auto &t : th) t.join();
 }
 
-static std::mutex g_smem_turn, g_c2a_turn, g_host_turn, g_pes_lock;
-static bool g_host_turns = false;
+static std::mutex g_smem_turn, g_c2a_turn, g_pes_lock;
 
 static double now_ms()
 {
@@ -428,9 +427,6 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			ps.k_sa = ev_sa.ms();
 			ps.sa_bytes = ix.fm.sa_full ? (uint64_t)S * 16 : cnt[1] * 64 + (uint64_t)S * 8;
 		}
-		// host stages also take turns (when enabled): each one then runs on all host threads instead of a share of them
-		std::unique_lock<std::mutex> host_turn(g_host_turn, std::defer_lock);
-		if (g_host_turns) host_turn.lock();
 		double t3 = now_ms();
 
 		// chaining and chain filters (host).  Each block of reads is chained by one thread with recycled scratch and packed
@@ -542,7 +538,6 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		ps.n_chains = n_chains_total;
 		const int64_t n_slots = base + NS;    // size of the seed / order / region arrays on the device
 		double t4 = now_ms();
-		if (g_host_turns) host_turn.unlock();
 
 		// chain -> regions on the GPU
 		int *nregs = (int *)W.h_nregs.ensure((size_t)n * 4 + 8);
@@ -618,7 +613,6 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 				hregs = all;
 			}
 		}
-		if (g_host_turns) host_turn.lock();
 		double t5 = now_ms();
 
 		// region post-processing (host); every read gets a slice of the batch-wide arena: its regions + room for rescued mates
@@ -677,7 +671,6 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		std::vector<int> cut(n_sub + 1);
 		for (int k = 0; k <= n_sub; ++k) cut[k] = (int)((int64_t)n * k / n_sub) & ~1;   // keep mates together
 		cut[n_sub] = n;
-		g_host_turns = getenv("MPIBWA_HOST_TURNS") != nullptr;
 		// every lane may use all host threads: while one lane waits for a kernel the other one gets the whole CPU share
 		int thr_each = n_thr;
 		if (const char *e = getenv("MPIBWA_P1_THREADS")) thr_each = std::max(1, atoi(e));
