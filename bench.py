@@ -44,6 +44,7 @@ def main():
                     help="pairs given to the reference for the CPU baseline and the parity check (0 = the whole step batch)")
     ap.add_argument("--read-len", type=int, default=int(os.environ.get("MPIBWA_BENCH_READ_LEN", "150")),
                     help="read length (150 = the headline config; 250 = BASELINE config 4's shape, a parity case)")
+    ap.add_argument("--seed", type=int, default=1000, help="seed of the read simulator (rank r uses seed + r)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workdir", default=os.environ.get("MPIBWA_BENCH_DIR", "/tmp/mpibwa_bench"))
     args = ap.parse_args()
@@ -83,7 +84,7 @@ def main():
             (time.time() - t0, idx.l_pac, idx.blk_bytes / 1e9, idx.sa_bytes / 1e9))
 
     # ---- reads: seeded per rank, same generator as the tests (2 % unmappable, 1 % subst., 0.1 % indel) ----
-    reads = idx.simulate_pairs(args.pairs, seed=1000 + rank, read_len=args.read_len, frag_mean=max(400.0, 2.2 * args.read_len))
+    reads = idx.simulate_pairs(args.pairs, seed=args.seed + rank, read_len=args.read_len, frag_mean=max(400.0, 2.2 * args.read_len))
     batch = abi.SeqBatch(api.libc, reads)
     cores = int(lib.mi355x_host_cpus())
     opt = eng.opt(flag=abi.MEM_F_PE, n_threads=cores)
