@@ -198,41 +198,12 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 		++nout;
 	};
 
-	// One pass per iteration, no inner re-dispatch: [consume the previous extend] -> [backward bookkeeping] ->
-	// [pick the next call / read] -> [forward bookkeeping] -> one bwt_extend for every quad that has a request.
+	// One pass per iteration, no inner re-dispatch: [backward bookkeeping] -> [pick the next call / read] ->
+	// [forward bookkeeping] -> one bwt_extend for every quad that has a request -> [consume its result].
 	bool need = false, back = false;
 	u64 o0 = 0, o1 = 0, o2 = 0;
 	int qi = 0;    // base at position i (forward / LAST-like sweeps)
 	for (;;) {
-		// ---- consume ----
-		if (need) {
-			const int csel = back ? cb : 3 - qi;
-			const u64 s0 = __shfl(o0, qlead | csel), s1 = __shfl(o1, qlead | csel), s2 = __shfl(o2, qlead | csel);
-			if (st == ST_FWD) {
-				bool stop = false;
-				if (s2 != ik2) {
-					push_fwd();
-					if (s2 < (u64)min_intv) { fwd_done(); stop = true; }
-				}
-				if (!stop) { ik0 = s0; ik1 = s1; ik2 = s2; ik_end = i + 1; ++i; }
-			} else if (st == ST_BWD) {
-				if (s2 < (u64)min_intv) {
-					if (nc == 0 && (last_start < 0 || i + 1 < last_start)) {
-						emit(p0, p1, p2, i + 1, (int)p_end);
-						last_start = i + 1;
-					}
-				} else if (nc == 0 || s2 != lastc_x2) {
-					list_store(L, top - 1 - nc, c, s0, s1, s2, p_end);
-					++nc; lastc_x2 = s2;
-				}
-				++j;
-			} else { // ST_P3
-				if (s2 < (u64)sp.max_mem_intv && i - x >= sp.min_seed_len) {
-					if (s2 > 0) emit(s0, s1, s2, x, i + 1);
-					x = i + 1; st = ST_PICK;
-				} else { ik0 = s0; ik1 = s1; ik2 = s2; ++i; }
-			}
-		}
 		need = false;
 		// ---- backward sweep: end of a row, end of the call, or the next list entry ----
 		if (st == ST_BWD) {
@@ -335,6 +306,35 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 		}
 		if (__ballot(st != ST_DONE) == 0) break;
 		if (need) nblk += quad_extend(fm, back ? p0 : ik0, back ? p1 : ik1, back ? p2 : ik2, back, c, o0, o1, o2);
+		// ---- consume ----
+		if (need) {
+			const int csel = back ? cb : 3 - qi;
+			const u64 s0 = __shfl(o0, qlead | csel), s1 = __shfl(o1, qlead | csel), s2 = __shfl(o2, qlead | csel);
+			if (st == ST_FWD) {
+				bool stop = false;
+				if (s2 != ik2) {
+					push_fwd();
+					if (s2 < (u64)min_intv) { fwd_done(); stop = true; }
+				}
+				if (!stop) { ik0 = s0; ik1 = s1; ik2 = s2; ik_end = i + 1; ++i; }
+			} else if (st == ST_BWD) {
+				if (s2 < (u64)min_intv) {
+					if (nc == 0 && (last_start < 0 || i + 1 < last_start)) {
+						emit(p0, p1, p2, i + 1, (int)p_end);
+						last_start = i + 1;
+					}
+				} else if (nc == 0 || s2 != lastc_x2) {
+					list_store(L, top - 1 - nc, c, s0, s1, s2, p_end);
+					++nc; lastc_x2 = s2;
+				}
+				++j;
+			} else { // ST_P3
+				if (s2 < (u64)sp.max_mem_intv && i - x >= sp.min_seed_len) {
+					if (s2 > 0) emit(s0, s1, s2, x, i + 1);
+					x = i + 1; st = ST_PICK;
+				} else { ik0 = s0; ik1 = s1; ik2 = s2; ++i; }
+			}
+		}
 	}
 }
 
