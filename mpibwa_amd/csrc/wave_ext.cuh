@@ -27,27 +27,27 @@ __device__ __forceinline__ int wx_dpp(int old, int v)
 	return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, false);
 }
 
-// inclusive prefix max over the 64 lanes (identity WX_NEG)
+// inclusive prefix max over the 64 lanes: six v_max_i32 with a DPP source operand.  A lane that receives nothing in a
+// step (shifted in from outside its row, or masked by row_mask) is simply not written, so it keeps its own value — no
+// identity constant, no separate v_mov_dpp.  (The builtin form costs three VALU ops per step: the compiler does not
+// fold it.)  s_nop 1: a DPP operand must not be read within two wait states of the VALU write that produced it.
 __device__ __forceinline__ int wx_scan_max(int v)
 {
-	v = max(v, wx_dpp<0x111, 0xf>(WX_NEG, v));   // row_shr:1
-	v = max(v, wx_dpp<0x112, 0xf>(WX_NEG, v));   // row_shr:2
-	v = max(v, wx_dpp<0x114, 0xf>(WX_NEG, v));   // row_shr:4
-	v = max(v, wx_dpp<0x118, 0xf>(WX_NEG, v));   // row_shr:8
-	v = max(v, wx_dpp<0x142, 0xa>(WX_NEG, v));   // row_bcast:15 -> rows 1,3
-	v = max(v, wx_dpp<0x143, 0xc>(WX_NEG, v));   // row_bcast:31 -> rows 2,3
+	asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+	             "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+	             "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+	             "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+	             "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+	             "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+	             "s_nop 1"
+	             : "+v"(v));
 	return v;
 }
-// the same scan with a caller-chosen identity (for value ranges that go below WX_NEG)
+// (kept for callers that pass their own identity: it is no longer needed for correctness)
 __device__ __forceinline__ int wx_scan_max_id(int v, int id)
 {
-	v = max(v, wx_dpp<0x111, 0xf>(id, v));
-	v = max(v, wx_dpp<0x112, 0xf>(id, v));
-	v = max(v, wx_dpp<0x114, 0xf>(id, v));
-	v = max(v, wx_dpp<0x118, 0xf>(id, v));
-	v = max(v, wx_dpp<0x142, 0xa>(id, v));
-	v = max(v, wx_dpp<0x143, 0xc>(id, v));
-	return v;
+	(void)id;
+	return wx_scan_max(v);
 }
 // value of the previous lane (lane 0 gets `first`)
 __device__ __forceinline__ int wx_prev_lane(int v, int first)
