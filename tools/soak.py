@@ -1,0 +1,27 @@
+"""Soak run: many chunks through mem_process_seqs, resident set size and device memory watched for growth."""
+import ctypes as C, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mpibwa_amd import abi, api, bigindex
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+os.makedirs("/tmp/mpibwa_bench", exist_ok=True)
+idx = bigindex.make_or_get("/tmp/mpibwa_bench", genome_mbp=3100, seed=38, log=lambda *a: None)
+eng = idx.engine
+lib = eng.lib
+C.c_int.in_dll(lib, "bwa_verbose").value = 1
+opt = eng.opt(flag=abi.MEM_F_PE, n_threads=int(lib.mi355x_host_cpus()))
+batches = [abi.SeqBatch(api.libc, idx.simulate_pairs(200000 + 1111 * k, seed=50 + k)) for k in range(3)]   # three chunk sizes
+def rss():
+    for l in open("/proc/self/status"):
+        if l.startswith("VmRSS"):
+            return int(l.split()[1]) / 1e6
+t0 = time.time()
+for s in range(steps):
+    b = batches[s % 3]
+    eng.process_batch(opt, b)
+    n = C.c_size_t(0)
+    p = lib.mi355x_collect_sam(b.arr, b.n, C.byref(n))
+    api.libc.free(C.c_void_p(p))
+    if s in (5, 10, 20, steps - 1):
+        free, total = torch.cuda.mem_get_info()
+        print("step %d: RSS %.2f GB, device used %.2f GB, %.1f s" % (s, rss(), (total - free) / 1e9, time.time() - t0), flush=True)
