@@ -33,8 +33,14 @@ namespace mbw {
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
-#define LCAP 24            // interval-list entries kept in LDS per quad (16 B each)
-#define QSLOT 256          // bytes of LDS per quad for the read itself (longer reads are read from HBM)
+// Two LDS footprints per quad: {interval-list entries of 16 B kept in LDS, bytes for the read itself}.
+//   short reads (<= 160 bp): 20 entries + 160 B = 480 B per quad -> 30 KB per workgroup, 5 workgroups per CU (the VGPR limit)
+//   otherwise:               24 entries + 256 B = 640 B per quad -> 40 KB per workgroup, 4 workgroups per CU
+// (measured on 2x150 bp: 24.9 ms -> 22.7-23.5 ms for the whole chunk; 16 entries spill too often, 32 cost a workgroup)
+#define LCAP_S 20
+#define QSLOT_S 160
+#define LCAP 24
+#define QSLOT 256
 #define SMEM_BLOCK 256     // 4 waves = 64 quads per workgroup
 
 template <int CTRL>
@@ -114,20 +120,21 @@ __device__ __forceinline__ int quad_extend(const FmDev &fm, u64 x0, u64 x1, u64 
 // end coordinate (16 bits).  Lane c of the quad stores dword c; every lane reads the whole entry back (one
 // ds_read_b128, broadcast inside the quad).
 struct QuadList {
-	uint4 *lds;      // LCAP entries of this quad
-	uint4 *spill;    // per-quad HBM scratch for entries >= LCAP
+	uint4 *lds;      // `cap` entries of this quad
+	uint4 *spill;    // per-quad HBM scratch for entries >= cap
+	int cap;
 };
 
 __device__ __forceinline__ void list_store(const QuadList &L, int e, int c, u64 x0, u64 x1, u64 x2, u64 end)
 {
 	u32 hi = (u32)(x0 >> 32) | (u32)(x1 >> 32) << 2 | (u32)(x2 >> 32) << 4 | (u32)end << 16;
 	u32 v = c == 0 ? (u32)x0 : c == 1 ? (u32)x1 : c == 2 ? (u32)x2 : hi;
-	u32 *p = (u32 *)(e < LCAP ? L.lds + e : L.spill + (e - LCAP));
+	u32 *p = (u32 *)(e < L.cap ? L.lds + e : L.spill + (e - L.cap));
 	p[c] = v;
 }
 __device__ __forceinline__ void list_load(const QuadList &L, int e, u64 &x0, u64 &x1, u64 &x2, u64 &end)
 {
-	uint4 v = e < LCAP ? L.lds[e] : L.spill[e - LCAP];
+	uint4 v = e < L.cap ? L.lds[e] : L.spill[e - L.cap];
 	x0 = (u64)(v.w & 3) << 32 | v.x;
 	x1 = (u64)(v.w >> 2 & 3) << 32 | v.y;
 	x2 = (u64)(v.w >> 4 & 3) << 32 | v.z;
@@ -138,21 +145,22 @@ enum { ST_PICK = 0, ST_FWD = 1, ST_BWD = 2, ST_P3 = 3, ST_DONE = 4 };
 
 // QLDS: every read of the launch fits its quad's LDS slot, so a base is always a plain LDS byte (otherwise the
 // accessor needs a generic pointer and every base costs a flat load)
-template <bool QLDS>
+template <bool QLDS, int LC, int QS>
 __global__ void __launch_bounds__(SMEM_BLOCK)
 smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ seq, const int64_t *__restrict__ off,
             const int *__restrict__ lens, int cap, u64 *__restrict__ out, int *__restrict__ nout_arr, u64 *counters, uint4 *scratch,
             size_t scratch_ent_per_quad)
 {
-	__shared__ uint4 lds_list[(SMEM_BLOCK / 4) * LCAP];
-	__shared__ uint4 lds_read[(SMEM_BLOCK / 4) * (QSLOT / 16)];
+	__shared__ uint4 lds_list[(SMEM_BLOCK / 4) * LC];
+	__shared__ uint4 lds_read[(SMEM_BLOCK / 4) * (QS / 16)];
 	const int lane = threadIdx.x & 63, c = lane & 3, qlead = lane & ~3;
 	const int quad_in_blk = threadIdx.x >> 2;
 	const size_t quad_gid = (size_t)blockIdx.x * (SMEM_BLOCK / 4) + quad_in_blk;
 	QuadList L;
-	L.lds = lds_list + quad_in_blk * LCAP;
+	L.lds = lds_list + quad_in_blk * LC;
+	L.cap = LC;
 	L.spill = scratch + quad_gid * scratch_ent_per_quad;
-	uint4 *myread = lds_read + quad_in_blk * (QSLOT / 16);
+	uint4 *myread = lds_read + quad_in_blk * (QS / 16);
 	const uint8_t *lq = (const uint8_t *)myread;
 
 	int st = ST_PICK, pass = 0;
@@ -230,7 +238,7 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 				r = __shfl(r, qlead);
 				if (r >= n_reads) { st = ST_DONE; break; }
 				rd = r; gq = seq + off[r]; len = lens[r];
-				q_lds = QLDS || len <= QSLOT;
+				q_lds = QLDS || len <= QS;
 				if (q_lds) {   // off[] is 16-byte aligned: the quad copies the read with 16-B loads
 					const uint4 *src = (const uint4 *)gq;
 					for (int k = c; k * 16 < len; k += 4) myread[k] = src[k];
@@ -368,12 +376,15 @@ void launch_p3_build(void *stream, const FmDev &fm, int k, void *d_tab)
 
 int smem_grid_quads(int max_len, size_t *scratch_per_quad)
 {
-	// 4 workgroups (40 KB LDS, 4 waves each) per CU fill its LDS: nothing else that needs LDS can start next to a running
-	// SMEM launch.  MPIBWA_SMEM_WG_PER_CU=3 leaves room for the small kernels of the other sub-batches.
-	static int per_cu = getenv("MPIBWA_SMEM_WG_PER_CU") ? atoi(getenv("MPIBWA_SMEM_WG_PER_CU")) : 4;
-	if (per_cu < 1 || per_cu > 4) per_cu = 4;
+	// As many workgroups per CU as LDS and registers allow (persistent grid): 5 with the short-read footprint, else 4.
+	// They fill the LDS of the CU: nothing else that needs LDS starts next to a running SMEM launch (leaving room was
+	// measured to cost more than it gives back).  MPIBWA_SMEM_WG_PER_CU overrides.
+	const bool small = max_len <= QSLOT_S;
+	int per_cu = small ? 5 : 4;
+	if (const char *e = getenv("MPIBWA_SMEM_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= per_cu) per_cu = v; }
 	int n_blocks = 256 * per_cu;
-	size_t ent = max_len + 1 > LCAP ? (size_t)(max_len + 1 - LCAP) : 0;
+	const int lc = small ? LCAP_S : LCAP;
+	size_t ent = max_len + 1 > lc ? (size_t)(max_len + 1 - lc) : 0;
 	*scratch_per_quad = (ent + 1) * sizeof(uint4);
 	return n_blocks * (SMEM_BLOCK / 4);
 }
@@ -386,14 +397,13 @@ void launch_smem(void *stream, const FmDev &fm, const SmemParams &sp, int n_read
 	int want = (n_reads + SMEM_BLOCK / 4 - 1) / (SMEM_BLOCK / 4);
 	if (want < 1) want = 1;
 	if (n_blocks > want) n_blocks = want;
-	if (max_len <= QSLOT)
-		hipLaunchKernelGGL(smem_kernel<true>, dim3(n_blocks), dim3(SMEM_BLOCK), 0, (hipStream_t)stream, fm, sp, n_reads, d_seq,
-		                   d_off, d_len, cap, (u64 *)d_out, d_nout, (u64 *)d_counters, (uint4 *)d_scratch,
-		                   scratch_bytes_per_quad / sizeof(uint4));
-	else
-		hipLaunchKernelGGL(smem_kernel<false>, dim3(n_blocks), dim3(SMEM_BLOCK), 0, (hipStream_t)stream, fm, sp, n_reads, d_seq,
-		                   d_off, d_len, cap, (u64 *)d_out, d_nout, (u64 *)d_counters, (uint4 *)d_scratch,
-		                   scratch_bytes_per_quad / sizeof(uint4));
+#define SMEM_LAUNCH(...) hipLaunchKernelGGL((smem_kernel<__VA_ARGS__>), dim3(n_blocks), dim3(SMEM_BLOCK), 0, (hipStream_t)stream, fm, sp, n_reads, d_seq, \
+	                                    d_off, d_len, cap, (u64 *)d_out, d_nout, (u64 *)d_counters, (uint4 *)d_scratch,                          \
+	                                    scratch_bytes_per_quad / sizeof(uint4))
+	if (max_len <= QSLOT_S) SMEM_LAUNCH(true, LCAP_S, QSLOT_S);
+	else if (max_len <= QSLOT) SMEM_LAUNCH(true, LCAP, QSLOT);
+	else SMEM_LAUNCH(false, LCAP, QSLOT);
+#undef SMEM_LAUNCH
 }
 
 // ---------------------------------------------------------------------------
