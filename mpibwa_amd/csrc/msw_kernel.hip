@@ -22,7 +22,7 @@
 // ceiling is flagged and recomputed on the host.
 //
 // Mapping: one request per lane, 64 requests per wave, one wave per workgroup.  The row state of a lane — H(i-1,k), E(i,k)
-// and the query base of position k packed in one dword (13 + 13 + 3 bits) — lives in LDS as cell[k][lane], so the 64
+// the query base of position k and a segment-end flag packed in one dword (13 + 13 + 3 bits, bit 31) — lives in LDS as cell[k][lane], so the 64
 // lanes of a wave touch 64 consecutive dwords (no bank conflicts) and the whole DP runs out of LDS and registers.
 // HBM traffic is the target window (2 bits per row) and one u16 per row for the b[] pass.  The work is VALU-bound:
 // ~30 integer ops per cell.
@@ -69,38 +69,52 @@ __device__ __forceinline__ MswPassOut msw_pass(uint32_t *cell, const MswParams &
 		if (run && i + 1 < tn) tb_next = msw_base(pac, P.l_pac, t0 + (int64_t)(i + 1) * tdir);   // in flight during this row
 		// scores of this row's target base against query codes 0..3 (one byte each) and 4
 		const uint32_t slo = tb == 0 ? P.slo[0] : tb == 1 ? P.slo[1] : tb == 2 ? P.slo[2] : P.slo[3];
-		const int s4 = tb == 0 ? P.s4[0] : tb == 1 ? P.s4[1] : tb == 2 ? P.s4[2] : P.s4[3];
-		int diag = 0, fseg = 0, ffull = 0, cnt = slen;
+		// ... and against code 4 in byte 0 of the high half; bytes 5..7 (codes 5, 6 and the padding code 7) score 0
+		const uint32_t shi = (uint32_t)(uint8_t)(tb == 0 ? P.s4[0] : tb == 1 ? P.s4[1] : tb == 2 ? P.s4[2] : P.s4[3]);
+		int diag = 0, fseg = 0, ffull = 0;
 		uint32_t key = 0;   // (row maximum << 16) | (0xffff - first position reaching it)
 		const int kmax = run ? npos : 0;
 		// uniform trip count: the longest row in the wave (positions are multiples of 8)
 		int kwave = kmax;
 		for (int o = 32; o; o >>= 1) kwave = max(kwave, __shfl_xor(kwave, o));
-		for (int k = 0; k < kwave; k += 4) {
+		auto step = [&](uint32_t &w, int kk) {
+			const int hk = w & 0x1fff;
+			int e = (int)__builtin_amdgcn_ubfe(w, 13, 13);
+			const uint32_t q = __builtin_amdgcn_ubfe(w, 26, 3);
+			// byte q of {shi, slo}: one v_perm_b32 instead of a data-dependent branch per cell
+			const int s = (int)(int8_t)__builtin_amdgcn_perm(shi, slo, q | 0x0c0c0c00u);
+			const int h = max(max(diag + s, e), fseg);               // Hpre(i,k)
+			key = max(key, (uint32_t)h << 16 | (uint32_t)(0xffff - kk));
+			const int hfin = max(h, ffull);                          // H(i,k) after the lazy-F pass
+			e = max(max(e - e_del, h - oe_del), 0);
+			const int t2 = h - oe_ins;
+			fseg = max(max(fseg - e_ins, t2), 0);
+			ffull = max(max(ffull - e_ins, t2), 0);
+			fseg &= ~((int)w >> 31);                                 // bit 31: last position of a segment, F restarts at 0
+			diag = hk;
+			w = (w & 0xfc000000u) | ((uint32_t)e << 13 | (uint32_t)hfin);
+		};
+		// software-pipelined, two register sets: the next four cells are in flight from LDS while four are computed (one
+		// wave per SIMD has nobody else to hide the LDS latency behind)
+		uint32_t wa[4], wb[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) wa[u] = kmax > 0 ? cell[u * 64 + lane] : 0;
+		for (int k = 0; k < kwave; k += 8) {
 			if (k < kmax) {
-				uint32_t w[4];
 #pragma unroll
-				for (int u = 0; u < 4; ++u) w[u] = cell[(k + u) * 64 + lane];
+				for (int u = 0; u < 4; ++u) wb[u] = cell[(k + 4 + u) * 64 + lane];
 #pragma unroll
-				for (int u = 0; u < 4; ++u) {
-					const int hk = w[u] & 0x1fff;
-					int e = (w[u] >> 13) & 0x1fff;
-					const uint32_t q = w[u] >> 26;
-					int s = (int)(int8_t)(slo >> ((q & 3) << 3));
-					s = q < 4 ? s : (q == 4 ? s4 : 0);
-					int h = max(max(diag + s, e), fseg);                 // Hpre(i,k)
-					key = max(key, (uint32_t)h << 16 | (uint32_t)(0xffff - (k + u)));
-					const int hfin = max(h, ffull);                      // H(i,k) after the lazy-F pass
-					e = max(max(e - e_del, h - oe_del), 0);
-					const int t2 = h - oe_ins;
-					fseg = max(max(fseg - e_ins, t2), 0);
-					ffull = max(max(ffull - e_ins, t2), 0);
-					if (--cnt == 0) { fseg = 0; cnt = slen; }
-					diag = hk;
-					w[u] = (uint32_t)hfin | (uint32_t)e << 13 | q << 26;
+				for (int u = 0; u < 4; ++u) step(wa[u], k + u);
+#pragma unroll
+				for (int u = 0; u < 4; ++u) cell[(k + u) * 64 + lane] = wa[u];
+				if (k + 8 < kmax) {
+#pragma unroll
+					for (int u = 0; u < 4; ++u) wa[u] = cell[(k + 8 + u) * 64 + lane];
 				}
 #pragma unroll
-				for (int u = 0; u < 4; ++u) cell[(k + u) * 64 + lane] = w[u];
+				for (int u = 0; u < 4; ++u) step(wb[u], k + 4 + u);
+#pragma unroll
+				for (int u = 0; u < 4; ++u) cell[(k + 4 + u) * 64 + lane] = wb[u];
 			}
 		}
 		if (run) {
@@ -144,7 +158,7 @@ __global__ __launch_bounds__(64) void msw_kernel(MswParams P, int n_req, const M
 				if (rq.is_rev) { uint32_t b = ms[qlen - 1 - k]; c = b < 4 ? 3 - b : 4; }
 				else { c = ms[k]; if (c > 4) c = 4; }
 			}
-			cell[k * 64 + lane] = c << 26;
+			cell[k * 64 + lane] = c << 26 | ((k + 1) % slen == 0 ? 0x80000000u : 0u);
 		}
 	}
 	const int minsc = P.min_seed_len * P.a;              // KSW_XSUBO | min_seed_len * a
@@ -177,11 +191,12 @@ __global__ __launch_bounds__(64) void msw_kernel(MswParams P, int n_req, const M
 	if (qlen2 > 0) {
 		// reverse the codes of positions 0..qe in place, pad the rest, clear H and E
 		for (int k = 0; k < (qlen2 + 1) / 2; ++k) {
-			uint32_t a = cell[k * 64 + lane] >> 26, b = cell[(qlen2 - 1 - k) * 64 + lane] >> 26;
+			uint32_t a = (cell[k * 64 + lane] >> 26) & 7, b = (cell[(qlen2 - 1 - k) * 64 + lane] >> 26) & 7;
 			cell[k * 64 + lane] = b << 26;
 			cell[(qlen2 - 1 - k) * 64 + lane] = a << 26;
 		}
 		for (int k = qlen2; k < npos2; ++k) cell[k * 64 + lane] = MSW_PAD << 26;
+		for (int k = slen2 - 1; k < npos2; k += slen2) cell[k * 64 + lane] |= 0x80000000u;   // segment ends of the shorter query
 	}
 	int sat2 = 0;
 	MswPassOut g = msw_pass(cell, P, pac, qlen2 > 0, npos2, slen2, f.te + 1, rq.rb + f.te, -1, f.score, sat_limit, nullptr, 0, &sat2);
