@@ -46,6 +46,9 @@ def main():
                     help="read length (150 = the headline config; 250 = BASELINE config 4's shape, a parity case)")
     ap.add_argument("--seed", type=int, default=1000, help="seed of the read simulator (rank r uses seed + r)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("MPIBWA_BENCH_IN_FLIGHT", "2")),
+                    help="caller threads inside mem_process_seqs at once (the library runs two calls side by side: "
+                         "the GPU-bound half of one chunk overlaps the host-bound half of the previous one)")
     ap.add_argument("--workdir", default=os.environ.get("MPIBWA_BENCH_DIR", "/tmp/mpibwa_bench"))
     args = ap.parse_args()
 
@@ -85,44 +88,67 @@ def main():
 
     # ---- reads: seeded per rank, same generator as the tests (2 % unmappable, 1 % subst., 0.1 % indel) ----
     reads = idx.simulate_pairs(args.pairs, seed=args.seed + rank, read_len=args.read_len, frag_mean=max(400.0, 2.2 * args.read_len))
-    batch = abi.SeqBatch(api.libc, reads)
+    import hashlib
+    import threading
+    n_fly = max(1, min(args.in_flight, 2))
+    batches = [abi.SeqBatch(api.libc, reads) for _ in range(n_fly)]   # every caller thread owns its bseq1_t[] (and its .sam)
+    batch = batches[0]
     cores = int(lib.mi355x_host_cpus())
     opt = eng.opt(flag=abi.MEM_F_PE, n_threads=cores)
     lib_verbose = C.c_int.in_dll(eng.lib, "bwa_verbose")
     lib_verbose.value = 1   # keep the per-chunk stderr chatter out of the timed region
 
-    pending = []   # seqs[i].sam pointers of finished steps; the caller (mpiBWA's writer thread, src/mainParallel.c:103-127) owns them
+    pending = []   # (thread, seqs[i].sam pointers) of finished steps; the caller (mpiBWA's writer thread, src/mainParallel.c:103-127) owns them
+    lock = threading.Lock()
 
-    def step():
-        eng.process_batch(opt, batch)
-        pending.append(batch._rec["sam"].copy())   # hand the output over, exactly one pointer per read
-        return eng.stats()
+    def run_steps(k_steps, acc):
+        """Exactly k_steps calls of mem_process_seqs, at most n_fly of them in flight."""
+        todo = iter(range(k_steps))
+
+        def worker(t):
+            torch.cuda.set_device(dev)
+            while True:
+                with lock:
+                    if next(todo, None) is None:
+                        return
+                eng.process_batch(opt, batches[t])
+                st = eng.stats()                                          # this thread's last call
+                with lock:
+                    pending.append((t, batches[t]._rec["sam"].copy()))    # hand the output over, one pointer per read
+                    for k, v in st.items():
+                        acc[k] = acc.get(k, 0) + v
+
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(1, n_fly)]
+        for x in th:
+            x.start()
+        worker(0)
+        for x in th:
+            x.join()
+
+    digests = set()
 
     def drain():
         # concatenate + free every step's SAM strings, as mpiBWA's copy_buffer_thr does — outside the timed region,
         # where the reference's writer thread runs concurrently with the next chunk
         tot = 0
-        for ptrs in pending:
-            batch._rec["sam"][:] = ptrs
+        for t, ptrs in pending:
+            batches[t]._rec["sam"][:] = ptrs
             n = C.c_size_t(0)
-            p = lib.mi355x_collect_sam(batch.arr, batch.n, C.byref(n))
+            p = lib.mi355x_collect_sam(batches[t].arr, batches[t].n, C.byref(n))
             tot += n.value
+            digests.add(hashlib.md5(C.string_at(p, n.value)).hexdigest())
             api.libc.free(C.c_void_p(p))
         pending.clear()
         return tot
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup * n_fly, {})   # every in-flight slot warms its own workspaces
     drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     acc = {}
-    for _ in range(args.steps):
-        st = step()
-        for k, v in st.items():
-            acc[k] = acc.get(k, 0) + v
+    run_steps(args.steps, acc)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -132,7 +158,6 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-
     n_reads_total = 2 * args.pairs * args.steps * world
     value = n_reads_total / elapsed / 1e6
 
@@ -162,7 +187,8 @@ def main():
         "vs_baseline": None, "dtype": "int32", "data": "synthetic",
         "config": {"workload": "2x%d bp PE reads vs seeded synthetic %.0f Mbp reference (GRCh38 absent on the box)" % (args.read_len, idx.l_pac / 1e6),
                    "pairs_per_step_per_gpu": args.pairs, "reference_mbp": round(idx.l_pac / 1e6, 1),
-                   "chunking": "one mem_process_seqs chunk per step (mpiBWA -K 1e8 semantics)", "parallelism": "reads sharded, 1 rank/GPU"},
+                   "chunking": "one mem_process_seqs chunk per step (mpiBWA -K 1e8 semantics)", "parallelism": "reads sharded, 1 rank/GPU",
+                   "calls_in_flight": n_fly},
         "sam_bytes_per_step": int(sam_bytes / args.steps),
         "roofline": roofline,
         "stage_ms_per_step": {k: round(acc[k] / args.steps, 2) for k in
@@ -190,6 +216,8 @@ def main():
                 out["cpu_baseline"] = {"value": round(rb.n / dt / 1e6, 5), "unit": "Mreads/s", "cores": cores, "kind": "reference",
                                        "sample": "%d pairs of the same reads, one chunk, reference mem_process_seqs -t %d (%.1f s)" % (len(sample), cores, dt)}
                 out["parity_on_sample"] = bool(got == want)
+                if len(sample) == len(reads):   # every step of the run (warm-up included) produced exactly this SAM
+                    out["all_steps_identical_to_checked_sam"] = bool(digests == {hashlib.md5(b"".join(got)).hexdigest()})
             else:
                 out["cpu_baseline"] = None
         except Exception as e:  # the baseline must never take the bench line down

@@ -143,6 +143,13 @@ typedef struct {
 /* (bwt,bns,pac) must have been uploaded with mi355x_index_upload()    */
 /* first; calling without a usable MI355X device aborts loudly — there */
 /* is no CPU fallback.                                                 */
+/*                                                                     */
+/* Threads: the function may be called from several threads at once    */
+/* (same index, disjoint seqs[]).  Two calls run side by side — the    */
+/* first half of a call is bound by the GPU, the second by the host,   */
+/* so chunk i+1 overlaps chunk i — and further callers wait for a free */
+/* slot.  The reference's own function is re-entrant in the same way   */
+/* (it only reads opt and the index).                                  */
 /* ------------------------------------------------------------------ */
 void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const bntseq_t *bns, const uint8_t *pac,
                       int64_t n_processed, int n, bseq1_t *seqs, const mem_pestat_t *pes0);
@@ -238,7 +245,8 @@ int64_t mi355x_fastq_chunks(const int32_t *bases1, const int32_t *bases2, int64_
 int64_t mi355x_fastq_fill(char *buf1, const int64_t *off1, char *buf2, const int64_t *off2, int64_t first, int64_t count,
                           int copy_comment, int lockstep, bseq1_t *seqs);
 
-/* timing of the last mem_process_seqs() call, per stage (ms) */
+/* timing of the calling thread's last mem_process_seqs() call (of the last call of any thread when this thread
+ * has made none), per stage (ms) */
 typedef struct {
 	double total_ms, h2d_ms, smem_ms, sa_ms, chain_ms, ext_ms, regs_ms, pestat_ms, sam_ms;
 	double k_smem_ms, k_sa_ms, k_ext_ms;        /* HIP-event kernel times */

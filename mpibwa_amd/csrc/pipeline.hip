@@ -19,6 +19,7 @@
 #include <memory>
 #include <mutex>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -197,16 +198,52 @@ struct Workspace {
 	DevBuf chain_off, chains, seeds, srt, reg_off, regs, nregs, tab, areq, ahdr, apool, agap, acnt, areq2, ahdr2, apool2, acnt2;
 };
 static const int MAX_LANES = 4;
-static Workspace g_ws[MAX_LANES];   // one per concurrent sub-batch
-static HostBuf g_reg_arena[16];      // one per sub-batch: the regions live until the SAM stage
-static Workspace g_gws;     // batch-wide buffers (packed reads, CIGAR requests)
+// Everything one mem_process_seqs() call owns between its first and last line.  Two of them: two caller threads may be inside
+// the function at once (chunk i+1 seeding and extending on the GPU while the host pairs and prints chunk i — the stage that
+// keeps the GPU busy and the stage that keeps the host busy belong to different halves of a call).  A third caller waits.
+struct CallCtx {
+	Workspace ws[MAX_LANES];   // one per concurrent sub-batch
+	HostBuf reg_arena[16];     // one per sub-batch: the regions live until the SAM stage
+	Workspace gws;             // batch-wide buffers (packed reads, CIGAR requests)
+	hipStream_t p_streams[MAX_LANES] = {nullptr}, a_streams[2] = {nullptr, nullptr};
+	bool busy = false;
+};
+static const int MAX_CALLS = 2;
+static CallCtx g_ctx[MAX_CALLS];
+static std::mutex g_ctx_mu, g_init_mu;
+static std::condition_variable g_ctx_cv;
+struct CtxLease {
+	CallCtx *c = nullptr;
+	CtxLease()
+	{
+		std::unique_lock<std::mutex> lk(g_ctx_mu);
+		for (;;) {
+			for (int i = 0; i < MAX_CALLS && !c; ++i)
+				if (!g_ctx[i].busy) { c = &g_ctx[i]; c->busy = true; }
+			if (c) break;
+			g_ctx_cv.wait(lk);
+		}
+	}
+	~CtxLease()
+	{
+		{ std::lock_guard<std::mutex> lk(g_ctx_mu); c->busy = false; }
+		g_ctx_cv.notify_one();
+	}
+};
+static thread_local mi355x_stats_t t_stats;   // of the last call made by this thread
+static thread_local bool t_stats_set = false;
 static const void *g_host_bwt = nullptr;
 
 } // namespace mbw
 
 using namespace mbw;
 
-extern "C" void mi355x_last_stats(mi355x_stats_t *st) { *st = g_stats; }
+extern "C" void mi355x_last_stats(mi355x_stats_t *st)
+{
+	if (t_stats_set) { *st = t_stats; return; }
+	std::lock_guard<std::mutex> lk(g_ctx_mu);
+	*st = g_stats;
+}
 extern "C" int mi355x_host_cpus(void) { return usable_cpus(); }
 
 // Caller-side helper mirroring mpiBWA's copy_buffer_thr (src/mainParallel.c:103-127): concatenate all
@@ -237,6 +274,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 {
 	const double t_begin = now_ms(), c_begin = cpu_sec(), s_begin = sys_sec();
 	DevIndex &ix = dev_index();
+	std::unique_lock<std::mutex> init_lk(g_init_mu);
 	if (!ix.ready || g_host_bwt != (const void *)bwt->bwt) {
 		// first call with this index: make it resident (one rank per GPU; LOCAL_RANK as set by torchrun / mpirun wrappers)
 		int lr = 0;
@@ -246,13 +284,25 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		if (!ix.ready) mi355x_index_upload(lr, bwt, bns, pac);
 		g_host_bwt = (const void *)bwt->bwt;
 	}
+	init_lk.unlock();
 	HIP_OK(hipSetDevice(ix.device));
-	memset(&g_stats, 0, sizeof g_stats);
+	mi355x_stats_t STAT;
+	memset(&STAT, 0, sizeof STAT);
+	struct Publish {   // the statistics of this call become visible when it returns, whichever way
+		mi355x_stats_t &s;
+		~Publish() { t_stats = s; t_stats_set = true; std::lock_guard<std::mutex> lk(g_ctx_mu); g_stats = s; }
+	} publish{STAT};
 	if (n <= 0) return;
+	CtxLease lease;
+	CallCtx &C = *lease.c;
 	const int n_thr = host_threads(opt);
 	const bool pe = (opt->flag & MEM_F_PE) != 0;
-	hipStream_t st = 0;
-	Workspace &W = g_gws;
+	if (!C.a_streams[0]) {
+		for (int l = 0; l < MAX_LANES; ++l) HIP_OK(hipStreamCreateWithFlags(&C.p_streams[l], hipStreamNonBlocking));
+		for (int l = 0; l < 2; ++l) HIP_OK(hipStreamCreateWithFlags(&C.a_streams[l], hipStreamNonBlocking));
+	}
+	hipStream_t st = C.p_streams[0];   // never the null stream: another call may be in flight
+	Workspace &W = C.gws;
 
 	// ---- 1. encode + pack ----
 	std::vector<int64_t> off(n + 1);   // 16-byte aligned slot of every read in the packed buffer
@@ -286,8 +336,9 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	ann_off[bns->n_seqs] = bns->l_pac;
 	int64_t *d_ann_off = (int64_t *)W.ann_off.ensure(ann_off.size() * 8);
 	uint8_t *d_ann_alt = (uint8_t *)W.ann_alt.ensure(ann_alt.size());
-	HIP_OK(hipMemcpy(d_ann_off, ann_off.data(), ann_off.size() * 8, hipMemcpyHostToDevice));
-	HIP_OK(hipMemcpy(d_ann_alt, ann_alt.data(), ann_alt.size(), hipMemcpyHostToDevice));
+	HIP_OK(hipMemcpyAsync(d_ann_off, ann_off.data(), ann_off.size() * 8, hipMemcpyHostToDevice, st));
+	HIP_OK(hipMemcpyAsync(d_ann_alt, ann_alt.data(), ann_alt.size(), hipMemcpyHostToDevice, st));
+	HIP_OK(hipStreamSynchronize(st));
 
 	// ---- 2-6. seeding -> SA -> chaining -> extension -> region clean-up, on one or two sub-batches ----
 	// The stages of one sub-batch are strictly dependent (GPU, host, GPU, host), so two sub-batches run on two host
@@ -663,11 +714,9 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	if (const char *e = getenv("MPIBWA_SUBBATCH_MIN")) min_sub = atoi(e);
 	if (n < min_sub) n_sub = n_lanes = 1;
 	std::vector<P1> ps(n_sub);
-	if (n_sub == 1) phase1(0, n, g_ws[0], g_reg_arena[0], st, n_thr, ps[0]);
+	if (n_sub == 1) phase1(0, n, C.ws[0], C.reg_arena[0], st, n_thr, ps[0]);
 	else {
-		static hipStream_t s_streams[MAX_LANES] = {nullptr};
-		for (int l = 0; l < n_lanes; ++l)
-			if (!s_streams[l]) HIP_OK(hipStreamCreateWithFlags(&s_streams[l], hipStreamNonBlocking));
+		hipStream_t *s_streams = C.p_streams;
 		std::vector<int> cut(n_sub + 1);
 		for (int k = 0; k <= n_sub; ++k) cut[k] = (int)((int64_t)n * k / n_sub) & ~1;   // keep mates together
 		cut[n_sub] = n;
@@ -679,7 +728,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			for (;;) {
 				int k = next.fetch_add(1);
 				if (k >= n_sub) break;
-				phase1(cut[k], cut[k + 1], g_ws[l], g_reg_arena[k], s_streams[l], thr_each, ps[k]);
+				phase1(cut[k], cut[k + 1], C.ws[l], C.reg_arena[k], s_streams[l], thr_each, ps[k]);
 			}
 		};
 		std::vector<std::thread> th;
@@ -688,17 +737,17 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		for (auto &t : th) t.join();
 	}
 	for (int k = 0; k < n_sub; ++k) {
-		g_stats.k_smem_ms += ps[k].k_smem; g_stats.k_sa_ms += ps[k].k_sa; g_stats.k_ext_ms += ps[k].k_ext;
-		g_stats.smem_bytes += ps[k].smem_bytes; g_stats.sa_bytes += ps[k].sa_bytes; g_stats.ext_cells += ps[k].cells; g_stats.n_ext += ps[k].n_ext;
-		g_stats.n_intv += ps[k].n_intv; g_stats.n_seeds += ps[k].n_seeds; g_stats.n_chains += ps[k].n_chains;
+		STAT.k_smem_ms += ps[k].k_smem; STAT.k_sa_ms += ps[k].k_sa; STAT.k_ext_ms += ps[k].k_ext;
+		STAT.smem_bytes += ps[k].smem_bytes; STAT.sa_bytes += ps[k].sa_bytes; STAT.ext_cells += ps[k].cells; STAT.n_ext += ps[k].n_ext;
+		STAT.n_intv += ps[k].n_intv; STAT.n_seeds += ps[k].n_seeds; STAT.n_chains += ps[k].n_chains;
 		// per-stage wall times: the sub-batches of a lane run back to back and the lanes side by side, so sum / lanes
-		g_stats.smem_ms += ps[k].smem / n_lanes; g_stats.sa_ms += ps[k].sa / n_lanes;
-		g_stats.chain_ms += ps[k].chain / n_lanes; g_stats.ext_ms += ps[k].ext / n_lanes;
-		g_stats.regs_ms += ps[k].regs / n_lanes;
+		STAT.smem_ms += ps[k].smem / n_lanes; STAT.sa_ms += ps[k].sa / n_lanes;
+		STAT.chain_ms += ps[k].chain / n_lanes; STAT.ext_ms += ps[k].ext / n_lanes;
+		STAT.regs_ms += ps[k].regs / n_lanes;
 	}
 	double t6 = now_ms();
-	g_stats.phase1_ms = t6 - t1;
-	g_stats.n_sub = n_sub;
+	STAT.phase1_ms = t6 - t1;
+	STAT.n_sub = n_sub;
 	const double c6 = cpu_sec();
 
 	// ---- 7. insert-size statistics over the whole batch ----
@@ -741,8 +790,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		EvTimer ev;
 	};
 	Part parts[2];
-	static hipStream_t a_streams[2] = {nullptr, nullptr};
-	if (!a_streams[0]) { HIP_OK(hipStreamCreateWithFlags(&a_streams[0], hipStreamNonBlocking)); HIP_OK(hipStreamCreateWithFlags(&a_streams[1], hipStreamNonBlocking)); }
+	hipStream_t *a_streams = C.a_streams;
 	std::vector<int> gaptab(max_len + 2);
 	for (int l = 0; l <= max_len + 1; ++l) {   // max_gap of bwa_gen_cigar2 (src/bwa.c:155-158), a function of l_query only
 		int max_ins = (int)((double)(((l + 1) >> 1) * opt->mat[0] - opt->o_ins) / opt->e_ins + 1.);
@@ -751,7 +799,8 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		gaptab[l] = g > 1 ? g : 1;
 	}
 	int *d_gap = (int *)W.agap.ensure(gaptab.size() * 4);
-	HIP_OK(hipMemcpy(d_gap, gaptab.data(), gaptab.size() * 4, hipMemcpyHostToDevice));
+	HIP_OK(hipMemcpyAsync(d_gap, gaptab.data(), gaptab.size() * 4, hipMemcpyHostToDevice, st));
+	HIP_OK(hipStreamSynchronize(st));
 	double plan_ms = 0, aln_wait_ms = 0;
 
 	// mate rescue on the device: list the local alignments the pairs of a part will ask for, run them in one launch
@@ -819,8 +868,8 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		double ta = now_ms();
 		stream_wait(P.st);
 		HIP_OK(hipGetLastError());
-		g_stats.k_msw_ms += P.mev.ms();
-		g_stats.n_msw += P.n_mreq;
+		STAT.k_msw_ms += P.mev.ms();
+		STAT.n_msw += P.n_mreq;
 		msw_ms += now_ms() - ta;
 	};
 
@@ -901,15 +950,16 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		double ta = now_ms();
 		stream_wait(P.st);
 		HIP_OK(hipGetLastError());
-		HIP_OK(hipMemcpy(P.cnt, P.d_cnt, 64, hipMemcpyDeviceToHost));
-		g_stats.k_aln_ms += P.ev.ms();
+		HIP_OK(hipMemcpyAsync(P.cnt, P.d_cnt, 64, hipMemcpyDeviceToHost, P.st));
+		HIP_OK(hipStreamSynchronize(P.st));
+		STAT.k_aln_ms += P.ev.ms();
 		size_t used = std::min<size_t>(P.cnt[0], P.pool_bytes);
 		P.hdr = (AlnHdrH *)W.h_ahdr[P.slot].ensure(n_req * sizeof(AlnHdr) + 64);
 		P.pool = (uint8_t *)W.h_apool[P.slot].ensure(used + 64);
 		HIP_OK(hipMemcpyAsync(P.hdr, P.d_hdr, n_req * sizeof(AlnHdr), hipMemcpyDeviceToHost, P.st));
 		if (used) HIP_OK(hipMemcpyAsync(P.pool, P.d_pool, used, hipMemcpyDeviceToHost, P.st));
 		HIP_OK(hipStreamSynchronize(P.st));
-		g_stats.n_aln += n_req;
+		STAT.n_aln += n_req;
 		aln_wait_ms += now_ms() - ta;
 	};
 	double emit_ms = 0;
@@ -949,7 +999,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		finish(parts[0]); replay(parts[0]);
 		finish(parts[1]); replay(parts[1]);
 	}
-	g_stats.plan_ms = plan_ms; g_stats.aln_ms = aln_wait_ms; g_stats.msw_ms = msw_ms; g_stats.emit_ms = emit_ms;
+	STAT.plan_ms = plan_ms; STAT.aln_ms = aln_wait_ms; STAT.msw_ms = msw_ms; STAT.emit_ms = emit_ms;
 	double t8 = now_ms();
 	hprof_report("sam stage");
 	if (s_cpusec) fprintf(stderr, "[plan Mcycles] sam_pe_plan %.0f  emit(collect) %.0f\n", tsc_plan.load() * 1e-6, tsc_emitc.load() * 1e-6);
@@ -958,9 +1008,9 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		        c1 - c_begin, c6 - c1, cpu_sec() - c6, cpu_msw, cpu_collect, cpu_emit, sys_emit, pf_emit, cpu_sec() - c_begin, sys_sec() - s_begin, (t8 - t_begin) * 1e-3);
 	// release the per-read containers in parallel (millions of small blocks: serial destruction costs ~0.2 s per chunk)
 	parallel_for(n_thr, n, 8192, [&](int i) { HRegV().swap(regs[i]); });   // only reads that outgrew their arena slice own memory
-	g_stats.n_reads = n;
-	g_stats.h2d_ms = t1 - t_begin;
-	g_stats.pestat_ms = t7 - t6; g_stats.sam_ms = t8 - t7; g_stats.total_ms = now_ms() - t_begin;
+	STAT.n_reads = n;
+	STAT.h2d_ms = t1 - t_begin;
+	STAT.pestat_ms = t7 - t6; STAT.sam_ms = t8 - t7; STAT.total_ms = now_ms() - t_begin;
 	if (bwa_verbose >= 3)
 		fprintf(stderr, "[M::%s] Processed %d reads in %.3f CPU sec, %.3f real sec\n", "mem_process_seqs", n, cpu_sec() - c_begin,
 		        (t8 - t_begin) * 1e-3);

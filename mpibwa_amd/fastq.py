@@ -100,28 +100,32 @@ class FastqSource:
         return rec, files * count
 
 
-def align_files(engine, opt, r1, r2=None, out=None, K=10_000_000, copy_comment=False, mode=None, n_processed0=0, rank=0, world=1):
+def align_files(engine, opt, r1, r2=None, out=None, K=10_000_000, copy_comment=False, mode=None, n_processed0=0, rank=0, world=1,
+                in_flight=2):
     """`mpiBWA mem` for one rank: its chunks through mem_process_seqs, SAM records in read order.
 
     The chunk list is the same on every rank (it does not depend on the number of ranks); rank r of `world` takes chunks
     r, r + world, ... — the reference hands chunks out with a fetch-and-add counter (src/mainParallel.c:1112-1119), which
     balances better on uneven data but yields the same set of records.  With world > 1 the trimmed branch's running
     n_processed (reads this rank has already done, :2355-2357) is counted over this rank's chunks, as in the reference.
+    in_flight: caller threads inside mem_process_seqs at once (the library takes two: the GPU half of chunk i+1 overlaps the
+    host half of chunk i); the records are written in chunk order whatever the completion order.
     out: a binary file object (the SAM body is written to it) or None (the body is returned as bytes).
     Returns (bytes or None, per-chunk read counts of this rank)."""
+    from concurrent.futures import ThreadPoolExecutor
     lib = engine.lib
     src = FastqSource(lib, r1, r2, K=K, copy_comment=copy_comment, mode=mode)
     pieces = [] if out is None else None
-    todo = queue.Queue(maxsize=2)
+    todo = queue.Queue(maxsize=max(2, in_flight + 1))
     err = []
 
-    def writer():   # copy_buffer_thr: concatenate + free the chunk's SAM strings while the next chunk is being aligned
+    def writer():   # copy_buffer_thr: concatenate + free the chunk's SAM strings while the next chunks are being aligned
         while True:
-            item = todo.get()
-            if item is None:
+            fut = todo.get()
+            if fut is None:
                 return
-            rec, n = item
             try:
+                rec, n = fut.result()
                 tot = C.c_size_t(0)
                 p = lib.mi355x_collect_sam(C.cast(rec.ctypes.data, C.POINTER(abi.bseq1_t)), n, C.byref(tot))
                 data = C.string_at(p, tot.value)
@@ -133,19 +137,24 @@ def align_files(engine, opt, r1, r2=None, out=None, K=10_000_000, copy_comment=F
             except Exception as e:  # pragma: no cover
                 err.append(e)
 
+    def align(c, npz):
+        rec, n = src.chunk(c)
+        lib.mem_process_seqs(opt, engine.bwt, engine.bns, engine.pac, npz, n, C.cast(rec.ctypes.data, C.POINTER(abi.bseq1_t)), None)
+        return rec, n
+
     th = threading.Thread(target=writer, daemon=True)
     th.start()
     counts = []
-    for c in range(rank, src.n_chunks, world):
-        rec, n = src.chunk(c)
-        # mpiBWA passes n_processed = 0 for equal-size pairs and single end, and the reads already done by the rank in
-        # the trimmed branch (src/mainParallel.c:1314, 2355-2357, 3093)
-        npz = n_processed0 + (sum(counts) if src.mode == "pe_trim" else 0)
-        lib.mem_process_seqs(opt, engine.bwt, engine.bns, engine.pac, npz, n, C.cast(rec.ctypes.data, C.POINTER(abi.bseq1_t)), None)
-        counts.append(n)
-        todo.put((rec, n))
-    todo.put(None)
-    th.join()
+    files = 1 if src.f2 is None else 2
+    with ThreadPoolExecutor(max_workers=max(1, in_flight)) as pool:
+        for c in range(rank, src.n_chunks, world):
+            # mpiBWA passes n_processed = 0 for equal-size pairs and single end, and the reads already done by the rank in
+            # the trimmed branch (src/mainParallel.c:1314, 2355-2357, 3093)
+            npz = n_processed0 + (sum(counts) if src.mode == "pe_trim" else 0)
+            counts.append(files * int(src.starts[c + 1] - src.starts[c]))
+            todo.put(pool.submit(align, c, npz))   # blocks while in_flight + 1 chunks are pending: bounded memory
+        todo.put(None)
+        th.join()
     if err:
         raise err[0]
     return (b"".join(pieces) if out is None else None), counts

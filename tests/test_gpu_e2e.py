@@ -177,3 +177,33 @@ def test_overlapped_sub_batches_and_host_cigar_paths(both, reads_pe, monkeypatch
     monkeypatch.delenv("MPIBWA_HOST_CIGAR")
     assert eng.process(eng.opt(flag=abi.MEM_F_PE), ra) == want
     assert eng.stats()["n_msw"] > 0
+
+
+@needs_ref
+def test_calls_in_flight_from_several_threads(both, reads_pe, monkeypatch):
+    """Two caller threads may be inside mem_process_seqs at once (a third one waits): different chunks, different
+    options, many rounds — every call returns the bytes the reference gives for its chunk."""
+    import threading
+    eng, ref = both
+    ra = simulate.reads_to_ascii(reads_pe)
+    monkeypatch.setenv("MPIBWA_SUBBATCH_MIN", "100")   # the sub-batch lanes and the two-part SAM stage as for big chunks
+    jobs = [(ra, dict(flag=abi.MEM_F_PE)), (ra[:300], dict(flag=abi.MEM_F_PE)), (ra[100:], dict(flag=abi.MEM_F_PE, T=20)),
+            ([(n, a, None) for n, a, _ in ra], dict(flag=0))]
+    want = [ref.process(ref.opt(**kw), r) for r, kw in jobs]
+    bad = []
+
+    def caller(t):
+        for rnd in range(6):
+            j = (t + rnd) % len(jobs)
+            r, kw = jobs[j]
+            got = eng.process(eng.opt(**kw), r)
+            st = eng.stats()
+            if got != want[j] or st["n_reads"] != len(got):
+                bad.append((t, rnd, j))
+
+    th = [threading.Thread(target=caller, args=(t,)) for t in range(3)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not bad, bad
