@@ -46,8 +46,8 @@ def main():
                     help="read length (150 = the headline config; 250 = BASELINE config 4's shape, a parity case)")
     ap.add_argument("--seed", type=int, default=1000, help="seed of the read simulator (rank r uses seed + r)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("MPIBWA_BENCH_IN_FLIGHT", "2")),
-                    help="caller threads inside mem_process_seqs at once (the library runs two calls side by side: "
+    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("MPIBWA_BENCH_IN_FLIGHT", "3")),
+                    help="caller threads inside mem_process_seqs at once (the library runs up to three calls side by side: "
                          "the GPU-bound half of one chunk overlaps the host-bound half of the previous one)")
     ap.add_argument("--workdir", default=os.environ.get("MPIBWA_BENCH_DIR", "/tmp/mpibwa_bench"))
     args = ap.parse_args()
@@ -90,7 +90,7 @@ def main():
     reads = idx.simulate_pairs(args.pairs, seed=args.seed + rank, read_len=args.read_len, frag_mean=max(400.0, 2.2 * args.read_len))
     import hashlib
     import threading
-    n_fly = max(1, min(args.in_flight, 2))
+    n_fly = max(1, min(args.in_flight, 3))
     batches = [abi.SeqBatch(api.libc, reads) for _ in range(n_fly)]   # every caller thread owns its bseq1_t[] (and its .sam)
     batch = batches[0]
     cores = int(lib.mi355x_host_cpus())
@@ -154,6 +154,11 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     sam_bytes = drain()
+    # one more call with nothing else in flight, outside the timed region: the kernels' durations when they have the GPU
+    # to themselves (inside the timed region a launch shares the chip with the kernels of the other calls)
+    alone = {}
+    run_steps(1, alone)
+    drain()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -179,6 +184,10 @@ def main():
                 "frac": round(ach / 8000.0, 4), "traffic": traffic,
                 "launch_ms": round(acc["k_smem_ms"] / n_launch, 3), "algo_bytes_per_launch": int(acc["smem_bytes"] / n_launch),
                 "launches_per_step": n_launch // args.steps}
+    if alone.get("k_smem_ms") and alone.get("n_sub"):
+        a1 = alone["smem_bytes"] / (alone["k_smem_ms"] * 1e-3) / 1e9
+        roofline["one_call_in_flight"] = {"launch_ms": round(alone["k_smem_ms"] / alone["n_sub"], 3), "achieved": round(a1, 1),
+                                          "frac": round(a1 / 8000.0, 4)}
 
     out = {
         "metric": "Mreads/s (whole node) 2x150 bp PE vs GRCh38-size reference; SAM bit-match",

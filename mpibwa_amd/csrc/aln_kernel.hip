@@ -46,6 +46,11 @@ __device__ __forceinline__ int put_num(uint8_t *md, int len, int v, int lane)
 	return len + n;
 }
 
+// FAST: only the requests that need no DP (same length, band 0: src/bwa.c:143-151) — four of five.  They need no direction
+// matrix, so their workgroups take 1.4 KB of LDS instead of 17 KB and the CU holds as many waves as it has slots for;
+// the latency of the dependent fetches (request -> read offset -> bases) is what such a request costs.  !FAST: the rest.
+// Both kernels are launched over the whole request list and a wave returns at once when the request is not its kind.
+template <bool FAST>
 __global__ void __launch_bounds__(64 * ALN_WAVES)
 aln_kernel(AlnParams P, WxParams X, int n_req, const AlnReq *__restrict__ reqs, const uint8_t *__restrict__ seq,
            const int64_t *__restrict__ off, const uint8_t *__restrict__ pac, const int *__restrict__ gaptab, AlnHdr *__restrict__ hdr,
@@ -57,15 +62,25 @@ aln_kernel(AlnParams P, WxParams X, int n_req, const AlnReq *__restrict__ reqs, 
 	if (rq >= n_req) return;
 	// carve this wavefront's LDS
 	const int ALN_ZCAP = aln_zcap(max_len);
-	const size_t per_wave = (size_t)2 * (max_len + 2) * 4 + ((max_len + 3) & ~3) + ((tcap + 3) & ~3) + ALN_ZCAP + ALN_MDCAP + ALN_CIGCAP * 4;
-	uint8_t *base = (uint8_t *)lds_raw + (size_t)wave * per_wave;
 	AlnLds L;
-	L.H = (int *)base; L.E = L.H + (max_len + 2);
-	L.cig = (uint32_t *)(L.E + (max_len + 2));
-	L.q = (uint8_t *)(L.cig + ALN_CIGCAP);
-	L.t = L.q + ((max_len + 3) & ~3);
-	L.z = L.t + ((tcap + 3) & ~3);
-	L.md = L.z + ALN_ZCAP;
+	if (FAST) {
+		const size_t per_wave = (size_t)2 * ((max_len + 3) & ~3) + ALN_MDCAP + 16;
+		uint8_t *base = (uint8_t *)lds_raw + (size_t)wave * per_wave;
+		L.H = L.E = nullptr; L.z = nullptr;
+		L.cig = (uint32_t *)base;
+		L.q = base + 16;
+		L.t = L.q + ((max_len + 3) & ~3);
+		L.md = L.t + ((max_len + 3) & ~3);
+	} else {
+		const size_t per_wave = (size_t)2 * (max_len + 2) * 4 + ((max_len + 3) & ~3) + ((tcap + 3) & ~3) + ALN_ZCAP + ALN_MDCAP + ALN_CIGCAP * 4;
+		uint8_t *base = (uint8_t *)lds_raw + (size_t)wave * per_wave;
+		L.H = (int *)base; L.E = L.H + (max_len + 2);
+		L.cig = (uint32_t *)(L.E + (max_len + 2));
+		L.q = (uint8_t *)(L.cig + ALN_CIGCAP);
+		L.t = L.q + ((max_len + 3) & ~3);
+		L.z = L.t + ((tcap + 3) & ~3);
+		L.md = L.z + ALN_ZCAP;
+	}
 
 	const AlnReq R = reqs[rq];
 	const int lq = R.qe - R.qb;
@@ -73,7 +88,10 @@ aln_kernel(AlnParams P, WxParams X, int n_req, const AlnReq *__restrict__ reqs, 
 	AlnHdr out;
 	out.score = 0; out.NM = -1; out.n_cigar = 0; out.md_len = 0; out.pool_off = 0; out.flags = 0;
 	const bool bridging = R.rb < P.l_pac && R.re > P.l_pac;
-	if (lq <= 0 || rlen64 <= 0 || bridging || lq > max_len || rlen64 > tcap) {
+	const bool invalid = lq <= 0 || rlen64 <= 0 || bridging || lq > max_len || rlen64 > tcap;
+	const bool no_dp = !invalid && rlen64 == lq && (R.w2 < (P.w << 2) ? R.w2 : (P.w << 2)) == 0;   // stays so in every round of the loop below
+	if (FAST != no_dp) return;
+	if (invalid) {
 		out.flags = 1;   // host fallback (also reproduces the reference's rejection cases)
 		if (lane == 0) hdr[rq] = out;
 		return;
@@ -100,12 +118,18 @@ aln_kernel(AlnParams P, WxParams X, int n_req, const AlnReq *__restrict__ reqs, 
 	bool fallback = false;
 	for (int it = 0;; ) {
 		w2 = w2 < wmax4 ? w2 : wmax4;
-		if (lq == rlen && w2 == 0) {   // ungapped: no DP (src/bwa.c:143-151)
+		if (FAST) {   // ungapped: no DP (src/bwa.c:143-151); lq == rlen && w2 == 0
 			int s = 0;
 			for (int i = lane; i < lq; i += 64) s += X.mat[L.t[i] * 5 + L.q[i]];
 			score = wave_sum_int(s);
 			n_cig = 1;
 			if (lane == 0) L.cig[0] = (uint32_t)lq << 4;
+			// the other lanes read it below: without this the compiler sinks their load into the else-side of the
+			// lane-0 branch, which the hardware runs first
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			break;   // a second round of mem_reg2aln's loop would take the same shortcut and stop on score == last_sc
 		} else {
 			int d_len = rlen - lq; d_len = d_len < 0 ? -d_len : d_len;
 			int w = (gaptab[lq] + d_len + 1) >> 1;
@@ -279,10 +303,14 @@ void launch_aln(void *stream, const AlnParams &P, const ExtParams &ep, int n_req
 	for (int i = 0; i < 25; ++i) X.mat[i] = ep.mat[i];
 	X.o_del = ep.o_del; X.e_del = ep.e_del; X.o_ins = ep.o_ins; X.e_ins = ep.e_ins; X.zdrop = ep.zdrop;
 	size_t shmem = aln_lds_per_block(max_len, tcap);
+	const size_t shmem_fast = ((size_t)2 * ((max_len + 3) & ~3) + ALN_MDCAP + 16) * ALN_WAVES;
 	int n_blocks = (n_req + ALN_WAVES - 1) / ALN_WAVES;
-	if (shmem > 64 * 1024 && hipFuncSetAttribute((const void *)aln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)
+	if (shmem > 64 * 1024 && hipFuncSetAttribute((const void *)aln_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)
 		die("aln_kernel: cannot reserve %zu bytes of LDS", shmem);
-	hipLaunchKernelGGL(aln_kernel, dim3(n_blocks), dim3(64 * ALN_WAVES), shmem, (hipStream_t)stream, P, X, n_req, d_req, d_seq, d_off, d_pac,
+	if (shmem_fast > 64 * 1024) die("aln_kernel: reads of %d bp do not fit the LDS staging buffers", max_len);
+	hipLaunchKernelGGL(aln_kernel<true>, dim3(n_blocks), dim3(64 * ALN_WAVES), shmem_fast, (hipStream_t)stream, P, X, n_req, d_req, d_seq, d_off, d_pac,
+	                   d_gaptab, d_hdr, d_pool, d_counters, (unsigned long long)pool_bytes, max_len, tcap);
+	hipLaunchKernelGGL(aln_kernel<false>, dim3(n_blocks), dim3(64 * ALN_WAVES), shmem, (hipStream_t)stream, P, X, n_req, d_req, d_seq, d_off, d_pac,
 	                   d_gaptab, d_hdr, d_pool, d_counters, (unsigned long long)pool_bytes, max_len, tcap);
 }
 

@@ -208,7 +208,7 @@ struct CallCtx {
 	hipStream_t p_streams[MAX_LANES] = {nullptr}, a_streams[2] = {nullptr, nullptr};
 	bool busy = false;
 };
-static const int MAX_CALLS = 2;
+static const int MAX_CALLS = 3;
 static CallCtx g_ctx[MAX_CALLS];
 static std::mutex g_ctx_mu, g_init_mu;
 static std::condition_variable g_ctx_cv;
