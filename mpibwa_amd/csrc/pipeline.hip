@@ -766,7 +766,8 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	const int n_units = pe ? n >> 1 : n;
 	std::vector<PairPlan> plans(pe ? n_units : 0);
 	const bool gpu_aln = getenv("MPIBWA_HOST_CIGAR") == nullptr;
-	const int n_parts = (gpu_aln && n_units >= 20000 && n_sub > 1) ? 2 : 1;
+	int n_parts = (gpu_aln && n_units >= 20000 && n_sub > 1) ? 2 : 1;
+	if (const char *e = getenv("MPIBWA_SAM_PARTS")) n_parts = std::max(1, std::min(2, atoi(e)));
 	struct Part {
 		int lo = 0, hi = 0;
 		std::vector<AlnReqH> req;
