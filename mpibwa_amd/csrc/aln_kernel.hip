@@ -113,6 +113,14 @@ aln_kernel(AlnParams P, WxParams X, int n_req, const AlnReq *__restrict__ reqs, 
 	__builtin_amdgcn_wave_barrier();
 
 	const int oe_del = X.o_del + X.e_del, oe_ins = X.o_ins + X.e_ins, e_del = X.e_del, e_ins = X.e_ins;
+	// scoring matrix rows as packed bytes (see wave_ext.cuh): byte q of {phi[t], plo[t]} = mat[t][q]
+	uint32_t plo[5], phi[5];
+#pragma unroll
+	for (int t = 0; t < 5; ++t) {
+		plo[t] = (uint32_t)(uint8_t)X.mat[t * 5] | (uint32_t)(uint8_t)X.mat[t * 5 + 1] << 8 | (uint32_t)(uint8_t)X.mat[t * 5 + 2] << 16 |
+		         (uint32_t)(uint8_t)X.mat[t * 5 + 3] << 24;
+		phi[t] = (uint32_t)(uint8_t)X.mat[t * 5 + 4];
+	}
 	const int wmax4 = P.w << 2;
 	int w2 = R.w2, last_sc = -(1 << 30), score = 0, n_cig = 0;
 	bool fallback = false;
@@ -145,8 +153,9 @@ aln_kernel(AlnParams P, WxParams X, int n_req, const AlnReq *__restrict__ reqs, 
 			}
 			__builtin_amdgcn_wave_barrier();
 			for (int i = 0; i < rlen; ++i) {
-				const int tb = L.t[i];
-				const int m0 = X.mat[tb * 5 + 0], m1 = X.mat[tb * 5 + 1], m2 = X.mat[tb * 5 + 2], m3 = X.mat[tb * 5 + 3], m4 = X.mat[tb * 5 + 4];
+				const int tb = __builtin_amdgcn_readfirstlane((int)L.t[i]);
+				const uint32_t slo = tb == 0 ? plo[0] : tb == 1 ? plo[1] : tb == 2 ? plo[2] : tb == 3 ? plo[3] : plo[4];
+				const uint32_t shi = tb == 0 ? phi[0] : tb == 1 ? phi[1] : tb == 2 ? phi[2] : tb == 3 ? phi[3] : phi[4];
 				const int beg = i > w ? i - w : 0, end = i + w + 1 < lq ? i + w + 1 : lq;
 				const int hleft0 = beg == 0 ? -(X.o_del + e_del * (i + 1)) : ALN_NEG;
 				int A = ALN_NEG;   // running max of g_k + e_ins over the columns already done (F(i,beg) = -inf)
@@ -162,7 +171,7 @@ aln_kernel(AlnParams P, WxParams X, int n_req, const AlnReq *__restrict__ reqs, 
 						const int nxt = (s + 1) << 6;
 						if (nxt <= lq) diag0 = L.H[nxt];
 						const int qb = act ? (int)L.q[j] : 4;
-						const int sc = qb == 0 ? m0 : qb == 1 ? m1 : qb == 2 ? m2 : qb == 3 ? m3 : m4;
+						const int sc = (int)(int8_t)__builtin_amdgcn_perm(shi, slo, (uint32_t)qb | 0x0c0c0c00u);
 						const int m = diag + sc;
 						const int g = act ? m - oe_ins + j * e_ins : ALN_NEG - (1 << 28);
 						const int incl = wx_scan_max_id(g, ALN_NEG - (1 << 28));

@@ -98,11 +98,20 @@ __device__ __forceinline__ WxResult wave_extend(int qlen, QF qf, int tlen, TF tf
 	int best = h0, best_i = -1, best_j = -1, best_ie = -1, gscore = -1, max_off = 0;
 	int beg = 0, end = qlen;
 	int tv = 0, tv_base = -64;
+	// the five rows of the scoring matrix as packed bytes in scalar registers: byte q of {hi, lo} = mat[t][q], so the
+	// score of a cell is one v_perm_b32 (+ sign extension) instead of a chain of four compares and selects
+	uint32_t plo[5], phi[5];
+#pragma unroll
+	for (int t = 0; t < 5; ++t) {
+		plo[t] = (uint32_t)(uint8_t)P.mat[t * 5] | (uint32_t)(uint8_t)P.mat[t * 5 + 1] << 8 | (uint32_t)(uint8_t)P.mat[t * 5 + 2] << 16 |
+		         (uint32_t)(uint8_t)P.mat[t * 5 + 3] << 24;
+		phi[t] = (uint32_t)(uint8_t)P.mat[t * 5 + 4];
+	}
 	for (int i = 0; i < tlen; ++i) {
 		if (i - tv_base >= 64) { tv_base = i; tv = (i + lane < tlen) ? (int)tf(i + lane) : 4; }
 		const int tb = __builtin_amdgcn_readlane(tv, i - tv_base);
-		const int m0 = P.mat[tb * 5 + 0], m1 = P.mat[tb * 5 + 1], m2 = P.mat[tb * 5 + 2], m3 = P.mat[tb * 5 + 3],
-		          m4 = P.mat[tb * 5 + 4];
+		const uint32_t slo = tb == 0 ? plo[0] : tb == 1 ? plo[1] : tb == 2 ? plo[2] : tb == 3 ? plo[3] : plo[4];
+		const uint32_t shi = tb == 0 ? phi[0] : tb == 1 ? phi[1] : tb == 2 ? phi[2] : tb == 3 ? phi[3] : phi[4];
 		if (beg < i - w) beg = i - w;
 		if (end > i + w + 1) end = i + w + 1;
 		if (end > qlen) end = qlen;
@@ -124,7 +133,7 @@ __device__ __forceinline__ WxResult wave_extend(int qlen, QF qf, int tlen, TF tf
 				const int nxt = (s + 1) << 6;
 				if (nxt <= qlen) diag0 = H[nxt];
 				int qb = act ? (int)qf(j) : 4;
-				int sc = qb == 0 ? m0 : qb == 1 ? m1 : qb == 2 ? m2 : qb == 3 ? m3 : m4;
+				const int sc = (int)(int8_t)__builtin_amdgcn_perm(shi, slo, (uint32_t)qb | 0x0c0c0c00u);
 				int M = diag ? diag + sc : 0;
 				int tI = M - oe_ins; tI = tI > 0 ? tI : 0;
 				int g = act ? tI + j * e_ins : WX_NEG;
