@@ -147,12 +147,14 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    c0 = time.process_time()
     acc = {}
     run_steps(args.steps, acc)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    host_cpu_s = time.process_time() - c0
     sam_bytes = drain()
     # one more call with nothing else in flight, outside the timed region: the kernels' durations when they have the GPU
     # to themselves (inside the timed region a launch shares the chip with the kernels of the other calls)
@@ -199,6 +201,7 @@ def main():
                    "chunking": "one mem_process_seqs chunk per step (mpiBWA -K 1e8 semantics)", "parallelism": "reads sharded, 1 rank/GPU",
                    "calls_in_flight": n_fly},
         "sam_bytes_per_step": int(sam_bytes / args.steps),
+        "host_cpu_s_per_step": round(host_cpu_s / args.steps, 3), "host_cpu_busy_frac": round(host_cpu_s / (elapsed * max(cores, 1)), 3),
         "roofline": roofline,
         "stage_ms_per_step": {k: round(acc[k] / args.steps, 2) for k in
                               ("total_ms", "h2d_ms", "phase1_ms", "smem_ms", "sa_ms", "chain_ms", "ext_ms", "regs_ms", "pestat_ms", "sam_ms", "msw_ms", "plan_ms", "aln_ms", "emit_ms", "k_smem_ms", "k_sa_ms", "k_ext_ms", "k_msw_ms", "k_aln_ms")},

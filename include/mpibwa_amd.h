@@ -145,10 +145,10 @@ typedef struct {
 /* is no CPU fallback.                                                 */
 /*                                                                     */
 /* Threads: the function may be called from several threads at once    */
-/* (same index, disjoint seqs[]).  Two calls run side by side — the    */
-/* first half of a call is bound by the GPU, the second by the host,   */
-/* so chunk i+1 overlaps chunk i — and further callers wait for a free */
-/* slot.  The reference's own function is re-entrant in the same way   */
+/* (same index, disjoint seqs[]).  Up to three calls run side by side  */
+/* — the first half of a call is bound by the GPU, the second by the   */
+/* host, so chunk i+1 overlaps chunk i — and further callers wait for  */
+/* a free slot.  The reference's own function is re-entrant in the same way   */
 /* (it only reads opt and the index).                                  */
 /* ------------------------------------------------------------------ */
 void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const bntseq_t *bns, const uint8_t *pac,

@@ -7,10 +7,18 @@
 //   host   nt4-encode, pack reads                              (bwamem.c:1057-1058)
 //   GPU    SMEM seeding                 smem_kernel            (bwamem.c:114-162)
 //   GPU    interval sort / seed enumeration                    (bwamem.c:161, 265-283)
-//   GPU    suffix-array lookup          sa_kernel              (bwt.c:86-96)
-//   host   chaining + chain filters     (ordered-map logic)    (bwamem.c:251-385, 598-617)
+//   GPU    suffix-array lookup          sa_dense_kernel        (bwt.c:86-96)
+//   GPU    chaining + chain filters     chain_kernel           (bwamem.c:251-385, 598-617); host for reads beyond one B-tree node
 //   GPU    chain -> regions, banded DP  c2a_kernel             (bwamem.c:632-786, ksw.c:380-479)
-//   host   dedup / patch, pestat, mate rescue, pairing, CIGAR, SAM text
+//   host   dedup / patch, insert-size votes                    (bwamem.c:439-497, bwamem_pair.c:59-109)
+//   ---- mem_pestat over the whole chunk ----
+//   GPU    mate-rescue local alignment  msw_kernel             (bwamem_pair.c:111-180, ksw.c:111-356)
+//   host   pairing decisions                                   (bwamem_pair.c:182-388)
+//   GPU    CIGAR / MD / NM              aln_kernel             (bwamem.c:1106-1122, bwa.c:121-207)
+//   host   SAM text                                            (bwamem.c:824-1010)
+//
+// Up to three calls run side by side (CallCtx below): the GPU-bound first half of one chunk overlaps the host-bound
+// second half of another.
 //
 // There is no CPU fallback for the GPU stages: without a gfx950 device the call aborts.
 #include <hip/hip_runtime.h>
@@ -198,9 +206,9 @@ struct Workspace {
 	DevBuf chain_off, chains, seeds, srt, reg_off, regs, nregs, tab, areq, ahdr, apool, agap, acnt, areq2, ahdr2, apool2, acnt2;
 };
 static const int MAX_LANES = 4;
-// Everything one mem_process_seqs() call owns between its first and last line.  Two of them: two caller threads may be inside
+// Everything one mem_process_seqs() call owns between its first and last line.  Three of them: three caller threads may be inside
 // the function at once (chunk i+1 seeding and extending on the GPU while the host pairs and prints chunk i — the stage that
-// keeps the GPU busy and the stage that keeps the host busy belong to different halves of a call).  A third caller waits.
+// keeps the GPU busy and the stage that keeps the host busy belong to different halves of a call).  A fourth caller waits.
 struct CallCtx {
 	Workspace ws[MAX_LANES];   // one per concurrent sub-batch
 	HostBuf reg_arena[16];     // one per sub-batch: the regions live until the SAM stage
@@ -340,8 +348,8 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	HIP_OK(hipMemcpyAsync(d_ann_alt, ann_alt.data(), ann_alt.size(), hipMemcpyHostToDevice, st));
 	HIP_OK(hipStreamSynchronize(st));
 
-	// ---- 2-6. seeding -> SA -> chaining -> extension -> region clean-up, on one or two sub-batches ----
-	// The stages of one sub-batch are strictly dependent (GPU, host, GPU, host), so two sub-batches run on two host
+	// ---- 2-6. seeding -> SA -> chaining -> extension -> region clean-up, in sub-batches ----
+	// The stages of one sub-batch are strictly dependent (GPU, host, GPU, host), so several sub-batches run on their own host
 	// threads with their own HIP stream and workspace: the GPU work of one overlaps the host work of the other.
 	std::vector<HRegV> regs(n);
 	// insert-size votes are gathered sub-batch by sub-batch (when they will be needed and can be counted)
@@ -404,7 +412,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			d_intv = (uint64_t *)W.intv.ensure((size_t)n * cap * 32);
 			d_nintv = (int *)W.nintv.ensure((size_t)n * 4);
 			HIP_OK(hipMemsetAsync(d_cnt, 0, 256, st));
-			// the two sub-batches take turns on the big kernels: each one fills the chip by itself, and running them one
+			// the sub-batches (and the other calls in flight) take turns on the big kernels: each one fills the chip by itself, and running them one
 			// after the other staggers the sub-batches so that the host stages of one fall under the kernels of the other
 			std::unique_lock<std::mutex> turn(g_smem_turn);
 			ev_smem.start(st);
@@ -704,7 +712,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		ps.smem = t2 - t1; ps.sa = t3 - t2; ps.chain = t4 - t3; ps.ext = t5 - t4; ps.regs = t6 - t5;
 	};
 
-	// K sub-batches are worked off by up to two host threads ("lanes"), each with its own HIP stream and workspace
+	// K sub-batches are worked off by up to MAX_LANES host threads ("lanes"), each with its own HIP stream and workspace
 	int n_sub = 3, n_lanes = 3;
 	if (const char *e = getenv("MPIBWA_SUBBATCH")) n_sub = atoi(e);
 	if (const char *e = getenv("MPIBWA_LANES")) n_lanes = atoi(e);
