@@ -17,6 +17,8 @@ namespace mbw {
 #define ALN_WAVES 1
 // direction bytes per wavefront: grows with the read length (a band of ~40 columns at every row), at least 12 KB
 __host__ __device__ inline int aln_zcap(int max_len) { int z = 80 * (max_len + 32); z = (z + 255) & ~255; return z < 12288 ? 12288 : z; }
+// ... and of the narrow-band variant: 32 columns at every row
+__host__ __device__ inline int aln_zcap_small(int max_len) { int z = 32 * (max_len + 32); return (z + 255) & ~255; }
 #define ALN_MDCAP 768
 #define ALN_CIGCAP 96
 #define ALN_NEG (-0x40000000)
@@ -46,11 +48,17 @@ __device__ __forceinline__ int put_num(uint8_t *md, int len, int v, int lane)
 	return len + n;
 }
 
-// FAST: only the requests that need no DP (same length, band 0: src/bwa.c:143-151) — four of five.  They need no direction
-// matrix, so their workgroups take 1.4 KB of LDS instead of 17 KB and the CU holds as many waves as it has slots for;
-// the latency of the dependent fetches (request -> read offset -> bases) is what such a request costs.  !FAST: the rest.
-// Both kernels are launched over the whole request list and a wave returns at once when the request is not its kind.
-template <bool FAST>
+// Three instantiations, launched one after the other over the whole request list; a wave returns at once when the request is
+// not its kind.
+//   KIND 0  the requests that need no DP (same length, band 0: src/bwa.c:143-151) — four of five.  No direction matrix, so a
+//           workgroup takes 1.1 KB of LDS instead of 17 KB and the CU holds as many waves as it has slots for; the latency
+//           of the dependent fetches (request -> read offset -> bases) is what such a request costs.
+//   KIND 1  DP with a direction matrix of at most 32 columns per row (8.7 KB of LDS per wave: 16 waves per CU instead of 9 —
+//           a row is a chain of dependent LDS and cross-lane steps, so the waves per SIMD set the rate).  A request whose
+//           band outgrows that in one of mem_reg2aln's rounds is marked (flags = 2) and left to
+//   KIND 2  the full-size variant, which starts those requests again from the first round.
+#define ALN_PENDING 2
+template <int KIND>
 __global__ void __launch_bounds__(64 * ALN_WAVES)
 aln_kernel(AlnParams P, WxParams X, int n_req, const AlnReq *__restrict__ reqs, const uint8_t *__restrict__ seq,
            const int64_t *__restrict__ off, const uint8_t *__restrict__ pac, const int *__restrict__ gaptab, AlnHdr *__restrict__ hdr,
@@ -61,7 +69,8 @@ aln_kernel(AlnParams P, WxParams X, int n_req, const AlnReq *__restrict__ reqs, 
 	const int rq = blockIdx.x * ALN_WAVES + wave;
 	if (rq >= n_req) return;
 	// carve this wavefront's LDS
-	const int ALN_ZCAP = aln_zcap(max_len);
+	constexpr bool FAST = KIND == 0;
+	const int ALN_ZCAP = KIND == 1 ? aln_zcap_small(max_len) : aln_zcap(max_len);
 	AlnLds L;
 	if (FAST) {
 		const size_t per_wave = (size_t)2 * ((max_len + 3) & ~3) + ALN_MDCAP + 16;
@@ -91,6 +100,7 @@ aln_kernel(AlnParams P, WxParams X, int n_req, const AlnReq *__restrict__ reqs, 
 	const bool invalid = lq <= 0 || rlen64 <= 0 || bridging || lq > max_len || rlen64 > tcap;
 	const bool no_dp = !invalid && rlen64 == lq && (R.w2 < (P.w << 2) ? R.w2 : (P.w << 2)) == 0;   // stays so in every round of the loop below
 	if (FAST != no_dp) return;
+	if (KIND == 2 && hdr[rq].flags != ALN_PENDING) return;   // written by the KIND 1 launch before this one on the stream
 	if (invalid) {
 		out.flags = 1;   // host fallback (also reproduces the reference's rejection cases)
 		if (lane == 0) hdr[rq] = out;
@@ -145,7 +155,7 @@ aln_kernel(AlnParams P, WxParams X, int n_req, const AlnReq *__restrict__ reqs, 
 			const int min_w = d_len + 3;
 			w = w > min_w ? w : min_w;
 			const int n_col = lq < 2 * w + 1 ? lq : 2 * w + 1;
-			if ((long long)n_col * rlen > ALN_ZCAP) { fallback = true; break; }
+			if ((long long)n_col * rlen > ALN_ZCAP) { fallback = true; break; }   // KIND 1: to the full-size variant; KIND 2: to the host
 			// ---- banded global DP (src/ksw.c:523-589) ----
 			for (int j = lane; j <= lq; j += 64) {
 				L.H[j] = j == 0 ? 0 : (j <= w ? -(X.o_ins + e_ins * j) : ALN_NEG);
@@ -229,7 +239,7 @@ aln_kernel(AlnParams P, WxParams X, int n_req, const AlnReq *__restrict__ reqs, 
 		if (!(++it < 3 && score < R.truesc - P.a)) break;
 	}
 	if (fallback) {
-		out.flags = 1;
+		out.flags = KIND == 1 ? ALN_PENDING : 1;
 		if (lane == 0) hdr[rq] = out;
 		return;
 	}
@@ -311,16 +321,22 @@ void launch_aln(void *stream, const AlnParams &P, const ExtParams &ep, int n_req
 	WxParams X;
 	for (int i = 0; i < 25; ++i) X.mat[i] = ep.mat[i];
 	X.o_del = ep.o_del; X.e_del = ep.e_del; X.o_ins = ep.o_ins; X.e_ins = ep.e_ins; X.zdrop = ep.zdrop;
-	size_t shmem = aln_lds_per_block(max_len, tcap);
+	const size_t shmem = aln_lds_per_block(max_len, tcap);
+	const size_t shmem_small = shmem - (size_t)(aln_zcap(max_len) - aln_zcap_small(max_len)) * ALN_WAVES;
 	const size_t shmem_fast = ((size_t)2 * ((max_len + 3) & ~3) + ALN_MDCAP + 16) * ALN_WAVES;
 	int n_blocks = (n_req + ALN_WAVES - 1) / ALN_WAVES;
-	if (shmem > 64 * 1024 && hipFuncSetAttribute((const void *)aln_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)
+	if (shmem > 64 * 1024 && hipFuncSetAttribute((const void *)aln_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)
 		die("aln_kernel: cannot reserve %zu bytes of LDS", shmem);
+	if (shmem_small > 64 * 1024 && hipFuncSetAttribute((const void *)aln_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_small) != hipSuccess)
+		die("aln_kernel: cannot reserve %zu bytes of LDS", shmem_small);
 	if (shmem_fast > 64 * 1024) die("aln_kernel: reads of %d bp do not fit the LDS staging buffers", max_len);
-	hipLaunchKernelGGL(aln_kernel<true>, dim3(n_blocks), dim3(64 * ALN_WAVES), shmem_fast, (hipStream_t)stream, P, X, n_req, d_req, d_seq, d_off, d_pac,
-	                   d_gaptab, d_hdr, d_pool, d_counters, (unsigned long long)pool_bytes, max_len, tcap);
-	hipLaunchKernelGGL(aln_kernel<false>, dim3(n_blocks), dim3(64 * ALN_WAVES), shmem, (hipStream_t)stream, P, X, n_req, d_req, d_seq, d_off, d_pac,
-	                   d_gaptab, d_hdr, d_pool, d_counters, (unsigned long long)pool_bytes, max_len, tcap);
+	const dim3 grid(n_blocks), block(64 * ALN_WAVES);
+	hipLaunchKernelGGL(aln_kernel<0>, grid, block, shmem_fast, (hipStream_t)stream, P, X, n_req, d_req, d_seq, d_off, d_pac, d_gaptab, d_hdr, d_pool,
+	                   d_counters, (unsigned long long)pool_bytes, max_len, tcap);
+	hipLaunchKernelGGL(aln_kernel<1>, grid, block, shmem_small, (hipStream_t)stream, P, X, n_req, d_req, d_seq, d_off, d_pac, d_gaptab, d_hdr, d_pool,
+	                   d_counters, (unsigned long long)pool_bytes, max_len, tcap);
+	hipLaunchKernelGGL(aln_kernel<2>, grid, block, shmem, (hipStream_t)stream, P, X, n_req, d_req, d_seq, d_off, d_pac, d_gaptab, d_hdr, d_pool,
+	                   d_counters, (unsigned long long)pool_bytes, max_len, tcap);
 }
 
 } // namespace mbw

@@ -207,3 +207,29 @@ def test_calls_in_flight_from_several_threads(both, reads_pe, monkeypatch):
     for x in th:
         x.join()
     assert not bad, bad
+
+
+@needs_ref
+def test_long_indels_take_the_wide_band_paths(both, genome):
+    """Reads with insertions / deletions of 8 to 40 bp: their CIGARs need bands beyond the narrow direction matrix (the
+    full-size variant of the CIGAR kernel, and the host for the few that outgrow that too).  Same bytes as the reference."""
+    eng, ref = both
+    g = genome["seqs"][0]
+    lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    rng = np.random.default_rng(77)
+    reads = []
+    for k in range(240):
+        L = int(rng.integers(8, 41))
+        p = int(rng.integers(1000, len(g) - 2000))
+        cut = int(rng.integers(40, 110))
+        if k % 2:      # deletion in the read: skip L reference bases
+            r1 = np.concatenate([g[p:p + cut], g[p + cut + L:p + 150 + L]])
+        else:          # insertion in the read: L random bases
+            r1 = np.concatenate([g[p:p + cut], rng.integers(0, 4, L).astype(g.dtype), g[p + cut:p + 150 - L]])
+        m = g[p + 300:p + 450]
+        r2 = simulate._COMP[np.minimum(m, 3)][::-1]
+        reads.append(("indel%d" % k, lut[np.minimum(r1, 4)].tobytes(), lut[np.minimum(r2, 4)].tobytes()))
+    _cmp(eng, ref, reads, dict(flag=abi.MEM_F_PE))
+    _cmp(eng, ref, reads, dict(flag=abi.MEM_F_PE, w=200))          # wider extension band: longer gaps survive into the CIGAR
+    _cmp(eng, ref, [(n, a, None) for n, a, b in reads], dict(flag=0, o_del=3, o_ins=3))
+    assert eng.stats()["n_aln"] > 0
