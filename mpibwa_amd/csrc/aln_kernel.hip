@@ -9,6 +9,7 @@
 // LDS (cheap because thousands of wavefronts do theirs concurrently).  Regions whose band matrix does not fit the
 // LDS budget are flagged and re-done by the host (rare: long gaps).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include "device.h"
 #include "wave_ext.cuh"
 
@@ -48,8 +49,9 @@ __device__ __forceinline__ int put_num(uint8_t *md, int len, int v, int lane)
 	return len + n;
 }
 
-// Three instantiations, launched one after the other over the whole request list; a wave returns at once when the request is
-// not its kind.
+// Three instantiations, launched one after the other.  A classification pass (aln_classify_kernel) sorts the request numbers
+// into one list per kind first, and the waves of a kind walk their list with a grid-sized stride — nobody launches a
+// workgroup per request only to find that the request belongs to another variant.
 //   KIND 0  the requests that need no DP (same length, band 0: src/bwa.c:143-151) — four of five.  No direction matrix, so a
 //           workgroup takes 1.1 KB of LDS instead of 17 KB and the CU holds as many waves as it has slots for; the latency
 //           of the dependent fetches (request -> read offset -> bases) is what such a request costs.
@@ -58,16 +60,50 @@ __device__ __forceinline__ int put_num(uint8_t *md, int len, int v, int lane)
 //           band outgrows that in one of mem_reg2aln's rounds is marked (flags = 2) and left to
 //   KIND 2  the full-size variant, which starts those requests again from the first round.
 #define ALN_PENDING 2
+// counters[]: [0] bytes of the result pool handed out, [ALN_CNT + k] length of the request list of kind k
+#define ALN_CNT 8
+
+__device__ __forceinline__ bool aln_invalid(const AlnParams &P, const AlnReq &R, int max_len, int tcap)
+{
+	const int lq = R.qe - R.qb;
+	const long long rlen64 = R.re - R.rb;
+	const bool bridging = R.rb < P.l_pac && R.re > P.l_pac;
+	return lq <= 0 || rlen64 <= 0 || bridging || lq > max_len || rlen64 > tcap;
+}
+__device__ __forceinline__ bool aln_no_dp(const AlnParams &P, const AlnReq &R, int max_len, int tcap)
+{
+	// stays so in every round of mem_reg2aln's loop
+	return !aln_invalid(P, R, max_len, tcap) && R.re - R.rb == R.qe - R.qb && (R.w2 < (P.w << 2) ? R.w2 : (P.w << 2)) == 0;
+}
+
+// request numbers -> lists[0 .. n_req) (no DP) and lists[n_req .. 2 n_req) (DP); one atomic per wave and list
+__global__ void __launch_bounds__(256) aln_classify_kernel(AlnParams P, int n_req, const AlnReq *__restrict__ reqs, int max_len, int tcap,
+                                                           int *__restrict__ lists, unsigned long long *counters)
+{
+	const int rq = blockIdx.x * 256 + threadIdx.x;
+	const bool live = rq < n_req;
+	bool nodp = false;
+	if (live) nodp = aln_no_dp(P, reqs[rq], max_len, tcap);
+	const unsigned long long below = (1ull << (threadIdx.x & 63)) - 1;
+	for (int kind = 0; kind < 2; ++kind) {
+		const bool mine = live && (nodp == (kind == 0));
+		const unsigned long long m = __ballot(mine);
+		if (!m) continue;
+		unsigned long long base = 0;
+		if ((threadIdx.x & 63) == __ffsll((long long)m) - 1) base = atomicAdd(&counters[ALN_CNT + kind], (unsigned long long)__popcll(m));
+		base = __shfl(base, __ffsll((long long)m) - 1);
+		if (mine) lists[(size_t)kind * n_req + base + __popcll(m & below)] = rq;
+	}
+}
+
 template <int KIND>
-__global__ void __launch_bounds__(64 * ALN_WAVES)
-aln_kernel(AlnParams P, WxParams X, int n_req, const AlnReq *__restrict__ reqs, const uint8_t *__restrict__ seq,
-           const int64_t *__restrict__ off, const uint8_t *__restrict__ pac, const int *__restrict__ gaptab, AlnHdr *__restrict__ hdr,
-           uint8_t *__restrict__ pool, unsigned long long *counters, unsigned long long pool_bytes, int max_len, int tcap)
+__device__ __forceinline__ void aln_one(int rq, const AlnParams &P, const WxParams &X, int n_req, const AlnReq *__restrict__ reqs,
+                                        const uint8_t *__restrict__ seq, const int64_t *__restrict__ off, const uint8_t *__restrict__ pac,
+                                        const int *__restrict__ gaptab, AlnHdr *__restrict__ hdr, uint8_t *__restrict__ pool,
+                                        unsigned long long *counters, unsigned long long pool_bytes, int max_len, int tcap, int *lists)
 {
 	extern __shared__ int lds_raw[];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const int rq = blockIdx.x * ALN_WAVES + wave;
-	if (rq >= n_req) return;
 	// carve this wavefront's LDS
 	constexpr bool FAST = KIND == 0;
 	const int ALN_ZCAP = KIND == 1 ? aln_zcap_small(max_len) : aln_zcap(max_len);
@@ -96,11 +132,7 @@ aln_kernel(AlnParams P, WxParams X, int n_req, const AlnReq *__restrict__ reqs, 
 	const long long rlen64 = R.re - R.rb;
 	AlnHdr out;
 	out.score = 0; out.NM = -1; out.n_cigar = 0; out.md_len = 0; out.pool_off = 0; out.flags = 0;
-	const bool bridging = R.rb < P.l_pac && R.re > P.l_pac;
-	const bool invalid = lq <= 0 || rlen64 <= 0 || bridging || lq > max_len || rlen64 > tcap;
-	const bool no_dp = !invalid && rlen64 == lq && (R.w2 < (P.w << 2) ? R.w2 : (P.w << 2)) == 0;   // stays so in every round of the loop below
-	if (FAST != no_dp) return;
-	if (KIND == 2 && hdr[rq].flags != ALN_PENDING) return;   // written by the KIND 1 launch before this one on the stream
+	const bool invalid = aln_invalid(P, R, max_len, tcap);
 	if (invalid) {
 		out.flags = 1;   // host fallback (also reproduces the reference's rejection cases)
 		if (lane == 0) hdr[rq] = out;
@@ -239,7 +271,11 @@ aln_kernel(AlnParams P, WxParams X, int n_req, const AlnReq *__restrict__ reqs, 
 		if (!(++it < 3 && score < R.truesc - P.a)) break;
 	}
 	if (fallback) {
-		out.flags = KIND == 1 ? ALN_PENDING : 1;
+		if (KIND == 1) {   // to the full-size variant: append to its list
+			if (lane == 0) lists[(size_t)2 * n_req + atomicAdd(&counters[ALN_CNT + 2], 1ull)] = rq;
+			return;
+		}
+		out.flags = 1;
 		if (lane == 0) hdr[rq] = out;
 		return;
 	}
@@ -307,6 +343,24 @@ aln_kernel(AlnParams P, WxParams X, int n_req, const AlnReq *__restrict__ reqs, 
 	if (lane == 0) hdr[rq] = out;
 }
 
+template <int KIND>
+__global__ void __launch_bounds__(64 * ALN_WAVES)
+aln_kernel(AlnParams P, WxParams X, int n_req, const AlnReq *__restrict__ reqs, const uint8_t *__restrict__ seq,
+           const int64_t *__restrict__ off, const uint8_t *__restrict__ pac, const int *__restrict__ gaptab, AlnHdr *__restrict__ hdr,
+           uint8_t *__restrict__ pool, unsigned long long *counters, unsigned long long pool_bytes, int max_len, int tcap, int *lists)
+{
+	const int wave = threadIdx.x >> 6;
+	// KIND 2's list is filled by the KIND 1 launch before this one on the stream
+	const int n = (int)counters[ALN_CNT + KIND];
+	const int *mine = lists + (size_t)KIND * n_req;
+	for (int k = blockIdx.x * ALN_WAVES + wave; k < n; k += gridDim.x * ALN_WAVES) {
+		aln_one<KIND>(mine[k], P, X, n_req, reqs, seq, off, pac, gaptab, hdr, pool, counters, pool_bytes, max_len, tcap, lists);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the wave's LDS slice is reused by its next request
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	}
+}
+
 size_t aln_lds_per_block(int max_len, int tcap)
 {
 	const int ALN_ZCAP = aln_zcap(max_len);
@@ -316,27 +370,44 @@ size_t aln_lds_per_block(int max_len, int tcap)
 
 void launch_aln(void *stream, const AlnParams &P, const ExtParams &ep, int n_req, const AlnReq *d_req, const uint8_t *d_seq,
                 const int64_t *d_off, const uint8_t *d_pac, const int *d_gaptab, AlnHdr *d_hdr, uint8_t *d_pool,
-                unsigned long long *d_counters, size_t pool_bytes, int max_len, int tcap)
+                unsigned long long *d_counters, size_t pool_bytes, int max_len, int tcap, int *d_lists)
 {
+	if (n_req <= 0) return;
 	WxParams X;
 	for (int i = 0; i < 25; ++i) X.mat[i] = ep.mat[i];
 	X.o_del = ep.o_del; X.e_del = ep.e_del; X.o_ins = ep.o_ins; X.e_ins = ep.e_ins; X.zdrop = ep.zdrop;
 	const size_t shmem = aln_lds_per_block(max_len, tcap);
 	const size_t shmem_small = shmem - (size_t)(aln_zcap(max_len) - aln_zcap_small(max_len)) * ALN_WAVES;
 	const size_t shmem_fast = ((size_t)2 * ((max_len + 3) & ~3) + ALN_MDCAP + 16) * ALN_WAVES;
-	int n_blocks = (n_req + ALN_WAVES - 1) / ALN_WAVES;
 	if (shmem > 64 * 1024 && hipFuncSetAttribute((const void *)aln_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)
 		die("aln_kernel: cannot reserve %zu bytes of LDS", shmem);
 	if (shmem_small > 64 * 1024 && hipFuncSetAttribute((const void *)aln_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_small) != hipSuccess)
 		die("aln_kernel: cannot reserve %zu bytes of LDS", shmem_small);
 	if (shmem_fast > 64 * 1024) die("aln_kernel: reads of %d bp do not fit the LDS staging buffers", max_len);
-	const dim3 grid(n_blocks), block(64 * ALN_WAVES);
-	hipLaunchKernelGGL(aln_kernel<0>, grid, block, shmem_fast, (hipStream_t)stream, P, X, n_req, d_req, d_seq, d_off, d_pac, d_gaptab, d_hdr, d_pool,
-	                   d_counters, (unsigned long long)pool_bytes, max_len, tcap);
-	hipLaunchKernelGGL(aln_kernel<1>, grid, block, shmem_small, (hipStream_t)stream, P, X, n_req, d_req, d_seq, d_off, d_pac, d_gaptab, d_hdr, d_pool,
-	                   d_counters, (unsigned long long)pool_bytes, max_len, tcap);
-	hipLaunchKernelGGL(aln_kernel<2>, grid, block, shmem, (hipStream_t)stream, P, X, n_req, d_req, d_seq, d_off, d_pac, d_gaptab, d_hdr, d_pool,
-	                   d_counters, (unsigned long long)pool_bytes, max_len, tcap);
+	static int s_cus = 0;
+	if (!s_cus) {
+		int dev = 0;
+		hipDeviceProp_t prop;
+		if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) die("aln_kernel: cannot query the device");
+		s_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	}
+	// enough workgroups to fill every wave slot the variant's LDS footprint leaves, twice over (the requests of a list
+	// differ in length, so a wave takes the next one as soon as it is done)
+	auto grid_for = [&](size_t lds) {
+		long long per_cu = (long long)(160 * 1024 / std::max<size_t>(lds, 1));
+		per_cu = std::max(1ll, std::min(per_cu, 32ll / ALN_WAVES));
+		return dim3((unsigned)std::min<long long>((long long)s_cus * per_cu * 2, ((long long)n_req + ALN_WAVES - 1) / ALN_WAVES));
+	};
+	const dim3 block(64 * ALN_WAVES);
+	hipStream_t st = (hipStream_t)stream;
+	hipLaunchKernelGGL(aln_classify_kernel, dim3((n_req + 255) / 256), dim3(256), 0, st, P, n_req, d_req, max_len, tcap, d_lists, d_counters);
+	hipLaunchKernelGGL(aln_kernel<0>, grid_for(shmem_fast), block, shmem_fast, st, P, X, n_req, d_req, d_seq, d_off, d_pac, d_gaptab, d_hdr, d_pool,
+	                   d_counters, (unsigned long long)pool_bytes, max_len, tcap, d_lists);
+	hipLaunchKernelGGL(aln_kernel<1>, grid_for(shmem_small), block, shmem_small, st, P, X, n_req, d_req, d_seq, d_off, d_pac, d_gaptab, d_hdr, d_pool,
+	                   d_counters, (unsigned long long)pool_bytes, max_len, tcap, d_lists);
+	hipLaunchKernelGGL(aln_kernel<2>, grid_for(shmem), block, shmem, st, P, X, n_req, d_req, d_seq, d_off, d_pac, d_gaptab, d_hdr, d_pool,
+	                   d_counters, (unsigned long long)pool_bytes, max_len, tcap, d_lists);
+	if (hipGetLastError() != hipSuccess) die("aln_kernel: launch failed");
 }
 
 } // namespace mbw

@@ -140,7 +140,7 @@ struct AlnHdr {                  // result header; cigar (n_cigar x u32) and MD 
 struct AlnParams { int64_t l_pac; int a, w; };
 void launch_aln(void *stream, const AlnParams &P, const ExtParams &ep, int n_req, const AlnReq *d_req, const uint8_t *d_seq,
                 const int64_t *d_off, const uint8_t *d_pac, const int *d_gaptab, AlnHdr *d_hdr, uint8_t *d_pool,
-                unsigned long long *d_counters, size_t pool_bytes, int max_len, int tcap);
+                unsigned long long *d_counters, size_t pool_bytes, int max_len, int tcap, int *d_lists /* 3 * n_req ints of scratch */);
 
 // ---- mate-rescue local alignment on the device (msw_kernel.hip) ----
 struct MswReq {                  // one ksw_align2() call of mem_matesw (src/bwamem_pair.c:150-177)

@@ -201,7 +201,7 @@ struct Workspace {
 	PinBuf h_order;
 	PinBuf h_regs2;
 	PinBuf h_flat, h_sa, h_qbl, h_chains, h_seeds, h_srt, h_regs, h_nregs, h_mreq[2], h_mres[2], h_ahdr[2], h_apool[2];
-	DevBuf mreq[2], mres[2], mrows[2];
+	DevBuf mreq[2], mres[2], mrows[2], alist[2];
 	DevBuf seq, off, len, intv, nintv, cnt, scratch, nseeds, lrep, seed_off, rows, qbl, sa;
 	DevBuf chain_off, chains, seeds, srt, reg_off, regs, nregs, tab, areq, ahdr, apool, agap, acnt, areq2, ahdr2, apool2, acnt2;
 };
@@ -949,8 +949,9 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		memcpy(ep.mat, opt->mat, 25);
 		ep.o_del = opt->o_del; ep.e_del = opt->e_del; ep.o_ins = opt->o_ins; ep.e_ins = opt->e_ins; ep.zdrop = opt->zdrop;
 		P.ev.start(P.st);
+		int *d_lists = (int *)W.alist[slot].ensure(n_req * 3 * sizeof(int));
 		launch_aln(P.st, ap, ep, (int)n_req, d_req, d_seq, d_off, (const uint8_t *)ix.d_pac, d_gap, P.d_hdr, P.d_pool, P.d_cnt, P.pool_bytes, max_len,
-		           max_len + 256);
+		           max_len + 256, d_lists);
 		P.ev.stop(P.st);   // results are fetched in finish(): a D2H copy into pageable memory would block the host here
 	};
 	auto finish = [&](Part &P) {   // wait for B, fetch the pool
