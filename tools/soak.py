@@ -15,13 +15,24 @@ def rss():
     for l in open("/proc/self/status"):
         if l.startswith("VmRSS"):
             return int(l.split()[1]) / 1e6
+import threading
 t0 = time.time()
-for s in range(steps):
-    b = batches[s % 3]
-    eng.process_batch(opt, b)
-    n = C.c_size_t(0)
-    p = lib.mi355x_collect_sam(b.arr, b.n, C.byref(n))
-    api.libc.free(C.c_void_p(p))
-    if s in (5, 10, 20, steps - 1):
-        free, total = torch.cuda.mem_get_info()
-        print("step %d: RSS %.2f GB, device used %.2f GB, %.1f s" % (s, rss(), (total - free) / 1e9, time.time() - t0), flush=True)
+lock = threading.Lock()
+todo = iter(range(steps))
+def caller(t):   # three callers in flight, each with its own chunk size
+    b = batches[t]
+    while True:
+        with lock:
+            s = next(todo, None)
+        if s is None:
+            return
+        eng.process_batch(opt, b)
+        n = C.c_size_t(0)
+        p = lib.mi355x_collect_sam(b.arr, b.n, C.byref(n))
+        api.libc.free(C.c_void_p(p))
+        if s in (8, 32, 120, 240, 360, steps - 1):
+            free, total = torch.cuda.mem_get_info()
+            print("step %d: RSS %.2f GB, device used %.2f GB, %.1f s" % (s, rss(), (total - free) / 1e9, time.time() - t0), flush=True)
+th = [threading.Thread(target=caller, args=(t,)) for t in range(3)]
+for x in th: x.start()
+for x in th: x.join()
