@@ -14,6 +14,8 @@
 
 #include <cctype>
 #include <cstring>
+#include <thread>
+#include <vector>
 
 using namespace mbw;
 
@@ -86,15 +88,20 @@ extern "C" int64_t mi355x_fastq_fill(char *buf1, const int64_t *off1, char *buf2
                                      int copy_comment, int lockstep, bseq1_t *seqs)
 {
 	const int files = buf2 ? 2 : 1;
+	// records are independent of each other: a few threads take contiguous ranges (a chunk is ~700 000 records)
+	const int n_thr = count >= 65536 ? 8 : 1;
+	std::vector<int64_t> t_bases(n_thr, 0), t_bad(n_thr, -1);
+	auto range = [&](int tid) {
+	const int64_t k_lo = count * tid / n_thr, k_hi = count * (tid + 1) / n_thr;
 	int64_t bases = 0;
-	for (int64_t k = 0; k < count; ++k) {
+	for (int64_t k = k_lo; k < k_hi; ++k) {
 		int64_t name_end1 = 0, ws1 = -1, comment1 = 0;   // offsets inside R1's header line (ws1 < 0: no white space in it)
 		for (int f = 0; f < files; ++f) {
 			char *buf = f ? buf2 : buf1;
 			const int64_t *off = f ? off2 : off1;
 			bseq1_t *s = &seqs[files * k + f];
 			RecLines r;
-			if (!split_record(buf + off[first + k], buf + off[first + k + 1], r)) return -(k + 1);
+			if (!split_record(buf + off[first + k], buf + off[first + k + 1], r)) { t_bad[tid] = k; return; }
 			char *h = r.line[0], *hend = h + r.len[0];
 			char *p;
 			if (f == 1 && lockstep) {
@@ -120,6 +127,17 @@ extern "C" int64_t mi355x_fastq_fill(char *buf1, const int64_t *off1, char *buf2
 			s->id = 0;
 			bases += r.len[1];
 		}
+	}
+	t_bases[tid] = bases;
+	};
+	std::vector<std::thread> th;
+	for (int t = 1; t < n_thr; ++t) th.emplace_back(range, t);
+	range(0);
+	for (auto &t : th) t.join();
+	int64_t bases = 0;
+	for (int t = 0; t < n_thr; ++t) {
+		if (t_bad[t] >= 0) return -(t_bad[t] + 1);   // the first malformed record (ranges are in record order)
+		bases += t_bases[t];
 	}
 	return bases;
 }

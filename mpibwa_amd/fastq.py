@@ -9,6 +9,7 @@ by a writer thread while chunk i+1 is on the GPU (src/mainParallel.c:103-127 `co
 """
 import ctypes as C
 import gzip
+import os
 import queue
 import threading
 
@@ -21,10 +22,27 @@ _libc.free.argtypes = [C.c_void_p]
 
 
 def _load(path):
-    data = gzip.open(path, "rb").read() if str(path).endswith(".gz") else open(path, "rb").read()
-    # one spare byte: the last quality line is NUL-terminated in place even when the file has no final newline
-    buf = C.create_string_buffer(data, len(data) + 1)
-    return buf, len(data)
+    """(keep-alive object, address, length) of the file's bytes in writable memory with one spare byte after them: the
+    strings are NUL-terminated (and the bases nt4-encoded) in place, the last quality line even when the file has no final
+    newline.  Plain files are read straight into the buffer (one copy out of the page cache).  A copy-on-write mapping of
+    the file looks cheaper but is not: every page is written to later, and 16 threads taking copy-on-write faults on one
+    address space cost more inside mem_process_seqs than the read costs here."""
+    path = str(path)
+    if path.endswith(".gz"):
+        data = gzip.open(path, "rb").read()
+        buf = C.create_string_buffer(data, len(data) + 1)
+        return buf, C.addressof(buf), len(data)
+    size = os.path.getsize(path)
+    buf = np.empty(size + 1, dtype=np.uint8)
+    with open(path, "rb", buffering=0) as f:
+        view, got = memoryview(buf)[:size], 0
+        while got < size:
+            n = f.readinto(view[got:])
+            if not n:
+                raise IOError("%s: short read" % path)
+            got += n
+    buf[size] = 0
+    return buf, buf.ctypes.data, size
 
 
 class FastqFile:
@@ -32,12 +50,12 @@ class FastqFile:
 
     def __init__(self, lib, path):
         self.lib = lib
-        self.buf, self.len = _load(path)
+        self.buf, self._addr, self.len = _load(path)
         cap = max(16, self.len // 32)          # a record has at least 8 bytes; grow if the guess is short
         while True:
             off = np.zeros(cap + 1, dtype=np.int64)
             bases = np.zeros(cap, dtype=np.int32)
-            n = lib.mi355x_fastq_scan(C.addressof(self.buf), self.len, cap, off.ctypes.data, bases.ctypes.data)
+            n = lib.mi355x_fastq_scan(self._addr, self.len, cap, off.ctypes.data, bases.ctypes.data)
             if n < 0:
                 raise ValueError("%s: malformed FASTQ record at byte %d" % (path, -n - 1))
             if n <= cap:
@@ -49,7 +67,7 @@ class FastqFile:
 
     @property
     def addr(self):
-        return C.addressof(self.buf)
+        return self._addr
 
 
 def chunk_starts(lib, bases1, bases2, maxsiz):
@@ -68,8 +86,13 @@ class FastqSource:
 
     def __init__(self, lib, r1, r2=None, K=10_000_000, copy_comment=False, mode=None):
         self.lib = lib
-        self.f1 = FastqFile(lib, r1)
-        self.f2 = FastqFile(lib, r2) if r2 is not None else None
+        if r2 is not None:   # the two files are scanned side by side (the scan is one pass in C, outside the GIL)
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=2) as pool:
+                a, b = pool.submit(FastqFile, lib, r1), pool.submit(FastqFile, lib, r2)
+                self.f1, self.f2 = a.result(), b.result()
+        else:
+            self.f1, self.f2 = FastqFile(lib, r1), None
         if self.f2 is not None and self.f1.n != self.f2.n:
             raise ValueError("the two FASTQ files hold %d and %d reads" % (self.f1.n, self.f2.n))
         if mode is None:
@@ -128,12 +151,13 @@ def align_files(engine, opt, r1, r2=None, out=None, K=10_000_000, copy_comment=F
                 rec, n = fut.result()
                 tot = C.c_size_t(0)
                 p = lib.mi355x_collect_sam(C.cast(rec.ctypes.data, C.POINTER(abi.bseq1_t)), n, C.byref(tot))
-                data = C.string_at(p, tot.value)
-                _libc.free(C.c_void_p(p))
-                if out is None:
-                    pieces.append(data)
-                else:
-                    out.write(data)
+                try:
+                    if out is None:
+                        pieces.append(C.string_at(p, tot.value))
+                    else:   # straight from the C buffer to the file, no Python copy of the chunk's SAM text
+                        out.write(memoryview((C.c_char * tot.value).from_address(p)))
+                finally:
+                    _libc.free(C.c_void_p(p))
             except Exception as e:  # pragma: no cover
                 err.append(e)
 
