@@ -46,8 +46,8 @@ def main():
                     help="read length (150 = the headline config; 250 = BASELINE config 4's shape, a parity case)")
     ap.add_argument("--seed", type=int, default=1000, help="seed of the read simulator (rank r uses seed + r)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("MPIBWA_BENCH_IN_FLIGHT", "3")),
-                    help="caller threads inside mem_process_seqs at once (the library runs up to three calls side by side: "
+    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("MPIBWA_BENCH_IN_FLIGHT", "4")),
+                    help="caller threads inside mem_process_seqs at once (the library runs up to four calls side by side: "
                          "the GPU-bound half of one chunk overlaps the host-bound half of the previous one)")
     ap.add_argument("--workdir", default=os.environ.get("MPIBWA_BENCH_DIR", "/tmp/mpibwa_bench"))
     args = ap.parse_args()
@@ -90,7 +90,7 @@ def main():
     reads = idx.simulate_pairs(args.pairs, seed=args.seed + rank, read_len=args.read_len, frag_mean=max(400.0, 2.2 * args.read_len))
     import hashlib
     import threading
-    n_fly = max(1, min(args.in_flight, 3))
+    n_fly = max(1, min(args.in_flight, 4))
     batches = [abi.SeqBatch(api.libc, reads) for _ in range(n_fly)]   # every caller thread owns its bseq1_t[] (and its .sam)
     batch = batches[0]
     cores = int(lib.mi355x_host_cpus())

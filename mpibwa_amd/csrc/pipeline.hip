@@ -17,7 +17,7 @@
 //   GPU    CIGAR / MD / NM              aln_kernel             (bwamem.c:1106-1122, bwa.c:121-207)
 //   host   SAM text                                            (bwamem.c:824-1010)
 //
-// Up to three calls run side by side (CallCtx below): the GPU-bound first half of one chunk overlaps the host-bound
+// Up to four calls run side by side (CallCtx below): the GPU-bound first half of one chunk overlaps the host-bound
 // second half of another.
 //
 // There is no CPU fallback for the GPU stages: without a gfx950 device the call aborts.
@@ -206,9 +206,9 @@ struct Workspace {
 	DevBuf chain_off, chains, seeds, srt, reg_off, regs, nregs, tab, areq, ahdr, apool, agap, acnt, areq2, ahdr2, apool2, acnt2;
 };
 static const int MAX_LANES = 4;
-// Everything one mem_process_seqs() call owns between its first and last line.  Three of them: three caller threads may be inside
+// Everything one mem_process_seqs() call owns between its first and last line.  Four of them: four caller threads may be inside
 // the function at once (chunk i+1 seeding and extending on the GPU while the host pairs and prints chunk i — the stage that
-// keeps the GPU busy and the stage that keeps the host busy belong to different halves of a call).  A fourth caller waits.
+// keeps the GPU busy and the stage that keeps the host busy belong to different halves of a call).  A fifth caller waits.
 struct CallCtx {
 	Workspace ws[MAX_LANES];   // one per concurrent sub-batch
 	HostBuf reg_arena[16];     // one per sub-batch: the regions live until the SAM stage
@@ -216,7 +216,7 @@ struct CallCtx {
 	hipStream_t p_streams[MAX_LANES] = {nullptr}, a_streams[2] = {nullptr, nullptr};
 	bool busy = false;
 };
-static const int MAX_CALLS = 3;
+static const int MAX_CALLS = 4;
 static CallCtx g_ctx[MAX_CALLS];
 static std::mutex g_ctx_mu, g_init_mu;
 static std::condition_variable g_ctx_cv;

@@ -124,14 +124,14 @@ class FastqSource:
 
 
 def align_files(engine, opt, r1, r2=None, out=None, K=10_000_000, copy_comment=False, mode=None, n_processed0=0, rank=0, world=1,
-                in_flight=3):
+                in_flight=4):
     """`mpiBWA mem` for one rank: its chunks through mem_process_seqs, SAM records in read order.
 
     The chunk list is the same on every rank (it does not depend on the number of ranks); rank r of `world` takes chunks
     r, r + world, ... — the reference hands chunks out with a fetch-and-add counter (src/mainParallel.c:1112-1119), which
     balances better on uneven data but yields the same set of records.  With world > 1 the trimmed branch's running
     n_processed (reads this rank has already done, :2355-2357) is counted over this rank's chunks, as in the reference.
-    in_flight: caller threads inside mem_process_seqs at once (the library takes up to three: the GPU half of chunk i+1 overlaps the
+    in_flight: caller threads inside mem_process_seqs at once (the library takes up to four: the GPU half of chunk i+1 overlaps the
     host half of chunk i); the records are written in chunk order whatever the completion order.
     out: a binary file object (the SAM body is written to it) or None (the body is returned as bytes).
     Returns (bytes or None, per-chunk read counts of this rank)."""
