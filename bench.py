@@ -35,8 +35,8 @@ def log(*a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--genome-mbp", type=float, default=float(os.environ.get("MPIBWA_BENCH_GENOME_MBP", "3100")))
     ap.add_argument("--pairs", type=int, default=int(os.environ.get("MPIBWA_BENCH_PAIRS", "333334")),
                     help="read pairs per step per GPU (mpiBWA -K 100000000 closes a chunk at 10^8 bases)")
