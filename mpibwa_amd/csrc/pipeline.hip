@@ -222,6 +222,7 @@ static std::mutex g_ctx_mu, g_init_mu;
 static std::condition_variable g_ctx_cv;
 struct CtxLease {
 	CallCtx *c = nullptr;
+	int others = 0;   // calls that were in flight when this one started
 	CtxLease()
 	{
 		std::unique_lock<std::mutex> lk(g_ctx_mu);
@@ -231,6 +232,7 @@ struct CtxLease {
 			if (c) break;
 			g_ctx_cv.wait(lk);
 		}
+		for (int i = 0; i < MAX_CALLS; ++i) others += g_ctx[i].busy && &g_ctx[i] != c;
 	}
 	~CtxLease()
 	{
@@ -713,7 +715,10 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	};
 
 	// K sub-batches are worked off by up to MAX_LANES host threads ("lanes"), each with its own HIP stream and workspace
-	int n_sub = 3, n_lanes = 3;
+	// Sub-batches overlap the GPU and host stages of ONE call.  When enough other calls are in flight they provide that
+	// overlap, and one launch per kernel over the whole chunk is cheaper than three (one tail instead of three: the SMEM
+	// kernel needs 23 ms for the chunk in one launch, 3 x 10 ms in three).
+	int n_sub = lease.others >= 2 ? 1 : 3, n_lanes = 3;
 	if (const char *e = getenv("MPIBWA_SUBBATCH")) n_sub = atoi(e);
 	if (const char *e = getenv("MPIBWA_LANES")) n_lanes = atoi(e);
 	n_sub = std::max(1, std::min(n_sub, 16));
