@@ -185,7 +185,7 @@ def main():
     roofline = {"kernel": "smem_kernel", "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(ach / 8000.0, 4), "traffic": traffic,
                 "launch_ms": round(acc["k_smem_ms"] / n_launch, 3), "algo_bytes_per_launch": int(acc["smem_bytes"] / n_launch),
-                "launches_per_step": n_launch // args.steps}
+                "launches_per_step": round(n_launch / args.steps, 2)}
     if alone.get("k_smem_ms") and alone.get("n_sub"):
         a1 = alone["smem_bytes"] / (alone["k_smem_ms"] * 1e-3) / 1e9
         roofline["one_call_in_flight"] = {"launch_ms": round(alone["k_smem_ms"] / alone["n_sub"], 3), "achieved": round(a1, 1),
