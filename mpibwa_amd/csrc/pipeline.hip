@@ -308,8 +308,14 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	const int n_thr = host_threads(opt);
 	const bool pe = (opt->flag & MEM_F_PE) != 0;
 	if (!C.a_streams[0]) {
-		for (int l = 0; l < MAX_LANES; ++l) HIP_OK(hipStreamCreateWithFlags(&C.p_streams[l], hipStreamNonBlocking));
-		for (int l = 0; l < 2; ++l) HIP_OK(hipStreamCreateWithFlags(&C.a_streams[l], hipStreamNonBlocking));
+		// the SAM stage's kernels (mate rescue, CIGAR) are short and the host waits for them with all its threads: they go
+		// ahead of the seeding / extension kernels of the other calls in flight (MPIBWA_PRIO=n: no priorities, p: reversed)
+		int lo_p = 0, hi_p = 0;   // numerically lowest = highest priority
+		HIP_OK(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
+		const char *pe = getenv("MPIBWA_PRIO");
+		const int pp = pe && *pe == 'p' ? hi_p : 0, pa = !pe || *pe == 'a' ? hi_p : 0;
+		for (int l = 0; l < MAX_LANES; ++l) HIP_OK(hipStreamCreateWithPriority(&C.p_streams[l], hipStreamNonBlocking, pp));
+		for (int l = 0; l < 2; ++l) HIP_OK(hipStreamCreateWithPriority(&C.a_streams[l], hipStreamNonBlocking, pa));
 	}
 	hipStream_t st = C.p_streams[0];   // never the null stream: another call may be in flight
 	Workspace &W = C.gws;
