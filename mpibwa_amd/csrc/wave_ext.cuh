@@ -118,6 +118,7 @@ __device__ __forceinline__ WxResult wave_extend(int qlen, QF qf, int tlen, TF tf
 		int hleft0 = 0;
 		if (beg == 0) { hleft0 = h0 - (P.o_del + e_del * (i + 1)); if (hleft0 < 0) hleft0 = 0; }
 		int rowkey = -1;                           // (row maximum) << 13 | its largest column
+		int lanekey = -1;                          // ... per lane over the strips of the row; one wave reduction per row
 		int A = beg * e_ins;                       // F(i,beg) = 0
 		int h_carry = 0, h_last = hleft0;          // h of column 64*s-1; H[end] after the row
 		int first_nz = end, last_nz = -1;          // first / last cell of [beg,end] with H or E non-zero after the row
@@ -146,9 +147,8 @@ __device__ __forceinline__ WxResult wave_extend(int qlen, QF qf, int tlen, TF tf
 				if (j == beg) H[j] = hleft0;
 				if (act) { H[j + 1] = h; E[j] = en; }
 				A = max(A, __builtin_amdgcn_readlane(incl, 63) + e_ins);
-				// row maximum; the largest column wins ties: one max-scan over (h << 13 | column)
-				const int kmax = __builtin_amdgcn_readlane(wx_scan_max(act ? (h << 13 | j) : -1), 63);
-				rowkey = kmax > rowkey ? kmax : rowkey;
+				// row maximum; the largest column wins ties: maximum of (h << 13 | column)
+				lanekey = max(lanekey, act ? (h << 13 | j) : -1);
 				// cells of this strip that are non-zero after the row: H[c] = h of column c-1, E[c] = en of column c
 				const unsigned long long bh = __ballot(act && h != 0), be = __ballot(act && en != 0);
 				unsigned long long nz = (bh << 1) | be;
@@ -162,6 +162,7 @@ __device__ __forceinline__ WxResult wave_extend(int qlen, QF qf, int tlen, TF tf
 				h_carry = __builtin_amdgcn_readlane(h, 63);
 				if (s == s1) h_last = __builtin_amdgcn_readlane(h, (end - 1) & 63);
 			}
+			rowkey = __builtin_amdgcn_readlane(wx_scan_max(lanekey), 63);
 			if ((end & 63) == 0 && h_carry != 0 && end > last_nz) last_nz = end;   // cell `end` opens the next strip
 			cells += (unsigned long long)(end - beg);
 		} else {
