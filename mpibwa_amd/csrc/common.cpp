@@ -2,6 +2,7 @@
 #include "internal.h"
 #include <malloc.h>
 #include "hprof.h"
+#include <time.h>
 #include <cstdio>
 #include <cmath>
 #include <cstdlib>
@@ -38,12 +39,26 @@ static bool g_alloc_tuned = tune_allocator();
 std::atomic<long long> g_hprof[HP_N];
 std::atomic<long long> g_hcount[HP_N];
 bool g_hprof_on = getenv("MPIBWA_PROF") != nullptr;
+thread_local HProfLocal t_hprof;
+static double tsc_per_ms()
+{
+	static double r = 0;
+	if (r == 0) {   // calibrate once against the monotonic clock
+		timespec a, b;
+		clock_gettime(CLOCK_MONOTONIC, &a);
+		const unsigned long long t0 = __rdtsc();
+		do clock_gettime(CLOCK_MONOTONIC, &b); while ((b.tv_sec - a.tv_sec) * 1e9 + (b.tv_nsec - a.tv_nsec) < 2e6);
+		r = (double)(__rdtsc() - t0) / (((b.tv_sec - a.tv_sec) * 1e9 + (b.tv_nsec - a.tv_nsec)) * 1e-6);
+	}
+	return r;
+}
 void hprof_report(const char *tag)
 {
 	if (!g_hprof_on) return;
+	t_hprof.flush();
 	static const char *nm[HP_N] = {"matesw", "ksw_align2", "reg2aln", "ksw_global2", "gen_alt", "aln2sam", "mark_primary", "pair", "dedup_patch"};
-	fprintf(stderr, "[hprof %s]", tag);
-	for (int i = 0; i < HP_N; ++i) { fprintf(stderr, " %s=%.1fms/%lld", nm[i], g_hprof[i].load() * 1e-6, g_hcount[i].load()); g_hprof[i] = 0; g_hcount[i] = 0; }
+	fprintf(stderr, "[hprof %s] (thread-ms / calls; nested sections are counted in their parents too)", tag);
+	for (int i = 0; i < HP_N; ++i) { fprintf(stderr, " %s=%.1f/%lld", nm[i], g_hprof[i].load() / tsc_per_ms(), g_hcount[i].load()); g_hprof[i] = 0; g_hcount[i] = 0; }
 	fprintf(stderr, "\n");
 }
 

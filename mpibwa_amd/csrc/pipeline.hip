@@ -1010,7 +1010,9 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		parts[0].lo = 0; parts[0].hi = n_units;
 		mcollect(parts[0], 0); mlaunch(parts[0], 0);
 		collect(parts[0], 0); mfinish(parts[0]); collect(parts[0], 1);
-		launch(parts[0], 0); finish(parts[0]); replay(parts[0]);
+		launch(parts[0], 0); finish(parts[0]);
+		hprof_report("decisions + request lists");
+		replay(parts[0]);
 	} else {
 		parts[0].lo = 0; parts[0].hi = n_units / 2; parts[1].lo = n_units / 2; parts[1].hi = n_units;
 		mcollect(parts[0], 0); mlaunch(parts[0], 0);
