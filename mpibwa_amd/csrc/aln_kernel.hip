@@ -249,7 +249,8 @@ __device__ __forceinline__ void aln_one(int rq, const AlnParams &P, const WxPara
 					}
 				};
 				while (i >= 0 && k >= 0) {
-					which = L.z[(size_t)i * n_col + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
+					// the walk is the same in every lane: keep it in scalar registers (readfirstlane), off the vector ALU
+					which = __builtin_amdgcn_readfirstlane((int)L.z[(size_t)i * n_col + (k - (i > w ? i - w : 0))]) >> (which << 1) & 3;
 					if (which == 0) { push(0, 1); --i; --k; }
 					else if (which == 1) { push(2, 1); --i; }
 					else { push(1, 1); --k; }
