@@ -127,7 +127,19 @@ __device__ __forceinline__ void aln_one(int rq, const AlnParams &P, const WxPara
 		L.md = L.z + ALN_ZCAP;
 	}
 
-	const AlnReq R = reqs[rq];
+	// the request is the same in every lane but arrives through vector loads: pin it to scalar registers, or the DP
+	// loop's bookkeeping (band limits, strip counts, loop tests) is compiled into vector instructions
+	AlnReq R = reqs[rq];
+	if (KIND != 0) {   // (the no-DP variant has no such loop, and pinned it only unrolls its staging loops into 126 VGPRs)
+		const unsigned long long rb = (unsigned long long)R.rb, re = (unsigned long long)R.re;
+		R.rb = (int64_t)((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(rb >> 32)) << 32 |
+		                 (unsigned)__builtin_amdgcn_readfirstlane((int)rb));
+		R.re = (int64_t)((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(re >> 32)) << 32 |
+		                 (unsigned)__builtin_amdgcn_readfirstlane((int)re));
+		R.read = __builtin_amdgcn_readfirstlane(R.read); R.qb = __builtin_amdgcn_readfirstlane(R.qb);
+		R.qe = __builtin_amdgcn_readfirstlane(R.qe); R.w2 = __builtin_amdgcn_readfirstlane(R.w2);
+		R.truesc = __builtin_amdgcn_readfirstlane(R.truesc);
+	}
 	const int lq = R.qe - R.qb;
 	const long long rlen64 = R.re - R.rb;
 	AlnHdr out;
@@ -355,7 +367,7 @@ aln_kernel(AlnParams P, WxParams X, int n_req, const AlnReq *__restrict__ reqs, 
 	const int n = (int)counters[ALN_CNT + KIND];
 	const int *mine = lists + (size_t)KIND * n_req;
 	for (int k = blockIdx.x * ALN_WAVES + wave; k < n; k += gridDim.x * ALN_WAVES) {
-		aln_one<KIND>(mine[k], P, X, n_req, reqs, seq, off, pac, gaptab, hdr, pool, counters, pool_bytes, max_len, tcap, lists);
+		aln_one<KIND>(KIND != 0 ? __builtin_amdgcn_readfirstlane(mine[k]) : mine[k], P, X, n_req, reqs, seq, off, pac, gaptab, hdr, pool, counters, pool_bytes, max_len, tcap, lists);
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the wave's LDS slice is reused by its next request
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

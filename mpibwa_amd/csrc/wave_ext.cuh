@@ -80,6 +80,14 @@ __device__ __forceinline__ WxResult wave_extend(int qlen, QF qf, int tlen, TF tf
                                                 int *H, int *E, unsigned long long &cells, int max_sc = 1)
 {
 	const int lane = threadIdx.x & 63;
+	// The extension's shape is the same in every lane, but it was read through vector loads: pin it to scalar registers,
+	// or the row loop's whole bookkeeping (band limits, live range, strip counts, loop tests) is compiled into vector
+	// instructions with exec-mask branches around them.
+	qlen = __builtin_amdgcn_readfirstlane(qlen);
+	tlen = __builtin_amdgcn_readfirstlane(tlen);
+	w = __builtin_amdgcn_readfirstlane(w);
+	h0 = __builtin_amdgcn_readfirstlane(h0);
+	max_sc = __builtin_amdgcn_readfirstlane(max_sc);
 	const int oe_del = P.o_del + P.e_del, oe_ins = P.o_ins + P.e_ins, e_del = P.e_del, e_ins = P.e_ins;
 	// first row (src/ksw.c:389-393)
 	for (int j = lane; j <= qlen; j += 64) {
