@@ -47,6 +47,14 @@ __device__ __forceinline__ int ref_base(const uint8_t *pac, i64 l_pac, i64 p)
 	return (pac[p >> 2] >> ((~p & 3) << 1)) & 3;
 }
 
+// wave-uniform values that arrive through vector loads / cross-lane reductions -> scalar registers
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ i64 uni64(i64 v)
+{
+	const unsigned long long u = (unsigned long long)v;
+	return (i64)((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32 | (unsigned)__builtin_amdgcn_readfirstlane((int)u));
+}
+
 #define C2A_WAVES 1
 #define SRT_MARK 0xFFFFFFFFu
 
@@ -61,13 +69,13 @@ c2a_kernel(C2aParams P, WxParams X, int n_reads, const uint8_t *__restrict__ seq
 	const int slot = blockIdx.x * C2A_WAVES + wave;
 	if (slot >= n_reads) return;
 	// reads with the most seeds are started first, so that the kernel does not end on a few long-running reads
-	const int rd = order ? order[slot] : slot;
+	const int rd = uni(order ? order[slot] : slot);
 	int *H = lds + (size_t)wave * 2 * (max_len + 2);
 	int *E = H + (max_len + 2);
 	const int *gap = tab, *bound5 = tab + tab_stride, *bound3 = tab + 2 * tab_stride, *ceil95 = tab + 3 * tab_stride,
 	          *thr10 = tab + 4 * tab_stride;
 	const uint8_t *q = seq + off[rd];
-	const int lq = lens[rd];
+	const int lq = uni(lens[rd]);
 	DevReg *av = regs + reg_beg[rd];
 	int nav = 0;
 	unsigned long long cells = 0, n_ext = 0;
@@ -75,9 +83,12 @@ c2a_kernel(C2aParams P, WxParams X, int n_reads, const uint8_t *__restrict__ seq
 	int max_sc = 1;   // largest entry of the scoring matrix: what one more column can add at most
 	for (int t = 0; t < 25; ++t) max_sc = X.mat[t] > max_sc ? X.mat[t] : max_sc;
 
-	const int ci_end = chain_beg[rd] + (chain_cnt[rd] > 0 ? chain_cnt[rd] : 0);
-	for (int ci = chain_beg[rd]; ci < ci_end; ++ci) {
-		const DevChain C = chains[ci];
+	const int ci_beg = uni(chain_beg[rd]), ci_cnt = uni(chain_cnt[rd]);
+	const int ci_end = ci_beg + (ci_cnt > 0 ? ci_cnt : 0);
+	for (int ci = ci_beg; ci < ci_end; ++ci) {
+		DevChain C = chains[ci];
+		C.n_seeds = uni(C.n_seeds); C.seed_beg = uni(C.seed_beg); C.rid = uni(C.rid);
+		C.far_beg = uni64(C.far_beg); C.far_end = uni64(C.far_end);
 		const int n = C.n_seeds;
 		if (n == 0) continue;
 		const DevSeed *sd = seeds + C.seed_beg;
@@ -92,7 +103,7 @@ c2a_kernel(C2aParams P, WxParams X, int n_reads, const uint8_t *__restrict__ seq
 			lo = b < lo ? b : lo;
 			hi = e > hi ? e : hi;
 		}
-		i64 rmax0 = wave_min_i64(lo), rmax1 = wave_max_i64(hi);
+		i64 rmax0 = uni64(wave_min_i64(lo)), rmax1 = uni64(wave_max_i64(hi));
 		rmax0 = rmax0 > 0 ? rmax0 : 0;
 		rmax1 = rmax1 < l_pac << 1 ? rmax1 : l_pac << 1;
 		if (rmax0 < l_pac && l_pac < rmax1) {   // never cross the strand boundary
@@ -104,7 +115,8 @@ c2a_kernel(C2aParams P, WxParams X, int n_reads, const uint8_t *__restrict__ seq
 		rmax1 = rmax1 < C.far_end ? rmax1 : C.far_end;
 
 		for (int k = n - 1; k >= 0; --k) {
-			const DevSeed s = sd[ord[k]];
+			DevSeed s = sd[uni((int)ord[k])];
+			s.rbeg = uni64(s.rbeg); s.qbeg = uni(s.qbeg); s.len = uni(s.len);
 			// ---- is the seed already inside an earlier extension of this read? ----
 			bool hit = false;
 			for (int i0 = 0; i0 < nav && !hit; i0 += 64) {
