@@ -129,3 +129,83 @@ def test_example_fastq_through_reference_library_gives_the_binary_md5(lib, tmp_p
         h.update(C.string_at(p))
         po.libc.free(C.c_void_p(p))
     assert h.hexdigest() == "51ce7ba0592d4a199eac49526b6c9d8c"
+
+
+def test_threaded_fill_matches_record_by_record(lib, tmp_path):
+    """Chunks of 65 536 records and more are filled by several threads over contiguous ranges: same strings as the
+    per-record walk, same base count, and a malformed record is reported by its index whichever range it falls into."""
+    rng = np.random.default_rng(3)
+    n = 70_000
+    lens = rng.integers(30, 80, size=n)
+    lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    recs1, recs2 = [], []
+    for i in range(n):
+        s = lut[rng.integers(0, 5, size=int(lens[i]))].tobytes()
+        q = bytes(rng.integers(33, 74, size=int(lens[i]), dtype=np.uint8))
+        q = q.replace(b"@", b"A")
+        hdr = b"read%d" % i + (b"/1 c%d" % i if i % 3 == 0 else b"")
+        recs1.append((hdr, s, q))
+        recs2.append((hdr.replace(b"/1", b"/2"), s[::-1], q[::-1]))
+    p1, p2 = _write(tmp_path, "big_1.fq", recs1), _write(tmp_path, "big_2.fq", recs2, final_newline=False)
+    src = fastq.FastqSource(lib, p1, p2, K=10 ** 9, copy_comment=True, mode="pe_trim")
+    assert src.n_chunks == 1 and src.f1.n == n
+    rec, cnt = src.chunk(0)
+    assert cnt == 2 * n
+    got = _strings(rec, cnt)
+    for i in range(0, n, 997):
+        h, s, q = recs1[i]
+        name = h.split(b"/")[0].split(b" ")[0]
+        com = h.split(b" ", 1)[1] if b" " in h else b""
+        assert got[2 * i] == (name, com, s, q, len(s)), i
+        assert got[2 * i + 1] == (name, com, s[::-1], q[::-1], len(s)), i
+    assert sum(g[4] for g in got) == 2 * int(lens.sum())
+    # a record without its '+' line, deep inside the file
+    bad = list(recs1)
+    k = 54_321
+    txt = b"".join(b"@" + h + b"\n" + s + b"\n" + (b"-" if i == k else b"+") + b"\n" + q + b"\n" for i, (h, s, q) in enumerate(bad))
+    pb = tmp_path / "bad_big.fq"
+    pb.write_bytes(txt)
+    with pytest.raises(ValueError):
+        fastq.FastqFile(lib, str(pb))
+
+
+def test_align_files_writes_chunks_in_order_whatever_the_completion_order(lib, tmp_path):
+    """align_files with a stand-in for the engine whose mem_process_seqs finishes chunks out of order: the SAM body is in
+    chunk order, every record once, n_processed is passed as the trimmed branch does."""
+    import threading
+    import time
+    recs = [(b"r%d" % i, b"ACGT" * 5, b"I" * 20) for i in range(400)]
+    p1 = _write(tmp_path, "o_1.fq", recs)
+    p2 = _write(tmp_path, "o_2.fq", [(h, s[:-1], q[:-1]) for h, s, q in recs])    # different size -> trimmed branch
+    libc = C.CDLL("libc.so.6")
+    libc.malloc.restype = C.c_void_p
+    libc.malloc.argtypes = [C.c_size_t]
+    seen = []
+    lock = threading.Lock()
+
+    class StubLib:
+        """the C ABI's file functions are the real ones; mem_process_seqs is replaced"""
+        def __getattr__(self, name):
+            return getattr(lib, name)
+
+        def mem_process_seqs(self, opt, bwt, bns, pac, n_processed, n, seqs, pes0):
+            with lock:
+                seen.append((int(n_processed), int(n)))
+                k = len(seen)
+            time.sleep(0.05 if k % 2 else 0.0)            # odd calls finish late
+            for i in range(n):
+                line = b"%s\t%d\n" % (C.string_at(seqs[i].name), int(n_processed) + i)
+                p = libc.malloc(len(line) + 1)
+                C.memmove(p, line, len(line) + 1)
+                seqs[i].sam = p
+
+    class StubEngine:
+        lib = StubLib()
+        bwt = bns = pac = None
+
+    body, counts = fastq.align_files(StubEngine(), None, p1, p2, out=None, K=2000, in_flight=3)
+    lines = body.split(b"\n")[:-1]
+    assert len(lines) == 800 and sum(counts) == 800 and len(counts) > 5
+    assert [l.split(b"\t")[0] for l in lines] == [b"r%d" % (i // 2) for i in range(800)]
+    assert [int(l.split(b"\t")[1]) for l in lines] == list(range(800))           # running n_processed of the trimmed branch
+    assert sorted(seen) == sorted((sum(counts[:k]), counts[k]) for k in range(len(counts)))
