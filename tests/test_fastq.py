@@ -169,22 +169,17 @@ def test_threaded_fill_matches_record_by_record(lib, tmp_path):
         fastq.FastqFile(lib, str(pb))
 
 
-def test_align_files_writes_chunks_in_order_whatever_the_completion_order(lib, tmp_path):
-    """align_files with a stand-in for the engine whose mem_process_seqs finishes chunks out of order: the SAM body is in
-    chunk order, every record once, n_processed is passed as the trimmed branch does."""
+def _stub_engine(lib, seen, delay=True):
+    """An engine whose C ABI file functions are the real ones and whose mem_process_seqs is a stand-in that writes
+    "<name>\t<n_processed + i>" per read and finishes every other call late."""
     import threading
     import time
-    recs = [(b"r%d" % i, b"ACGT" * 5, b"I" * 20) for i in range(400)]
-    p1 = _write(tmp_path, "o_1.fq", recs)
-    p2 = _write(tmp_path, "o_2.fq", [(h, s[:-1], q[:-1]) for h, s, q in recs])    # different size -> trimmed branch
     libc = C.CDLL("libc.so.6")
     libc.malloc.restype = C.c_void_p
     libc.malloc.argtypes = [C.c_size_t]
-    seen = []
     lock = threading.Lock()
 
     class StubLib:
-        """the C ABI's file functions are the real ones; mem_process_seqs is replaced"""
         def __getattr__(self, name):
             return getattr(lib, name)
 
@@ -192,7 +187,8 @@ def test_align_files_writes_chunks_in_order_whatever_the_completion_order(lib, t
             with lock:
                 seen.append((int(n_processed), int(n)))
                 k = len(seen)
-            time.sleep(0.05 if k % 2 else 0.0)            # odd calls finish late
+            if delay:
+                time.sleep(0.05 if k % 2 else 0.0)        # odd calls finish late
             for i in range(n):
                 line = b"%s\t%d\n" % (C.string_at(seqs[i].name), int(n_processed) + i)
                 p = libc.malloc(len(line) + 1)
@@ -200,12 +196,47 @@ def test_align_files_writes_chunks_in_order_whatever_the_completion_order(lib, t
                 seqs[i].sam = p
 
     class StubEngine:
-        lib = StubLib()
         bwt = bns = pac = None
+    StubEngine.lib = StubLib()
+    return StubEngine()
 
-    body, counts = fastq.align_files(StubEngine(), None, p1, p2, out=None, K=2000, in_flight=3)
+
+def test_align_files_writes_chunks_in_order_whatever_the_completion_order(lib, tmp_path):
+    """align_files with a stand-in engine that finishes chunks out of order: the SAM body is in chunk order, every record
+    once, n_processed is passed as the trimmed branch does."""
+    recs = [(b"r%d" % i, b"ACGT" * 5, b"I" * 20) for i in range(400)]
+    p1 = _write(tmp_path, "o_1.fq", recs)
+    p2 = _write(tmp_path, "o_2.fq", [(h, s[:-1], q[:-1]) for h, s, q in recs])    # different size -> trimmed branch
+    seen = []
+    body, counts = fastq.align_files(_stub_engine(lib, seen), None, p1, p2, out=None, K=2000, in_flight=3)
     lines = body.split(b"\n")[:-1]
     assert len(lines) == 800 and sum(counts) == 800 and len(counts) > 5
     assert [l.split(b"\t")[0] for l in lines] == [b"r%d" % (i // 2) for i in range(800)]
     assert [int(l.split(b"\t")[1]) for l in lines] == list(range(800))           # running n_processed of the trimmed branch
     assert sorted(seen) == sorted((sum(counts[:k]), counts[k]) for k in range(len(counts)))
+
+
+def test_align_files_rank_striping_covers_every_chunk_once(lib, tmp_path):
+    """world = 3: rank r takes chunks r, r + 3, ... of the same chunk list; together the ranks emit every record once and a
+    rank's records are those of its chunks, in order.  Equal-size pairs: n_processed is 0 for every chunk (src/mainParallel.c:1314)."""
+    recs = [(b"q%d" % i, b"ACGTA" * 6, b"J" * 30) for i in range(500)]
+    p1, p2 = _write(tmp_path, "s_1.fq", recs), _write(tmp_path, "s_2.fq", recs)
+    seen = []
+    whole, counts = fastq.align_files(_stub_engine(lib, seen, delay=False), None, p1, p2, out=None, K=3000, in_flight=2)
+    assert all(npz == 0 for npz, _ in seen)
+    names = [l.split(b"\t")[0] for l in whole.split(b"\n")[:-1]]
+    assert names == [b"q%d" % (i // 2) for i in range(1000)] and len(counts) >= 7
+    starts = np.concatenate([[0], np.cumsum(counts)])
+    for world in (2, 3):
+        union = {}
+        for rank in range(world):
+            body, cr = fastq.align_files(_stub_engine(lib, [], delay=False), None, p1, p2, out=None, K=3000, rank=rank, world=world)
+            mine = list(range(rank, len(counts), world))
+            assert cr == [counts[c] for c in mine]
+            got = [l.split(b"\t")[0] for l in body.split(b"\n")[:-1]]
+            want = [n for c in mine for n in names[starts[c]:starts[c + 1]]]
+            assert got == want
+            for c in mine:
+                assert c not in union
+                union[c] = True
+        assert sorted(union) == list(range(len(counts)))
