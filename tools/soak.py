@@ -10,7 +10,7 @@ eng = idx.engine
 lib = eng.lib
 C.c_int.in_dll(lib, "bwa_verbose").value = 1
 opt = eng.opt(flag=abi.MEM_F_PE, n_threads=int(lib.mi355x_host_cpus()))
-batches = [abi.SeqBatch(api.libc, idx.simulate_pairs(200000 + 1111 * k, seed=50 + k)) for k in range(3)]   # three chunk sizes
+batches = [abi.SeqBatch(api.libc, idx.simulate_pairs(200000 + 1111 * k, seed=50 + k)) for k in range(4)]   # one chunk per caller, four sizes
 def rss():
     for l in open("/proc/self/status"):
         if l.startswith("VmRSS"):
@@ -19,7 +19,7 @@ import threading
 t0 = time.time()
 lock = threading.Lock()
 todo = iter(range(steps))
-def caller(t):   # three callers in flight, each with its own chunk size
+def caller(t):   # four callers in flight, each with its own chunk
     b = batches[t]
     while True:
         with lock:
@@ -33,6 +33,6 @@ def caller(t):   # three callers in flight, each with its own chunk size
         if s in (8, 32, 120, 240, 360, steps - 1):
             free, total = torch.cuda.mem_get_info()
             print("step %d: RSS %.2f GB, device used %.2f GB, %.1f s" % (s, rss(), (total - free) / 1e9, time.time() - t0), flush=True)
-th = [threading.Thread(target=caller, args=(t,)) for t in range(3)]
+th = [threading.Thread(target=caller, args=(t,)) for t in range(4)]   # disjoint seqs[] per caller, as the ABI asks
 for x in th: x.start()
 for x in th: x.join()
