@@ -148,8 +148,9 @@ typedef struct {
 /* (same index, disjoint seqs[]).  Up to four calls run side by side   */
 /* — the first half of a call is bound by the GPU, the second by the   */
 /* host, so chunk i+1 overlaps chunk i — and further callers wait for  */
-/* a free slot.  The reference's own function is re-entrant in the same way   */
-/* (it only reads opt and the index).                                  */
+/* a free slot (calls in flight on overlapping seqs[] abort).          */
+/* The reference's own function is re-entrant in the same way (it     */
+/* only reads opt and the index).                                      */
 /* ------------------------------------------------------------------ */
 void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const bntseq_t *bns, const uint8_t *pac,
                       int64_t n_processed, int n, bseq1_t *seqs, const mem_pestat_t *pes0);

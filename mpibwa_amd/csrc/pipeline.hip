@@ -215,6 +215,7 @@ struct CallCtx {
 	Workspace gws;             // batch-wide buffers (packed reads, CIGAR requests)
 	hipStream_t p_streams[MAX_LANES] = {nullptr}, a_streams[2] = {nullptr, nullptr};
 	bool busy = false;
+	const bseq1_t *seq_lo = nullptr, *seq_hi = nullptr;   // the caller's array while the call runs
 };
 static const int MAX_CALLS = 4;
 static CallCtx g_ctx[MAX_CALLS];
@@ -223,7 +224,7 @@ static std::condition_variable g_ctx_cv;
 struct CtxLease {
 	CallCtx *c = nullptr;
 	int others = 0;   // calls that were in flight when this one started
-	CtxLease()
+	CtxLease(const bseq1_t *seqs, int n)
 	{
 		std::unique_lock<std::mutex> lk(g_ctx_mu);
 		for (;;) {
@@ -232,11 +233,18 @@ struct CtxLease {
 			if (c) break;
 			g_ctx_cv.wait(lk);
 		}
-		for (int i = 0; i < MAX_CALLS; ++i) others += g_ctx[i].busy && &g_ctx[i] != c;
+		for (int i = 0; i < MAX_CALLS; ++i) {
+			if (!g_ctx[i].busy || &g_ctx[i] == c) continue;
+			++others;
+			// calls in flight must not share reads: each writes the seq[] and sam of its own
+			if (seqs < g_ctx[i].seq_hi && g_ctx[i].seq_lo < seqs + n)
+				die("mem_process_seqs: called on seqs[] that another call in flight is still working on");
+		}
+		c->seq_lo = seqs; c->seq_hi = seqs + n;
 	}
 	~CtxLease()
 	{
-		{ std::lock_guard<std::mutex> lk(g_ctx_mu); c->busy = false; }
+		{ std::lock_guard<std::mutex> lk(g_ctx_mu); c->busy = false; c->seq_lo = c->seq_hi = nullptr; }
 		g_ctx_cv.notify_one();
 	}
 };
@@ -303,7 +311,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		~Publish() { t_stats = s; t_stats_set = true; std::lock_guard<std::mutex> lk(g_ctx_mu); g_stats = s; }
 	} publish{STAT};
 	if (n <= 0) return;
-	CtxLease lease;
+	CtxLease lease(seqs, n);
 	CallCtx &C = *lease.c;
 	const int n_thr = host_threads(opt);
 	const bool pe = (opt->flag & MEM_F_PE) != 0;

@@ -233,3 +233,31 @@ def test_long_indels_take_the_wide_band_paths(both, genome):
     _cmp(eng, ref, reads, dict(flag=abi.MEM_F_PE, w=200))          # wider extension band: longer gaps survive into the CIGAR
     _cmp(eng, ref, [(n, a, None) for n, a, b in reads], dict(flag=0, o_del=3, o_ins=3))
     assert eng.stats()["n_aln"] > 0
+
+
+def test_overlapping_seqs_in_flight_abort_with_a_message(genome, tmp_path):
+    """Two calls in flight on the same seqs[] would both write its seq[] / sam: the library refuses loudly (own process)."""
+    import subprocess
+    import sys
+    import textwrap
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, threading
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        from mpibwa_amd import abi, api, simulate
+        eng = api.Engine(%r, device=0)
+        _, seqs = simulate.make_genome(50000, 1, seed=5, n_runs=0)
+        import numpy as np
+        rd = simulate.reads_to_ascii(simulate.simulate_reads(%s, 3000, 150, paired=True, seed=3))
+        batch = abi.SeqBatch(api.libc, rd)
+        opt = eng.opt(flag=abi.MEM_F_PE)
+        th = [threading.Thread(target=lambda: [eng.process_batch(opt, batch) for _ in range(20)]) for _ in range(2)]
+        [t.start() for t in th]; [t.join() for t in th]
+        print("SURVIVED")
+    """) % (root, os.path.join(root, "tests"), genome["prefix"], "__import__('pickle').load(open(%r, 'rb'))" % str(tmp_path / "g.pkl"))
+    import pickle
+    pickle.dump(genome["seqs"], open(tmp_path / "g.pkl", "wb"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "SURVIVED" not in r.stdout
+    assert "another call in flight" in r.stderr
