@@ -16,7 +16,8 @@
  *     bntann1_t     src/bntseq.h:41-48   (40 bytes)
  *     bntamb1_t     src/bntseq.h:50-54   (16 bytes)
  *     bntseq_t      src/bntseq.h:56-64   (48 bytes)
- * Sizes are checked with static asserts in mpibwa_amd/csrc/abi_check.cpp.
+ * Sizes and field offsets are checked at build time by static asserts in
+ * mpibwa_amd/csrc/abi_check.cpp (C++) and tests/abi_check.c (plain C).
  */
 #ifndef MPIBWA_AMD_H
 #define MPIBWA_AMD_H
@@ -161,11 +162,21 @@ mem_opt_t *mem_opt_init(void);
 void bwa_fill_scmat(int a, int b, int8_t mat[25]);
 extern int  bwa_verbose;
 extern char bwa_rg_id[256];
+/* read-group / extra header lines of the caller's CLI (src/bwa.c:431-476; used by src/mainParallel.c:356, :368, :373):
+ * bwa_set_rg() returns the unescaped "@RG..." line (malloc()ed) and fills bwa_rg_id with its ID, or 0 if malformed;
+ * bwa_insert_header() appends an unescaped '@' line to the header text (realloc()ed) and returns it. */
+char *bwa_set_rg(const char *s);
+char *bwa_insert_header(const char *s, char *hdr);
 
 /* index attach / load (src/bwa.c:262-345: bwa_idx_load_from_disk, bwa_mem2idx) */
 bwaidx_t *bwa_idx_load_from_disk(const char *prefix, int which);
 int       bwa_mem2idx(int64_t l_mem, uint8_t *mem, bwaidx_t *idx);
 void      bwa_idx_destroy(bwaidx_t *idx);
+/* `.map` packer (src/bwa.c:347-386, used by mpiBWAIdx src/pidx.c:52-63): turns a disk-loaded index into one contiguous
+ * malloc()ed image [bwt_t][bwt words][sa][bntseq_t][ambs][anns][name\0anno\0...][pac] and re-attaches idx to it. */
+int       bwa_idx2mem(bwaidx_t *idx);
+/* mpiBWAIdx in one call: load <prefix>.{bwt,sa,ann,amb,pac}, pack, write the image to map_path (pointer fields zeroed). */
+int       mi355x_write_map(const char *prefix, const char *map_path);
 
 /* ---- MI355X-specific additions (no reference equivalent) ---- */
 
@@ -183,6 +194,20 @@ int  mi355x_index_buffers(void **d_bwt, size_t *bwt_bytes, void **d_sa, size_t *
 int  mi355x_index_d2d(int which, void *ext_device_ptr, size_t bytes, int to_index);
 int  mi355x_index_commit(void);
 void mi355x_finalize(void);
+
+/* One call per rank after the index has been attached (replaces the per-rank copy of src/parallel_aux.c:1779-1830):
+ * selects GPU `local_rank`; with comm == NULL or comm->size == 1 the index is uploaded from idx; otherwise rank 0 of
+ * the communicator uploads its copy and the occ blocks, the sampled SA and pac reach the other ranks' GPUs by
+ * ncclBroadcast (RCCL over xGMI, in pieces), after which every rank expands its dense SA and jump table.
+ * The library does not link MPI: the caller lends its own transport for the 128-byte RCCL bootstrap id. */
+typedef struct {
+	int rank, size;                                                  /* among the ranks that share the broadcast (one per GPU) */
+	void (*bcast)(void *buf, size_t bytes, int root, void *user);    /* host-memory broadcast, e.g. a wrapper of MPI_Bcast */
+	void *user;
+} mi355x_comm_t;
+int  mi355x_init(int local_rank, const bwaidx_t *idx, const mi355x_comm_t *comm);
+/* seconds spent in the RCCL broadcast of the last mi355x_init (0 when none took place) */
+double mi355x_init_bcast_seconds(void);
 
 /* own bwa-compatible index builder (formats of src/bwt.c:385-462,
  * src/bntseq.c:66-96,275-328). Writes prefix.{pac,ann,amb,bwt,sa}. */
@@ -222,6 +247,18 @@ int mi355x_extend_batch(const mem_opt_t *opt, int n, const uint8_t *q, const int
 int64_t mi355x_chain_batch(const mem_opt_t *opt, const bntseq_t *bns, int n_reads, const int *lens, const int *l_rep,
                            const int64_t *seed_off, const uint64_t *rbeg, const int32_t *qbeg_len, int which,
                            int64_t *out, int64_t out_cap, int64_t *out_off);
+
+/* Final global re-alignment (mem_reg2aln's loop src/bwamem.c:1106-1122 around bwa_gen_cigar2 src/bwa.c:121-207 and
+ * ksw_global2 src/ksw.c:504-606) for n_req regions [rb,re) x [qb,qe) of read `read` (nt4 codes, read r =
+ * reads[off[r]..off[r+1])) against the 2-bit packed reference `pac` of l_pac bases, computed by aln_kernel.
+ * which: 0 = the product's dispatch (no-DP shortcut / narrow-band instantiation with hand-off to the full-size one),
+ * 1 = DP requests straight to the full-size instantiation.
+ * Per request out_hdr gets score, NM, n_cigar, md_len, flags (1 = the device declined: band matrix beyond its budget);
+ * cigar (BAM-encoded u32) goes to cigar_out[cigar_cap * i ..], MD text to md_out[md_cap * i ..]. */
+int mi355x_global_batch(const mem_opt_t *opt, int64_t l_pac, const uint8_t *pac, int n_reads, const uint8_t *reads,
+                        const int64_t *off, int n_req, const int64_t *rb, const int64_t *re, const int *read,
+                        const int *qb, const int *qe, const int *w, const int *truesc, int which,
+                        int *out_hdr5, uint32_t *cigar_out, int cigar_cap, char *md_out, int md_cap, double *kernel_ms);
 
 /* Mate-rescue local alignment: ksw_align2() exactly as mem_matesw() calls it (src/bwamem_pair.c:150-177,
  * src/ksw.c:321-356), for n_req windows [rb,re) of a 2-bit packed reference (doubled coordinate) against reads

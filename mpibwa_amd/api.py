@@ -18,7 +18,15 @@ EXPORTS = [
     "mi355x_index_upload", "mi355x_index_alloc", "mi355x_index_buffers", "mi355x_index_d2d", "mi355x_index_commit",
     "mi355x_finalize", "mi355x_index_build", "mi355x_index_build_gpu",
     "mi355x_smem_batch", "mi355x_sa_batch", "mi355x_sa_batch2", "mi355x_sa_dense_info", "mi355x_extend_batch", "mi355x_matesw_batch", "mi355x_chain_batch", "mi355x_fastq_scan", "mi355x_fastq_chunks", "mi355x_fastq_fill", "mi355x_last_stats", "mi355x_host_cpus", "mi355x_collect_sam", "mi355x_host_ksw_align2",
+    "bwa_set_rg", "bwa_insert_header", "bwa_idx2mem", "mi355x_write_map", "mi355x_init", "mi355x_init_bcast_seconds", "mi355x_global_batch",
 ]
+
+
+class mi355x_comm_t(C.Structure):
+    """include/mpibwa_amd.h: the caller's transport for the RCCL bootstrap id"""
+    BCAST = C.CFUNCTYPE(None, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+    _fields_ = [("rank", C.c_int), ("size", C.c_int), ("bcast", BCAST), ("user", C.c_void_p)]
+
 
 
 def load_library(build_if_missing=True):
@@ -67,6 +75,16 @@ def load_library(build_if_missing=True):
     sig("mi355x_host_ksw_align2", None, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p])
     sig("mi355x_host_cpus", C.c_int, [])
     sig("mi355x_collect_sam", C.c_void_p, [P(abi.bseq1_t), C.c_int, P(C.c_size_t)])
+    sig("bwa_set_rg", C.c_void_p, [C.c_char_p])
+    sig("bwa_insert_header", C.c_void_p, [C.c_char_p, C.c_void_p])
+    sig("bwa_idx2mem", C.c_int, [P(abi.bwaidx_t)])
+    sig("bwa_mem2idx", C.c_int, [C.c_int64, C.c_void_p, P(abi.bwaidx_t)])
+    sig("bwa_idx_destroy", None, [P(abi.bwaidx_t)])
+    sig("mi355x_write_map", C.c_int, [C.c_char_p, C.c_char_p])
+    sig("mi355x_init", C.c_int, [C.c_int, P(abi.bwaidx_t), P(mi355x_comm_t)])
+    sig("mi355x_init_bcast_seconds", C.c_double, [])
+    sig("mi355x_global_batch", C.c_int, [P(abi.mem_opt_t), C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 7 +
+        [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, P(C.c_double)])
     _LIB = lib
     return lib
 
@@ -91,17 +109,31 @@ def build_index(fasta, prefix):
 class Engine:
     """One rank = one GPU: loads a bwa index, uploads it to HBM and aligns batches."""
 
-    def __init__(self, prefix, device=0, upload=True, dist=None, rank=0):
+    def __init__(self, prefix, device=0, upload=True, dist=None, rank=0, map_path=None, comm=None):
         """dist given (torch.distributed, nccl = RCCL): rank 0 uploads the index from host memory, every other rank only
-        allocates the device buffers and receives occ blocks, SA and pac by broadcast over xGMI."""
+        allocates the device buffers and receives occ blocks, SA and pac by broadcast over xGMI.
+        map_path given: the index is attached from mpiBWA's `.map` image (bwa_mem2idx) instead of the five bwa files.
+        comm given (mi355x_comm_t): residency through mi355x_init(), i.e. the C-side RCCL broadcast."""
         self.lib = load_library()
-        self.idx = self.lib.bwa_idx_load_from_disk(prefix.encode(), 7)
+        if map_path is not None:
+            import numpy as np
+            self._map = np.fromfile(map_path, dtype=np.uint8)          # writable: bwa_mem2idx rebuilds the pointers inside
+            self._idx_obj = abi.bwaidx_t()
+            self.lib.bwa_mem2idx(len(self._map), self._map.ctypes.data, C.byref(self._idx_obj))
+            self.idx = C.pointer(self._idx_obj)
+        else:
+            self.idx = self.lib.bwa_idx_load_from_disk(prefix.encode(), 7)
         self.bwt = self.idx.contents.bwt
         self.bns = self.idx.contents.bns
         self.pac = self.idx.contents.pac
         self.uploaded = False
         self.bcast_seconds = None
-        if upload and dist is None:
+        if upload and comm is not None:
+            if self.lib.mi355x_init(device, self.idx, C.byref(comm)) != 0:
+                raise RuntimeError("mi355x_init failed")
+            self.uploaded = True
+            self.bcast_seconds = self.lib.mi355x_init_bcast_seconds()
+        elif upload and dist is None:
             if self.lib.mi355x_index_upload(device, self.bwt, self.bns, self.pac) != 0:
                 raise RuntimeError("mi355x_index_upload failed")
             self.uploaded = True
@@ -261,6 +293,32 @@ class Engine:
         self.lib.mi355x_matesw_batch(opt, int(l_pac), pac.ctypes.data, n, flat.ctypes.data, off.ctypes.data, len(rb), rb.ctypes.data,
                                      re.ctypes.data, read.ctypes.data, is_rev.ctypes.data, out.ctypes.data, C.byref(ms))
         return out, ms.value
+
+    def global_align(self, opt, l_pac, pac, reads, rb, re, read, qb, qe, w, truesc, which=0, cigar_cap=128, md_cap=800):
+        """mem_reg2aln's DP loop (CIGAR / MD / NM) for regions of `reads` against windows of `pac`, by aln_kernel.
+        Returns (hdr (n,5) int32: score, NM, n_cigar, md_len, flags; list of cigar arrays; list of MD bytes; kernel ms)."""
+        n = len(reads)
+        off = np.zeros(n + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(s) for s in reads])
+        flat = np.concatenate(reads).astype(np.uint8)
+        arr = lambda x, t: np.ascontiguousarray(x, dtype=t)
+        rb, re = arr(rb, np.int64), arr(re, np.int64)
+        read, qb, qe, w, truesc = (arr(x, np.int32) for x in (read, qb, qe, w, truesc))
+        pac = arr(pac, np.uint8)
+        nr = len(rb)
+        hdr = np.zeros((nr, 5), dtype=np.int32)
+        cig = np.zeros((nr, cigar_cap), dtype=np.uint32)
+        md = np.zeros((nr, md_cap), dtype=np.uint8)
+        ms = C.c_double(0)
+        rc = self.lib.mi355x_global_batch(opt, int(l_pac), pac.ctypes.data, n, flat.ctypes.data, off.ctypes.data, nr, rb.ctypes.data,
+                                          re.ctypes.data, read.ctypes.data, qb.ctypes.data, qe.ctypes.data, w.ctypes.data,
+                                          truesc.ctypes.data, which, hdr.ctypes.data, cig.ctypes.data, cigar_cap, md.ctypes.data, md_cap,
+                                          C.byref(ms))
+        if rc != 0:
+            raise RuntimeError("mi355x_global_batch: result beyond cigar_cap / md_cap")
+        cigs = [cig[i, :hdr[i, 2]].copy() for i in range(nr)]
+        mds = [md[i, :hdr[i, 3]].tobytes() for i in range(nr)]
+        return hdr, cigs, mds, ms.value
 
     def extend(self, opt, qs, ts, w, h0, end_bonus):
         n = len(qs)

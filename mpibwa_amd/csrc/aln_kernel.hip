@@ -77,16 +77,18 @@ __device__ __forceinline__ bool aln_no_dp(const AlnParams &P, const AlnReq &R, i
 }
 
 // request numbers -> lists[0 .. n_req) (no DP) and lists[n_req .. 2 n_req) (DP); one atomic per wave and list
+// dp_kind: the list DP requests start in (1 = narrow variant first, the product's dispatch; 2 = straight to the full-size one)
 __global__ void __launch_bounds__(256) aln_classify_kernel(AlnParams P, int n_req, const AlnReq *__restrict__ reqs, int max_len, int tcap,
-                                                           int *__restrict__ lists, unsigned long long *counters)
+                                                           int *__restrict__ lists, unsigned long long *counters, int dp_kind)
 {
 	const int rq = blockIdx.x * 256 + threadIdx.x;
 	const bool live = rq < n_req;
 	bool nodp = false;
 	if (live) nodp = aln_no_dp(P, reqs[rq], max_len, tcap);
 	const unsigned long long below = (1ull << (threadIdx.x & 63)) - 1;
-	for (int kind = 0; kind < 2; ++kind) {
-		const bool mine = live && (nodp == (kind == 0));
+	for (int pass = 0; pass < 2; ++pass) {
+		const bool mine = live && (nodp == (pass == 0));
+		const int kind = pass == 0 ? 0 : dp_kind;
 		const unsigned long long m = __ballot(mine);
 		if (!m) continue;
 		unsigned long long base = 0;
@@ -383,7 +385,7 @@ size_t aln_lds_per_block(int max_len, int tcap)
 
 void launch_aln(void *stream, const AlnParams &P, const ExtParams &ep, int n_req, const AlnReq *d_req, const uint8_t *d_seq,
                 const int64_t *d_off, const uint8_t *d_pac, const int *d_gaptab, AlnHdr *d_hdr, uint8_t *d_pool,
-                unsigned long long *d_counters, size_t pool_bytes, int max_len, int tcap, int *d_lists)
+                unsigned long long *d_counters, size_t pool_bytes, int max_len, int tcap, int *d_lists, bool wide_only)
 {
 	if (n_req <= 0) return;
 	WxParams X;
@@ -413,7 +415,8 @@ void launch_aln(void *stream, const AlnParams &P, const ExtParams &ep, int n_req
 	};
 	const dim3 block(64 * ALN_WAVES);
 	hipStream_t st = (hipStream_t)stream;
-	hipLaunchKernelGGL(aln_classify_kernel, dim3((n_req + 255) / 256), dim3(256), 0, st, P, n_req, d_req, max_len, tcap, d_lists, d_counters);
+	hipLaunchKernelGGL(aln_classify_kernel, dim3((n_req + 255) / 256), dim3(256), 0, st, P, n_req, d_req, max_len, tcap, d_lists, d_counters,
+	                   wide_only ? 2 : 1);
 	hipLaunchKernelGGL(aln_kernel<0>, grid_for(shmem_fast), block, shmem_fast, st, P, X, n_req, d_req, d_seq, d_off, d_pac, d_gaptab, d_hdr, d_pool,
 	                   d_counters, (unsigned long long)pool_bytes, max_len, tcap, d_lists);
 	hipLaunchKernelGGL(aln_kernel<1>, grid_for(shmem_small), block, shmem_small, st, P, X, n_req, d_req, d_seq, d_off, d_pac, d_gaptab, d_hdr, d_pool,

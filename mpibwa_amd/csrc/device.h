@@ -33,8 +33,15 @@ struct DevIndex {
 	void *d_sa_full = nullptr; size_t sa_full_bytes = 0; double sa_expand_ms = 0;
 	void *d_p3tab = nullptr;
 	int64_t l_pac = 0;
+	// what is resident, as the caller's host-side index describes itself (compared on every mem_process_seqs call)
+	uint64_t id_primary = 0, id_seq_len = 0, id_L2[5] = {0, 0, 0, 0, 0};
+	int id_n_seqs = 0;
 };
 DevIndex &dev_index();
+// true when (bwt, bns) describe the index that is resident; message = what differs
+bool index_matches(const bwt_t *bwt, const bntseq_t *bns, const char **what);
+// calls of mem_process_seqs currently inside the library (pipeline.hip); index upload / release need it to be 0
+int calls_in_flight();
 
 // SMEM seeding parameters (subset of mem_opt_t used by mem_collect_intv)
 struct SmemParams {
@@ -140,7 +147,8 @@ struct AlnHdr {                  // result header; cigar (n_cigar x u32) and MD 
 struct AlnParams { int64_t l_pac; int a, w; };
 void launch_aln(void *stream, const AlnParams &P, const ExtParams &ep, int n_req, const AlnReq *d_req, const uint8_t *d_seq,
                 const int64_t *d_off, const uint8_t *d_pac, const int *d_gaptab, AlnHdr *d_hdr, uint8_t *d_pool,
-                unsigned long long *d_counters, size_t pool_bytes, int max_len, int tcap, int *d_lists /* 3 * n_req ints of scratch */);
+                unsigned long long *d_counters, size_t pool_bytes, int max_len, int tcap, int *d_lists /* 3 * n_req ints of scratch */,
+                bool wide_only = false /* DP requests skip the narrow-band instantiation (stage tests) */);
 
 // ---- mate-rescue local alignment on the device (msw_kernel.hip) ----
 struct MswReq {                  // one ksw_align2() call of mem_matesw (src/bwamem_pair.c:150-177)

@@ -57,8 +57,27 @@ static void require_device(int local_rank)
 	g_idx.device = local_rank % n;
 }
 
+bool index_matches(const bwt_t *bwt, const bntseq_t *bns, const char **what)
+{
+	const char *w = nullptr;
+	if (bwt->seq_len != g_idx.id_seq_len) w = "seq_len";
+	else if (bwt->primary != g_idx.id_primary) w = "primary";
+	else if (memcmp(bwt->L2, g_idx.id_L2, sizeof g_idx.id_L2) != 0) w = "L2";
+	else if (bns->l_pac != g_idx.l_pac) w = "l_pac";
+	else if (bns->n_seqs != g_idx.id_n_seqs) w = "n_seqs";
+	if (what) *what = w;
+	return w == nullptr;
+}
+
+static void no_calls_in_flight(const char *who)
+{
+	if (calls_in_flight() > 0) die("%s while mem_process_seqs calls are in flight on the resident index", who);
+}
+
 static void alloc_index(const bwt_t *bwt, const bntseq_t *bns)
 {
+	no_calls_in_flight("index upload");
+	g_idx.ready = false;
 	if (g_idx.d_blk) { (void)hipFree(g_idx.d_blk); (void)hipFree(g_idx.d_sa); (void)hipFree(g_idx.d_pac); }
 	g_idx.blk_bytes = ((size_t)bwt->bwt_size * 4 + 63) / 64 * 64 + 64;   // whole 64-B blocks + one pad block
 	g_idx.sa_bytes = (size_t)bwt->n_sa * 8;
@@ -80,6 +99,8 @@ static void alloc_index(const bwt_t *bwt, const bntseq_t *bns)
 	if ((1 << sh) != bwt->sa_intv) die("SA sampling interval %d is not a power of two", bwt->sa_intv);
 	fm.sa_shift = sh;
 	g_idx.l_pac = bns->l_pac;
+	g_idx.id_primary = bwt->primary; g_idx.id_seq_len = bwt->seq_len; g_idx.id_n_seqs = bns->n_seqs;
+	memcpy(g_idx.id_L2, bwt->L2, sizeof g_idx.id_L2);
 	if (bwt->seq_len >= (1ull << 34))
 		die("reference of %llu symbols: this build packs SA-interval bounds into 34 bits (references up to 8.5 Gbp)", (unsigned long long)bwt->seq_len);
 }
@@ -187,6 +208,7 @@ extern "C" int mi355x_index_commit(void)
 
 extern "C" void mi355x_finalize(void)
 {
+	no_calls_in_flight("mi355x_finalize");
 	if (g_idx.d_blk) { (void)hipFree(g_idx.d_blk); (void)hipFree(g_idx.d_sa); (void)hipFree(g_idx.d_pac); }
 	if (g_idx.d_sa_full) (void)hipFree(g_idx.d_sa_full);
 	if (g_idx.d_p3tab) (void)hipFree(g_idx.d_p3tab);
@@ -569,4 +591,82 @@ extern "C" int64_t mi355x_chain_batch(const mem_opt_t *opt, const bntseq_t *bns,
 	}
 	out_off[n_reads] = at;
 	return at;
+}
+
+// Stage-level entry point of the CIGAR / MD / NM kernel (tests): n_req regions of reads of a batch against windows of the
+// packed reference `pac`, through mem_reg2aln's band-doubling loop (src/bwamem.c:1106-1122) exactly as the SAM stage asks
+// for them.  which = 0: the product's dispatch (no-DP / narrow band / full size); 1: DP requests straight to the full-size
+// instantiation.  out_hdr5 per request: score, NM, n_cigar, md_len, flags.
+extern "C" int mi355x_global_batch(const mem_opt_t *opt, int64_t l_pac, const uint8_t *pac, int n_reads, const uint8_t *reads,
+                                   const int64_t *off, int n_req, const int64_t *rb, const int64_t *re, const int *read,
+                                   const int *qb, const int *qe, const int *w, const int *truesc, int which,
+                                   int *out_hdr5, uint32_t *cigar_out, int cigar_cap, char *md_out, int md_cap, double *kernel_ms)
+{
+	int nd = 0;
+	if (hipGetDeviceCount(&nd) != hipSuccess || nd == 0) die("no HIP device visible (no CPU fallback)");
+	if (n_req <= 0) return 0;
+	hipStream_t st = 0;
+	std::vector<int64_t> slot(n_reads + 1);
+	int max_len = 0;
+	slot[0] = 0;
+	for (int i = 0; i < n_reads; ++i) {
+		const int len = (int)(off[i + 1] - off[i]);
+		slot[i + 1] = slot[i] + ((len + 15) & ~15);
+		max_len = std::max(max_len, len);
+	}
+	std::vector<uint8_t> flat(slot[n_reads] + 16, 4);
+	for (int i = 0; i < n_reads; ++i) memcpy(flat.data() + slot[i], reads + off[i], (size_t)(off[i + 1] - off[i]));
+	std::vector<AlnReq> rq(n_req);
+	for (int i = 0; i < n_req; ++i) {
+		if (read[i] < 0 || read[i] >= n_reads || rb[i] < 0 || re[i] > 2 * l_pac) die("mi355x_global_batch: bad request %d", i);
+		rq[i].rb = rb[i]; rq[i].re = re[i]; rq[i].read = read[i]; rq[i].qb = qb[i]; rq[i].qe = qe[i]; rq[i].w2 = w[i]; rq[i].truesc = truesc[i];
+		rq[i].pad = 0;
+	}
+	std::vector<int> gaptab(max_len + 2);
+	for (int l = 0; l <= max_len + 1; ++l) {   // max_gap of bwa_gen_cigar2 (src/bwa.c:155-158), as pipeline.hip tabulates it
+		int max_ins = (int)((double)(((l + 1) >> 1) * opt->mat[0] - opt->o_ins) / opt->e_ins + 1.);
+		int max_del = (int)((double)(((l + 1) >> 1) * opt->mat[0] - opt->o_del) / opt->e_del + 1.);
+		int g = max_ins > max_del ? max_ins : max_del;
+		gaptab[l] = g > 1 ? g : 1;
+	}
+	const size_t pool_bytes = (size_t)n_req * (4 * 96 + 768) + (1 << 20);
+	uint8_t *d_seq, *d_pac, *d_pool; int64_t *d_off; AlnReq *d_req; AlnHdr *d_hdr; int *d_gap, *d_lists; unsigned long long *d_cnt;
+	HIP_OK(hipMalloc(&d_seq, flat.size())); HIP_OK(hipMalloc(&d_pac, l_pac / 4 + 16)); HIP_OK(hipMalloc(&d_pool, pool_bytes));
+	HIP_OK(hipMalloc(&d_off, (size_t)(n_reads + 1) * 8)); HIP_OK(hipMalloc(&d_req, (size_t)n_req * sizeof(AlnReq)));
+	HIP_OK(hipMalloc(&d_hdr, (size_t)n_req * sizeof(AlnHdr))); HIP_OK(hipMalloc(&d_gap, gaptab.size() * 4));
+	HIP_OK(hipMalloc(&d_lists, (size_t)n_req * 3 * 4)); HIP_OK(hipMalloc(&d_cnt, 256));
+	HIP_OK(hipMemcpy(d_seq, flat.data(), flat.size(), hipMemcpyHostToDevice));
+	HIP_OK(hipMemcpy(d_pac, pac, l_pac / 4 + 1, hipMemcpyHostToDevice));
+	HIP_OK(hipMemcpy(d_off, slot.data(), (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice));
+	HIP_OK(hipMemcpy(d_req, rq.data(), (size_t)n_req * sizeof(AlnReq), hipMemcpyHostToDevice));
+	HIP_OK(hipMemcpy(d_gap, gaptab.data(), gaptab.size() * 4, hipMemcpyHostToDevice));
+	HIP_OK(hipMemset(d_cnt, 0, 256));
+	AlnParams ap;
+	ap.l_pac = l_pac; ap.a = opt->a; ap.w = opt->w;
+	ExtParams ep;
+	memcpy(ep.mat, opt->mat, 25);
+	ep.o_del = opt->o_del; ep.e_del = opt->e_del; ep.o_ins = opt->o_ins; ep.e_ins = opt->e_ins; ep.zdrop = opt->zdrop;
+	Timer tm;
+	tm.start(st);
+	launch_aln(st, ap, ep, n_req, d_req, d_seq, d_off, d_pac, d_gap, d_hdr, d_pool, d_cnt, pool_bytes, max_len, max_len + 256, d_lists, which != 0);
+	double ms = tm.stop(st);
+	HIP_OK(hipGetLastError());
+	std::vector<AlnHdr> hdr(n_req);
+	std::vector<uint8_t> pool(pool_bytes);
+	HIP_OK(hipMemcpy((void *)hdr.data(), d_hdr, (size_t)n_req * sizeof(AlnHdr), hipMemcpyDeviceToHost));
+	HIP_OK(hipMemcpy(pool.data(), d_pool, pool_bytes, hipMemcpyDeviceToHost));
+	(void)hipFree(d_seq); (void)hipFree(d_pac); (void)hipFree(d_pool); (void)hipFree(d_off); (void)hipFree(d_req); (void)hipFree(d_hdr);
+	(void)hipFree(d_gap); (void)hipFree(d_lists); (void)hipFree(d_cnt);
+	int rc = 0;
+	for (int i = 0; i < n_req; ++i) {
+		const AlnHdr &h = hdr[i];
+		int *o = out_hdr5 + 5 * (size_t)i;
+		o[0] = h.score; o[1] = h.NM; o[2] = h.n_cigar; o[3] = h.md_len; o[4] = h.flags;
+		if (h.flags) continue;
+		if (h.n_cigar > cigar_cap || h.md_len > md_cap) { rc = -1; continue; }
+		memcpy(cigar_out + (size_t)cigar_cap * i, pool.data() + (size_t)h.pool_off * 4, (size_t)h.n_cigar * 4);
+		memcpy(md_out + (size_t)md_cap * i, pool.data() + (size_t)h.pool_off * 4 + (size_t)h.n_cigar * 4, (size_t)h.md_len);
+	}
+	if (kernel_ms) *kernel_ms = ms;
+	return rc;
 }

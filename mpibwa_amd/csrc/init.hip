@@ -1,0 +1,121 @@
+// init.hip — mi355x_init(): device selection + index residency for one rank, with the index reaching the GPUs of the
+// other ranks by ncclBroadcast (RCCL over xGMI) instead of one H2D copy per rank.
+//
+// Replaces, for a one-rank-per-GPU run, what mpiBWA does per rank after attaching the `.map` image
+// (src/parallel_aux.c:1745-1838: every rank of a shared-memory group reads the mapped index through the CPU caches).
+// The reference has no device side, so there is nothing to mirror line by line; the contract is SURVEY.md §8b/§8e:
+// exactly one collective, at start-up, on the three index arrays.
+//
+// RCCL is loaded at run time (dlopen of librccl.so.1: the library ROCm ships and PyTorch-ROCm bundles), so the product
+// library carries no link-time dependency on it and single-rank users never load it.  The library does not link MPI
+// either: the caller lends a host-memory broadcast (mpiBWA: a two-line wrapper of MPI_Bcast) for the 128-byte RCCL
+// bootstrap id.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "device.h"
+
+namespace mbw {
+
+#define HIP_OK(call)                                                                                             \
+	do {                                                                                                         \
+		hipError_t e_ = (call);                                                                                  \
+		if (e_ != hipSuccess) die("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);    \
+	} while (0)
+
+// the five RCCL entry points used, with the types of rccl.h (ncclUniqueId = 128 opaque bytes, ncclUint8 = 1)
+struct RcclId { char internal[128]; };
+typedef void *RcclComm;
+struct Rccl {
+	void *so = nullptr;
+	int (*GetUniqueId)(RcclId *) = nullptr;
+	int (*CommInitRank)(RcclComm *, int, RcclId, int) = nullptr;
+	int (*Broadcast)(const void *, void *, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+	int (*CommDestroy)(RcclComm) = nullptr;
+	const char *(*GetErrorString)(int) = nullptr;
+};
+
+static Rccl &rccl()
+{
+	static Rccl r;
+	if (r.so) return r;
+	const char *names[] = {getenv("MPIBWA_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+	for (const char *n : names) {
+		if (!n) continue;
+		r.so = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+		if (r.so) break;
+	}
+	if (!r.so) die("mi355x_init: cannot load RCCL (librccl.so.1): %s", dlerror());
+	auto sym = [&](const char *s) { void *p = dlsym(r.so, s); if (!p) die("mi355x_init: RCCL lacks %s", s); return p; };
+	r.GetUniqueId = (int (*)(RcclId *))sym("ncclGetUniqueId");
+	r.CommInitRank = (int (*)(RcclComm *, int, RcclId, int))sym("ncclCommInitRank");
+	r.Broadcast = (int (*)(const void *, void *, size_t, int, int, RcclComm, hipStream_t))sym("ncclBroadcast");
+	r.CommDestroy = (int (*)(RcclComm))sym("ncclCommDestroy");
+	r.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
+	return r;
+}
+
+#define RCCL_OK(call)                                                                                           \
+	do {                                                                                                        \
+		int e_ = (call);                                                                                        \
+		if (e_ != 0) die("%s failed: %s (%s:%d)", #call, rccl().GetErrorString(e_), __FILE__, __LINE__);        \
+	} while (0)
+
+static double g_bcast_seconds = 0;
+
+} // namespace mbw
+
+using namespace mbw;
+
+extern "C" double mi355x_init_bcast_seconds(void) { return g_bcast_seconds; }
+
+extern "C" int mi355x_init(int local_rank, const bwaidx_t *idx, const mi355x_comm_t *comm)
+{
+	if (!idx || !idx->bwt || !idx->bns || !idx->pac) die("mi355x_init: the index handle is not attached");
+	g_bcast_seconds = 0;
+	if (!comm) return mi355x_index_upload(local_rank, idx->bwt, idx->bns, idx->pac);   // (a communicator of one rank still goes through RCCL)
+	if (comm->size < 1 || comm->rank < 0 || comm->rank >= comm->size || !comm->bcast) die("mi355x_init: bad communicator description");
+
+	// rank 0 puts its host copy into HBM; everybody else only allocates the three device arrays
+	if (comm->rank == 0) {
+		if (mi355x_index_alloc(local_rank, idx->bwt, idx->bns) != 0) return -1;
+		void *d[3]; size_t cap[3];
+		mi355x_index_buffers(&d[0], &cap[0], &d[1], &cap[1], &d[2], &cap[2]);
+		HIP_OK(hipMemcpy(d[0], idx->bwt->bwt, (size_t)idx->bwt->bwt_size * 4, hipMemcpyHostToDevice));
+		HIP_OK(hipMemcpy(d[1], idx->bwt->sa, (size_t)idx->bwt->n_sa * 8, hipMemcpyHostToDevice));
+		HIP_OK(hipMemcpy(d[2], idx->pac, (size_t)idx->bns->l_pac / 4 + 1, hipMemcpyHostToDevice));
+	} else if (mi355x_index_alloc(local_rank, idx->bwt, idx->bns) != 0) return -1;
+
+	Rccl &R = rccl();
+	RcclId id;
+	memset(&id, 0, sizeof id);
+	if (comm->rank == 0) RCCL_OK(R.GetUniqueId(&id));
+	comm->bcast(&id, sizeof id, 0, comm->user);
+	RcclComm nc = nullptr;
+	RCCL_OK(R.CommInitRank(&nc, comm->size, id, comm->rank));
+
+	void *d[3]; size_t cap[3];
+	mi355x_index_buffers(&d[0], &cap[0], &d[1], &cap[1], &d[2], &cap[2]);
+	hipStream_t st;
+	HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+	const auto t0 = std::chrono::steady_clock::now();
+	// in place on the index arrays, in pieces: a ring broadcast pipelines piece k+1 behind piece k on every xGMI hop, and
+	// no staging buffer is needed (the arrays have the same size on every rank: they are sized from the same metadata)
+	size_t piece = (size_t)256 << 20;
+	if (const char *e = getenv("MPIBWA_BCAST_PIECE_MB")) { long v = atol(e); if (v > 0) piece = (size_t)v << 20; }
+	for (int w = 0; w < 3; ++w)
+		for (size_t o = 0; o < cap[w]; o += piece) {
+			const size_t n = cap[w] - o < piece ? cap[w] - o : piece;
+			RCCL_OK(R.Broadcast((const char *)d[w] + o, (char *)d[w] + o, n, /*ncclUint8*/ 1, 0, nc, st));
+		}
+	HIP_OK(hipStreamSynchronize(st));
+	g_bcast_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	HIP_OK(hipStreamDestroy(st));
+	RCCL_OK(R.CommDestroy(nc));
+	// every rank expands its own dense SA and jump table from what it now holds (device-local, no further traffic)
+	return mi355x_index_commit();
+}

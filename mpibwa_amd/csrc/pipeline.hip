@@ -70,16 +70,37 @@ static int usable_cpus()
 	return hw;
 }
 
+// Which GPU a lazily uploading rank takes, and how many ranks share the node: the launcher's environment
+// (torchrun, Open MPI, MVAPICH2, Slurm/PMI, Intel MPI / MPICH hydra).  -1 / 0 when the launcher says nothing.
+static int env_int(const char *const *names, int dflt)
+{
+	for (; *names; ++names)
+		if (const char *e = getenv(*names)) return atoi(e);
+	return dflt;
+}
+static int env_local_rank()
+{
+	static const char *const n[] = {"LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "MV2_COMM_WORLD_LOCAL_RANK", "SLURM_LOCALID", "PMI_LOCAL_RANK",
+	                                "MPI_LOCALRANKID", nullptr};
+	return env_int(n, -1);
+}
+static int env_local_size()
+{
+	static const char *const n[] = {"LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MV2_COMM_WORLD_LOCAL_SIZE", "SLURM_NTASKS_PER_NODE", "PMI_LOCAL_SIZE",
+	                                "MPI_LOCALNRANKS", nullptr};
+	return env_int(n, 0);
+}
+
 static int host_threads(const mem_opt_t *opt)
 {
 	if (const char *e = getenv("MPIBWA_HOST_THREADS")) { int v = atoi(e); if (v > 0) return v; }
-	(void)opt;   // the result does not depend on the thread count (as in the reference), so use what the box gives us,
-	             // divided among the ranks that share this node (one rank per GPU)
-	int ranks = 1;
-	if (const char *e = getenv("LOCAL_WORLD_SIZE")) ranks = atoi(e);
-	else if (const char *e2 = getenv("OMPI_COMM_WORLD_LOCAL_SIZE")) ranks = atoi(e2);
+	// the result does not depend on the thread count (as in the reference), so use what the box gives us, divided among
+	// the ranks that share this node (one rank per GPU) — but never more than the caller's -t when it asked for several
+	int ranks = env_local_size();
 	if (ranks < 1) ranks = 1;
-	return std::max(1, std::min(usable_cpus() / ranks, 128));
+	int thr = std::max(1, std::min(usable_cpus() / ranks, 128));
+	if (opt && opt->n_threads > 1) thr = std::min(thr, opt->n_threads);
+	return thr;
 }
 
 template <class F>
@@ -250,7 +271,8 @@ struct CtxLease {
 };
 static thread_local mi355x_stats_t t_stats;   // of the last call made by this thread
 static thread_local bool t_stats_set = false;
-static const void *g_host_bwt = nullptr;
+static std::atomic<int> g_in_flight(0);
+int calls_in_flight() { return g_in_flight.load(); }
 
 } // namespace mbw
 
@@ -293,15 +315,23 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	const double t_begin = now_ms(), c_begin = cpu_sec(), s_begin = sys_sec();
 	DevIndex &ix = dev_index();
 	std::unique_lock<std::mutex> init_lk(g_init_mu);
-	if (!ix.ready || g_host_bwt != (const void *)bwt->bwt) {
-		// first call with this index: make it resident (one rank per GPU; LOCAL_RANK as set by torchrun / mpirun wrappers)
-		int lr = 0;
-		if (const char *e = getenv("LOCAL_RANK")) lr = atoi(e);
-		else if (const char *e2 = getenv("OMPI_COMM_WORLD_LOCAL_RANK")) lr = atoi(e2);
-		else if (const char *e3 = getenv("MV2_COMM_WORLD_LOCAL_RANK")) lr = atoi(e3);
-		if (!ix.ready) mi355x_index_upload(lr, bwt, bns, pac);
-		g_host_bwt = (const void *)bwt->bwt;
+	if (!ix.ready) {
+		// first call and nobody called mi355x_init / mi355x_index_upload: make the index resident (one rank per GPU, the GPU
+		// named by the launcher's local rank).  Several ranks on the node and no local rank known = every rank would pile
+		// its 60 GB onto GPU 0: refuse.
+		int lr = env_local_rank();
+		if (lr < 0) {
+			if (env_local_size() > 1) die("mem_process_seqs: %d ranks share this node but the launcher exports no local rank: call mi355x_init(local_rank, ...) first", env_local_size());
+			lr = 0;
+		}
+		mi355x_index_upload(lr, bwt, bns, pac);
 	}
+	// the resident index must be the one the caller passes: contig table, pac fetches and coordinates of the host stages
+	// come from the caller's copy, seeds and extensions from the device's
+	const char *what = nullptr;
+	if (!index_matches(bwt, bns, &what))
+		die("mem_process_seqs: the index passed in is not the one resident on the GPU (%s differs): mi355x_finalize() and upload it first", what);
+	struct InFlight { InFlight() { ++g_in_flight; } ~InFlight() { --g_in_flight; } } in_flight;
 	init_lk.unlock();
 	HIP_OK(hipSetDevice(ix.device));
 	mi355x_stats_t STAT;
