@@ -31,7 +31,8 @@ def build(force=False, verbose=False):
     hdrs.append(os.path.join(HERE, "..", "include", "mpibwa_amd.h"))
     objs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
-    common = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-g1", "-Wall", "-Wno-unused-function", "-Wno-unused-result",
+    extra = os.environ.get("MPIBWA_CXXFLAGS", "").split()
+    common = extra + ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-g1", "-Wall", "-Wno-unused-function", "-Wno-unused-result",
               "-I", CSRC, "-I", os.path.join(HERE, "..", "include")]
     for s in srcs:
         o = os.path.join(HERE, "build", os.path.basename(s) + ".o")
@@ -45,7 +46,7 @@ def build(force=False, verbose=False):
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)
     if force or _stale(OUT, objs):
-        cmd = [HIPCC, "-shared", "-o", OUT] + objs + ["-Wl,-Bsymbolic", "-lpthread", "-lm"]
+        cmd = [HIPCC, "-shared", "-o", OUT] + objs + ["-Wl,-Bsymbolic", "-Wl,-soname,libmpibwa_amd.so", "-lpthread", "-lm", "-ldl"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

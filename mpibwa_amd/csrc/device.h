@@ -56,20 +56,18 @@ struct DevBuf {
 };
 
 // Launchers (all asynchronous on `stream`; kernel time measured by the caller with HIP events)
+// SMEM seeding: two launches on the stream — the third pass (smem_kernels.hip, a read per lane) first, then passes 1-2
+// (fm_kernels.hip, a read per quad), which append to its output.
 // d_off[r] must be a multiple of 16 (reads padded to 16-byte slots); d_len[r] is the true length
 void launch_smem(void *stream, const FmDev &fm, const SmemParams &sp, int n_reads, const uint8_t *d_seq,
                  const int64_t *d_off, const int *d_len, int cap, uint64_t *d_out, int *d_nout, int max_len,
-                 unsigned long long *d_counters /* [0]=next read, [1]=blocks, [2]=overflow */,
+                 unsigned long long *d_counters /* zeroed; [1]=blocks, [2]=overflow on return */,
                  void *d_scratch, size_t scratch_bytes_per_quad, int n_quads);
 int  smem_grid_quads(int max_len, size_t *scratch_per_quad);
+void launch_smem_p3(void *stream, const FmDev &fm, const SmemParams &sp, int n_reads, const uint8_t *d_seq, const int64_t *d_off,
+                    const int *d_len, int cap, uint64_t *d_out, int *d_nout, unsigned long long *d_counters);
 // fills tab (4^(k+1) entries of 32 B) with the state of bwt_seed_strategy1 after k forward extensions of every (k+1)-mer
 void launch_p3_build(void *stream, const FmDev &fm, int k, void *d_tab);
-// lane-per-read variant (smem_lane.hip); same contract
-void launch_smem_lane(void *stream, const FmDev &fm, const SmemParams &sp, int n_reads, const uint8_t *d_seq,
-                      const int64_t *d_off, const int *d_len, int cap, uint64_t *d_out, int *d_nout,
-                      unsigned long long *d_counters, void *d_scratch, size_t scratch_bytes_per_lane, int n_lanes);
-int  smem_lane_grid(int max_len, size_t *scratch_per_lane);
-bool smem_use_lane();
 
 void launch_sa(void *stream, const FmDev &fm, int n, const uint64_t *d_k, uint64_t *d_out,
                unsigned long long *d_counters /* [0]=next task, [1]=steps */);

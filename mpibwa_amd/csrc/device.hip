@@ -19,14 +19,6 @@ namespace mbw {
 
 static DevIndex g_idx;
 DevIndex &dev_index() { return g_idx; }
-bool smem_use_lane()
-{
-	// default: the quad kernel (27 ms per 667 k reads on the 3.1 Gbp index).  MPIBWA_SMEM=lane selects the lane-per-read
-	// variant: half the VALU work, but its HBM-resident lists and 4 x 16-B block loads cost 2.4x the L2 misses (33 ms).
-	const char *e = getenv("MPIBWA_SMEM");
-	return e && strcmp(e, "lane") == 0;
-}
-
 void *DevBuf::ensure(size_t bytes)
 {
 	if (bytes > cap) {
@@ -243,6 +235,7 @@ SmemParams smem_params(const mem_opt_t *opt)
 	sp.min_seed_len = opt->min_seed_len;
 	sp.split_len = (int)(opt->min_seed_len * opt->split_factor + .499);   // src/bwamem.c:118
 	sp.split_width = opt->split_width;
+	if (opt->split_width < 0 || opt->split_width >= 65535) die("split_width %d: the seeding kernel packs re-seed requests into 16 bits", opt->split_width);
 	sp.max_mem_intv = (int)opt->max_mem_intv;
 	return sp;
 }
@@ -285,24 +278,22 @@ extern "C" int mi355x_smem_batch(const mem_opt_t *opt, int n, const uint8_t *seq
 	HIP_OK(hipMalloc(&d_off, (size_t)(n + 1) * 8));
 	HIP_OK(hipMalloc(&d_out, (size_t)n * cap * 32));
 	HIP_OK(hipMalloc(&d_nout, (size_t)n * 4));
-	HIP_OK(hipMalloc(&d_cnt, 64));
+	HIP_OK(hipMalloc(&d_cnt, 256));
 	size_t per_quad = 0;
-	const bool lane_k = smem_use_lane();
-	int n_quads = lane_k ? smem_lane_grid(max_len, &per_quad) : smem_grid_quads(max_len, &per_quad);
+	int n_quads = smem_grid_quads(max_len, &per_quad);
 	HIP_OK(hipMalloc(&d_scr, per_quad * n_quads));
 	HIP_OK(hipMemcpy(d_seq, packed.data(), packed.size(), hipMemcpyHostToDevice));
 	HIP_OK(hipMemcpy(d_off, poff.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
 	HIP_OK(hipMemcpy(d_len, lens.data(), (size_t)n * 4, hipMemcpyHostToDevice));
-	HIP_OK(hipMemset(d_cnt, 0, 64));
+	HIP_OK(hipMemset(d_cnt, 0, 256));
 	HIP_OK(hipMemset(d_nout, 0, (size_t)n * 4));
 	Timer tm;
 	tm.start(st);
-	if (lane_k) launch_smem_lane(st, g_idx.fm, smem_params(opt), n, d_seq, d_off, d_len, cap, d_out, d_nout, d_cnt, d_scr, per_quad, n_quads);
-	else launch_smem(st, g_idx.fm, smem_params(opt), n, d_seq, d_off, d_len, cap, d_out, d_nout, max_len, d_cnt, d_scr, per_quad, n_quads);
+	launch_smem(st, g_idx.fm, smem_params(opt), n, d_seq, d_off, d_len, cap, d_out, d_nout, max_len, d_cnt, d_scr, per_quad, n_quads);
 	double ms = tm.stop(st);
 	HIP_OK(hipGetLastError());
-	unsigned long long cnt[8];
-	HIP_OK(hipMemcpy(cnt, d_cnt, 64, hipMemcpyDeviceToHost));
+	unsigned long long cnt[32];
+	HIP_OK(hipMemcpy(cnt, d_cnt, 256, hipMemcpyDeviceToHost));
 	HIP_OK(hipMemcpy(n_out, d_nout, (size_t)n * 4, hipMemcpyDeviceToHost));
 	HIP_OK(hipMemcpy(intv_out, d_out, (size_t)n * cap * 32, hipMemcpyDeviceToHost));
 	(void)hipFree(d_seq); (void)hipFree(d_off); (void)hipFree(d_out); (void)hipFree(d_nout); (void)hipFree(d_cnt);

@@ -1,4 +1,6 @@
-// fm_kernels.hip — FM-index kernels for gfx950: SMEM seeding and suffix-array lookup.
+// fm_kernels.hip — FM-index kernels for gfx950 with a QUAD of lanes per task: SMEM seeding (passes 1 and 2 of
+// mem_collect_intv; the third pass is smem_p3_kernel in smem_kernels.hip), suffix-array lookup, dense-SA expansion,
+// the jump table of the third pass, seed enumeration.
 //
 // Replaces, on the device, the reference's
 //   mem_collect_intv          src/bwamem.c:114-162   (3-pass SMEM seeding)
@@ -18,7 +20,7 @@
 //    lookup table: no table traffic at all.
 //  * Every quad runs a small state machine whose loop body contains exactly
 //    one bwt_extend, so quads that are in different phases (forward sweep,
-//    backward sweep, re-seeding, LAST-like pass) or on reads of different
+//    backward sweep, re-seeding) or on reads of different
 //    length never serialise each other; a quad that finishes a read pulls the
 //    next one from a global counter (persistent grid, every wave exits when
 //    the counter runs past n_reads).
@@ -141,7 +143,7 @@ __device__ __forceinline__ void list_load(const QuadList &L, int e, u64 &x0, u64
 	end = v.w >> 16;
 }
 
-enum { ST_PICK = 0, ST_FWD = 1, ST_BWD = 2, ST_P3 = 3, ST_DONE = 4 };
+enum { ST_PICK = 0, ST_FWD = 1, ST_BWD = 2, ST_DONE = 4 };
 
 // QLDS: every read of the launch fits its quad's LDS slot, so a base is always a plain LDS byte (otherwise the
 // accessor needs a generic pointer and every base costs a flat load)
@@ -165,7 +167,7 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 
 	int st = ST_PICK, pass = 0;
 	int rd = 0, len = 0, x = 0, i = 0, j = 0, np = 0, nc = 0, top = 0, min_intv = 1, ret = 0, last_start = -1;
-	int nout = 0, k2 = 0, old_n = 0, cb = -1, last_push_end = 0;
+	int nout = 0, k2 = 0, old_n = 0, cb = -1, last_push_end = 0, p3_first = 0;
 	const uint8_t *gq = seq;
 	bool q_lds = false;
 	// read base i: from the quad's LDS copy when the read fits, else from HBM
@@ -244,12 +246,15 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 					for (int k = c; k * 16 < len; k += 4) myread[k] = src[k];
 				}
 				myout = out + (size_t)r * cap * 4;
-				nout = 0; x = 0; overflow = false; nblk = 0;
+				nout = p3_first = nout_arr[r];          // the third pass (smem_p3_kernel, launched before) has written its intervals
+				overflow = nout > cap;
+				if (overflow) nout = p3_first = cap;
+				x = 0; nblk = 0;
 				pass = len < sp.min_seed_len ? 4 : 1;   // src/bwamem.c:260: shorter than a seed => no intervals
 			}
 			if (pass == 1) {
 				while (x < len && Q(x) > 3) ++x;
-				if (x >= len) { pass = 2; k2 = 0; old_n = nout < cap ? nout : cap; }
+				if (x >= len) { pass = 2; k2 = p3_first; old_n = nout < cap ? nout : cap; }   // re-seeding looks at the SMEMs of pass 1 only
 				else begin_smem(x, 1);
 			} else if (pass == 2) {
 				bool found = false;
@@ -262,36 +267,7 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 					found = true;
 					break;
 				}
-				if (!found) { pass = 3; x = 0; }
-			} else if (pass == 3) {
-				if (sp.max_mem_intv <= 0) pass = 4;
-				else {
-					while (x < len && Q(x) > 3) ++x;
-					if (x >= len) pass = 4;
-					else {
-						// The first min_seed_len - 1 extensions of bwt_seed_strategy1 can never emit (src/bwt.c:369: i - x >=
-						// min_len), so when the next p3_k + 1 bases are unambiguous their outcome comes from the jump table
-						// (same device function, evaluated once per k-mer at upload), blocks-touched count included.
-						bool jumped = false;
-						if (fm.p3tab && fm.p3_k < sp.min_seed_len && x + fm.p3_k < len) {
-							u32 idx = 0;
-							bool ok = true;
-							for (int t = 0; t <= fm.p3_k; ++t) { const int bt = Q(x + t); ok = ok && bt < 4; idx = idx << 2 | (u32)(bt & 3); }
-							if (ok) {
-								const u64 v = ((const u64 *)fm.p3tab)[(size_t)idx * 4 + c];   // lane c: dword pair c of the 32-byte entry
-								ik0 = __shfl(v, qlead | 0); ik1 = __shfl(v, qlead | 1); ik2 = __shfl(v, qlead | 2);
-								nblk += (u32)__shfl(v, qlead | 3);
-								i = x + fm.p3_k + 1; st = ST_P3;
-								jumped = true;
-							}
-						}
-						if (!jumped) {
-							int b = Q(x);
-							ik0 = fm.L2[b] + 1; ik2 = fm.L2[b + 1] - fm.L2[b]; ik1 = fm.L2[3 - b] + 1;
-							i = x + 1; st = ST_P3;
-						}
-					}
-				}
+				if (!found) pass = 4;
 			} else if (pass == 4) {   // read finished
 				if (c == 0) {
 					nout_arr[rd] = nout;
@@ -305,11 +281,6 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 		if (st == ST_FWD) {
 			if (i < len) qi = Q(i);
 			if (i == len || qi > 3) { push_fwd(); fwd_done(); }   // the backward sweep starts in the next iteration
-			else { need = true; back = false; }
-		} else if (st == ST_P3) {
-			if (i < len) qi = Q(i);
-			if (i == len) { x = len; st = ST_PICK; }
-			else if (qi > 3) { x = i + 1; st = ST_PICK; }
 			else { need = true; back = false; }
 		}
 		if (__ballot(st != ST_DONE) == 0) break;
@@ -325,7 +296,7 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 					if (s2 < (u64)min_intv) { fwd_done(); stop = true; }
 				}
 				if (!stop) { ik0 = s0; ik1 = s1; ik2 = s2; ik_end = i + 1; ++i; }
-			} else if (st == ST_BWD) {
+			} else {   // ST_BWD
 				if (s2 < (u64)min_intv) {
 					if (nc == 0 && (last_start < 0 || i + 1 < last_start)) {
 						emit(p0, p1, p2, i + 1, (int)p_end);
@@ -336,11 +307,6 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 					++nc; lastc_x2 = s2;
 				}
 				++j;
-			} else { // ST_P3
-				if (s2 < (u64)sp.max_mem_intv && i - x >= sp.min_seed_len) {
-					if (s2 > 0) emit(s0, s1, s2, x, i + 1);
-					x = i + 1; st = ST_PICK;
-				} else { ik0 = s0; ik1 = s1; ik2 = s2; ++i; }
 			}
 		}
 	}
@@ -393,6 +359,8 @@ void launch_smem(void *stream, const FmDev &fm, const SmemParams &sp, int n_read
                  const int64_t *d_off, const int *d_len, int cap, uint64_t *d_out, int *d_nout, int max_len,
                  unsigned long long *d_counters, void *d_scratch, size_t scratch_bytes_per_quad, int n_quads)
 {
+	// the third pass depends on the read only: its own launch, first (it writes the interval counts the kernel below appends to)
+	launch_smem_p3(stream, fm, sp, n_reads, d_seq, d_off, d_len, cap, d_out, d_nout, d_counters);
 	int n_blocks = n_quads / (SMEM_BLOCK / 4);
 	int want = (n_reads + SMEM_BLOCK / 4 - 1) / (SMEM_BLOCK / 4);
 	if (want < 1) want = 1;

@@ -448,8 +448,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		int cap = std::max(64, std::min(max_len, 96));
 		uint64_t *d_intv; int *d_nintv;
 		size_t per_quad = 0;
-		const bool lane_k = smem_use_lane();
-		int n_quads = lane_k ? smem_lane_grid(max_len, &per_quad) : smem_grid_quads(max_len, &per_quad);
+		int n_quads = smem_grid_quads(max_len, &per_quad);
 		void *d_scr = W.scratch.ensure(per_quad * n_quads);
 		int *d_nseeds = (int *)W.nseeds.ensure((size_t)n * 4), *d_lrep = (int *)W.lrep.ensure((size_t)n * 4);
 		int *nseeds = (int *)W.h_nseeds.ensure((size_t)n * 4 + 8), *lrep = (int *)W.h_lrep.ensure((size_t)n * 4 + 8);
@@ -462,8 +461,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			// after the other staggers the sub-batches so that the host stages of one fall under the kernels of the other
 			std::unique_lock<std::mutex> turn(g_smem_turn);
 			ev_smem.start(st);
-			if (lane_k) launch_smem_lane(st, ix.fm, smem_params(opt), n, d_seq, d_off_r, d_len_r, cap, d_intv, d_nintv, d_cnt, d_scr, per_quad, n_quads);
-			else launch_smem(st, ix.fm, smem_params(opt), n, d_seq, d_off_r, d_len_r, cap, d_intv, d_nintv, max_len, d_cnt, d_scr, per_quad, n_quads);
+			launch_smem(st, ix.fm, smem_params(opt), n, d_seq, d_off_r, d_len_r, cap, d_intv, d_nintv, max_len, d_cnt, d_scr, per_quad, n_quads);
 			ev_smem.stop(st);
 			// seed bookkeeping queued right behind it (src/bwamem.c:265-283): one host round trip for both
 			launch_seed_prep(st, n, cap, d_intv, d_nintv, opt->max_occ, d_nseeds, d_lrep);

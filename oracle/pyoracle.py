@@ -232,3 +232,84 @@ class RefIndex:
         batch = abi.SeqBatch(libc, reads, with_qual=with_qual, comment=comment)
         self.lib.mem_process_seqs(opt, self.bwt, self.bns, self.pac, n_processed, batch.n, batch.arr, pes0)
         return batch.take_sam()
+
+    def gen_cigar2(self, opt, l_pac, pac, query, rb, re, w):
+        """The reference's bwa_gen_cigar2 (src/bwa.c:121-207) on a window of a packed reference: (score, cigar u32[], NM, MD bytes);
+        cigar is None when the reference rejects the request."""
+        o = opt.contents
+        q = np.ascontiguousarray(query, dtype=np.uint8).copy()
+        pac = np.ascontiguousarray(pac, dtype=np.uint8)
+        mat = (C.c_int8 * 25)(*o.mat)
+        f = self.lib.bwa_gen_cigar2
+        f.restype = C.c_void_p
+        f.argtypes = [C.c_void_p] + [C.c_int] * 5 + [C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64] + [C.POINTER(C.c_int)] * 3
+        sc, n, nm = C.c_int(0), C.c_int(0), C.c_int(0)
+        p = f(mat, o.o_del, o.e_del, o.o_ins, o.e_ins, int(w), int(l_pac), pac.ctypes.data, len(q), q.ctypes.data, int(rb), int(re),
+              C.byref(sc), C.byref(n), C.byref(nm))
+        if not p:
+            return sc.value, None, nm.value, b""
+        cig = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(n.value,)).copy()
+        md = C.string_at(p + 4 * n.value)
+        libc.free(C.c_void_p(p))
+        return sc.value, cig, nm.value, md
+
+    def reg2aln_loop(self, opt, l_pac, pac, query, rb, re, w2, truesc):
+        """mem_reg2aln's band-doubling loop (src/bwamem.c:1110-1120) around the reference's bwa_gen_cigar2: the result of its
+        last round."""
+        o = opt.contents
+        last, i = -(1 << 30), 0
+        while True:
+            w2 = min(w2, o.w << 2)
+            res = self.gen_cigar2(opt, l_pac, pac, query, rb, re, w2)
+            score = res[0]
+            if score == last or w2 == o.w << 2:
+                break
+            last = score
+            w2 <<= 1
+            i += 1
+            if not (i < 3 and score < truesc - o.a):
+                break
+        return res
+
+
+_inj = None
+
+
+def chain_inject_lib():
+    """oracle/_ref/libchaininj.so: the reference's mem_chain / mem_chain_flt fed with test-chosen seeds (oracle/chain_inject.c)"""
+    global _inj
+    if _inj is None:
+        ref_lib()
+        _inj = C.CDLL(os.path.join(HERE, "_ref", "libchaininj.so"))
+        _inj.inj_chain.restype = C.c_int64
+        _inj.inj_chain.argtypes = [C.POINTER(abi.mem_opt_t), C.POINTER(abi.bntseq_t), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                   C.c_void_p, C.c_int64]
+    return _inj
+
+
+def chain_inject_available():
+    return os.path.exists(os.path.join(HERE, "_ref", "libchaininj.so"))
+
+
+def ref_chains(opt, bns, read_len, intervals, do_flt=True):
+    """intervals: [(qbeg, qend, [rbeg, ...])] with distinct (qbeg, qend) -> the reference's chains after mem_chain (+ mem_chain_flt):
+    [(rid, w, kept, is_alt, frac_rep_bits, [(rbeg, qbeg, len), ...])]"""
+    lib = chain_inject_lib()
+    n = len(intervals)
+    iv = np.zeros((max(n, 1), 4), dtype=np.uint64)
+    sa = []
+    for k, (qb, qe, rbs) in enumerate(intervals):
+        iv[k] = (len(sa), 0, len(rbs), (qb << 32) | qe)
+        sa += list(rbs)
+    sa = np.array(sa if sa else [0], dtype=np.int64)
+    cap = 16 + 8 * n + 4 * len(sa) + 64
+    out = np.zeros(cap, dtype=np.int64)
+    got = lib.inj_chain(opt, bns, int(read_len), n, iv.ctypes.data, sa.ctypes.data, 1 if do_flt else 0, out.ctypes.data, cap)
+    assert got >= 0
+    p, res = 1, []
+    for _ in range(int(out[0])):
+        rid, ns, w, kept, is_alt, fb = (int(x) for x in out[p:p + 6])
+        p += 6
+        res.append((rid, w, kept, is_alt, fb, [tuple(int(x) for x in out[p + 3 * j:p + 3 * j + 3]) for j in range(ns)]))
+        p += 3 * ns
+    return res

@@ -261,3 +261,20 @@ def test_overlapping_seqs_in_flight_abort_with_a_message(genome, tmp_path):
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "SURVIVED" not in r.stdout
     assert "another call in flight" in r.stderr
+
+
+@needs_ref
+def test_pe_250bp_config4_shape(both, genome):
+    """BASELINE config 4's shape (2x250 bp PE): mate rescue takes its 16-bit flavour (250 * a >= 250, src/bwamem_pair.c:152),
+    the CIGAR kernel's direction-matrix budget scales with the read length, the seeding kernel its long-read LDS footprint.
+    2 400 pairs, default options and one variant, byte-identical to the reference."""
+    eng, ref = both
+    rd = simulate.reads_to_ascii(simulate.simulate_reads(genome["seqs"], 2400, 250, paired=True, seed=44, frag_mean=600.0, frag_sd=80.0,
+                                                         sub=0.012, indel=0.002))
+    _cmp(eng, ref, rd, dict(flag=abi.MEM_F_PE))
+    st = eng.stats()
+    assert st["n_msw"] > 0 and st["n_aln"] > 0
+    _cmp(eng, ref, rd[:1200], dict(flag=abi.MEM_F_PE | abi.MEM_F_NO_MULTI, w=60, T=40, pen_unpaired=9))
+    # config 3's shape next to it: single-end reads of 50..300 bp
+    se = simulate.reads_to_ascii(simulate.simulate_reads(genome["seqs"], 1500, 150, paired=False, seed=45, var_len=(50, 300)))
+    _cmp(eng, ref, se, dict(flag=0))

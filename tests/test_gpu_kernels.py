@@ -279,3 +279,137 @@ def test_chain_kernel_matches_host_chaining(engine, genome):
         n_dev += 1
         n_multi += len(h) >= 3
     assert n_dev > 2500 and n_declined > 100 and n_multi > 200
+
+
+@pytest.mark.skipif(not po.chain_inject_available(), reason="oracle/_ref/libchaininj.so not present")
+def test_chain_kernel_matches_the_reference_mem_chain(engine, genome):
+    """chain_kernel vs the reference's OWN mem_chain + mem_chain_flt (src/bwamem.c:251-385), which oracle/chain_inject.c
+    lets run on chosen seed sets: equal positions, equal weights, up to 9 chains, more than 9 chains / 64 seeds (the kernel
+    must decline those and the library's host path must get them right), both strands, contig-bridging seeds."""
+    rng = np.random.default_rng(78)
+    ref = po.RefIndex(genome["prefix"])
+    opt, ropt = engine.opt(), ref.opt()
+    l_pac = int(engine.bns.contents.l_pac)
+    n_seqs = int(engine.bns.contents.n_seqs)
+    offs = [int(engine.bns.contents.anns[k].offset) for k in range(n_seqs)] + [l_pac]
+    from chain_cases import adversarial_interval_sets, reference_chains
+    lens, seedsets, want = reference_chains(ref, ropt, adversarial_interval_sets(rng, 3000, l_pac, offs, n_seqs))
+    lrep = [0] * len(lens)
+    dev = engine.chains(opt, lens, lrep, seedsets, 0)
+    host = engine.chains(opt, lens, lrep, seedsets, 1)
+    n_dev = n_declined = n_multi = 0
+    for d, h, w, sd in zip(dev, host, want, seedsets):
+        hh = [(c[0], c[5], c[6]) for c in h]
+        assert hh == w, ("host path", sd, hh, w)
+        if d is None:
+            n_declined += 1
+            continue
+        dd = [(c[0], c[5], c[6]) for c in d]
+        assert dd == w, ("chain_kernel", sd, dd, w)
+        n_dev += 1
+        n_multi += len(w) >= 3
+    assert n_dev > 1800 and n_declined > 50 and n_multi > 150
+
+
+def _pack2bit(ref):
+    l_pac = len(ref)
+    pac = np.zeros(l_pac // 4 + 1, dtype=np.uint8)
+    for k in range(4):
+        part = ref[k::4]
+        pac[:len(part)] |= (part << ((3 - k) * 2)).astype(np.uint8)
+    return pac
+
+
+@pytest.mark.skipif(not po.ref_available(), reason="oracle/_ref/libbwaref.so not present")
+@pytest.mark.parametrize("which", [0, 1])
+def test_aln_kernel_matches_the_reference_gen_cigar2(engine, which):
+    """aln_kernel (all three instantiations: no-DP, narrow band with hand-off, full size) vs the reference's bwa_gen_cigar2
+    under mem_reg2aln's band-doubling loop (src/bwa.c:121-207, src/bwamem.c:1110-1120): score, NM, CIGAR, MD."""
+    rng = np.random.default_rng(31 + which)
+    l_pac = 60000
+    ref_seq = rng.integers(0, 4, size=l_pac).astype(np.uint8)
+    ref_seq[7000:7400] = np.tile(ref_seq[7000:7004], 100)        # tandem repeat: gap placement must match
+    pac = _pack2bit(ref_seq)
+    dbl = np.concatenate([ref_seq, 3 - ref_seq[::-1]]).astype(np.uint8)
+    ri = po.RefIndex.__new__(po.RefIndex)
+    ri.lib = po.ref_lib()
+    opt = engine.opt()
+    reads, rb, re, qb, qe, w2, truesc = [], [], [], [], [], [], []
+    for i in range(1500):
+        lq = int(rng.choice([30, 76, 100, 150, 151, 250]))
+        p = int(rng.integers(0, 2 * l_pac - 2 * lq - 80))
+        if p < l_pac < p + 2 * lq + 80:
+            p = l_pac + 5
+        kind = rng.random()
+        t = dbl[p:p + lq + 70].copy()
+        q = t[:lq].copy()
+        rl = lq
+        if kind < 0.35:
+            pass                                                      # same length: the no-DP shortcut when w2 == 0
+        elif kind < 0.7:                                              # one gap
+            g = int(rng.choice([1, 2, 3, 8, 20, 45]))
+            at = int(rng.integers(5, lq - 5))
+            if rng.random() < 0.5:
+                q = np.concatenate([t[:at], t[at + g:lq + g]])       # deletion from the read
+                rl = lq + g
+            else:
+                q = np.concatenate([t[:at], rng.integers(0, 4, size=g).astype(np.uint8), t[at:lq - g]])[:lq]
+                rl = lq - g
+        else:                                                         # two gaps of opposite sign
+            at1, at2 = sorted(int(x) for x in rng.integers(5, lq - 5, size=2))
+            g = int(rng.integers(1, 6))
+            q = np.concatenate([t[:at1], t[at1 + g:at2], rng.integers(0, 4, size=g).astype(np.uint8), t[at2:lq]])[:lq]
+        mm = rng.random(len(q)) < float(rng.choice([0, 0.01, 0.05]))
+        q[mm] = (q[mm] + 1) & 3
+        if rng.random() < 0.05:
+            q[int(rng.integers(0, len(q)))] = 4
+        b, e = 0, len(q)
+        if rng.random() < 0.3:                                        # a clipped region of the read
+            b = int(rng.integers(0, 10)); e = len(q) - int(rng.integers(0, 10))
+        reads.append(q); rb.append(p + b); re.append(p + b + max(rl - b - (len(q) - e), 1)); qb.append(b); qe.append(e)
+        w2.append(int(rng.choice([0, 0, 1, 3, 8, 15, 40, 100, 400])) if rl != lq or rng.random() < 0.5 else 0)
+        truesc.append(int(rng.choice([0, lq, lq - 10])))
+    hdr, cigs, mds, ms = engine.global_align(opt, l_pac, pac, reads, rb, re, np.arange(len(reads)), qb, qe, w2, truesc, which=which, cigar_cap=128, md_cap=800)
+    n_dp = n_declined = 0
+    for i in range(len(reads)):
+        sc, cig, nm, md = ri.reg2aln_loop(opt, l_pac, pac, reads[i][qb[i]:qe[i]], rb[i], re[i], w2[i], truesc[i])
+        if hdr[i, 4] != 0:     # band matrix beyond the LDS budget of the full-size instantiation: left to the library's host code
+            n_declined += 1
+            assert w2[i] >= 40 and qe[i] - qb[i] >= 140, (i, hdr[i], w2[i])
+            continue
+        assert cig is not None
+        assert (hdr[i, 0], hdr[i, 1]) == (sc, nm), (i, hdr[i], sc, nm, w2[i])
+        assert (cigs[i] == cig).all() and mds[i] == md, (i, cigs[i], cig, mds[i], md)
+        n_dp += len(cig) > 1
+    assert n_dp > 500 and n_declined < 120
+
+
+def test_aln_kernel_on_golden_ksw_global2_vectors(engine):
+    """The committed glo_* tuples (reference ksw_global2 outputs, src/ksw.c:504-606) through aln_kernel: the tuples whose band
+    equals what bwa_gen_cigar2 would choose for them (src/bwa.c:152-161) are reproduced exactly, score and CIGAR."""
+    from golden_util import kernel_vectors, ragged
+    kv = kernel_vectors()
+    qs, ts, ws, ss, cs = ragged(kv, "glo_q"), ragged(kv, "glo_t"), kv["glo_w"], kv["glo_s"], ragged(kv, "glo_c")
+    opt = engine.opt()
+    o = opt.contents
+    toff = np.zeros(len(ts) + 1, dtype=np.int64)
+    toff[1:] = np.cumsum([len(t) for t in ts])
+    genome = np.concatenate(ts).astype(np.uint8)
+    l_pac = len(genome)
+    pac = _pack2bit(genome)
+    sel = []
+    for i, (q, t, w) in enumerate(zip(qs, ts, ws)):
+        lq, d = len(q), abs(len(t) - len(q))
+        max_gap = max(int(((lq + 1) >> 1) * o.a - o.o_ins) // o.e_ins + 1, 1)
+        if lq == len(t) and w == 0:
+            continue
+        if ((max_gap + d + 1) >> 1) >= w >= d + 3 and w <= (o.w << 2):
+            sel.append(i)
+    assert len(sel) >= 40
+    for which in (0, 1):
+        hdr, cigs, mds, ms = engine.global_align(opt, l_pac, pac, [qs[i] for i in sel], [toff[i] for i in sel], [toff[i + 1] for i in sel],
+                                                 np.arange(len(sel)), [0] * len(sel), [len(qs[i]) for i in sel], [int(ws[i]) for i in sel],
+                                                 [-(1 << 20)] * len(sel), which=which)
+        for k, i in enumerate(sel):
+            assert hdr[k, 4] == 0 and hdr[k, 0] == ss[i], (i, hdr[k], ss[i])
+            assert (cigs[k] == cs[i]).all(), (i, cigs[k], cs[i])
