@@ -61,6 +61,9 @@ def test_set_rg_and_insert_header_match_the_reference(built):
         got = [(take(lib.bwa_set_rg(s)), bytes((C.c_char * 256).in_dll(lib, "bwa_rg_id"))) for lib in (ours, ref)]
         assert got[0] == got[1], s
     assert any(g is not None for g in [take(ours.bwa_set_rg(s)) for s in RG_CASES[:3]])
+    for lib in (ours, ref):      # leave no read group behind: both libraries would tag every later record with it
+        take(lib.bwa_set_rg(b"none"))
+        assert bytes((C.c_char * 256).in_dll(lib, "bwa_rg_id")) == bytes(256)
     po.libc.strdup = po.libc.strdup
     po.libc.strdup.restype = C.c_void_p
     po.libc.strdup.argtypes = [C.c_char_p]
