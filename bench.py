@@ -32,6 +32,15 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def kernel_sources_sha256(root):
+    """what tools/pmc_smem.sh records next to its FETCH_SIZE figures: the seeding kernels' sources"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("fm_kernels.hip", "smem_kernels.hip"):
+        h.update(open(os.path.join(root, "mpibwa_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -44,7 +53,11 @@ def main():
                     help="pairs given to the reference for the CPU baseline and the parity check (0 = the whole step batch)")
     ap.add_argument("--read-len", type=int, default=int(os.environ.get("MPIBWA_BENCH_READ_LEN", "150")),
                     help="read length (150 = the headline config; 250 = BASELINE config 4's shape, a parity case)")
-    ap.add_argument("--seed", type=int, default=1000, help="seed of the read simulator (rank r uses seed + r)")
+    ap.add_argument("--seed", type=int, default=1000, help="seed of the read simulator (rank r, chunk c use seed + 16 r + c)")
+    ap.add_argument("--chunks", type=int, default=int(os.environ.get("MPIBWA_BENCH_CHUNKS", "3")),
+                    help="distinct chunks per rank the steps cycle through (config 1: 1 M pairs = 3 chunks of 333 334)")
+    ap.add_argument("--repeat-frac", type=float, default=float(os.environ.get("MPIBWA_BENCH_REPEAT_FRAC", "0.05")),
+                    help="share of the synthetic genome covered by planted repeat families (real GRCh38 is ~0.5: see README)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--in-flight", type=int, default=int(os.environ.get("MPIBWA_BENCH_IN_FLIGHT", "4")),
                     help="caller threads inside mem_process_seqs at once (the library runs up to four calls side by side: "
@@ -80,19 +93,24 @@ def main():
     os.makedirs(args.workdir, exist_ok=True)
     t0 = time.time()
     idx = bigindex.make_or_get(args.workdir, genome_mbp=args.genome_mbp, seed=38, rank=rank, world=world,
-                               local_rank=dev, dist=dist if world > 1 else None, log=log if rank == 0 else None)
+                               local_rank=dev, dist=dist if world > 1 else None, log=log if rank == 0 else None,
+                               repeat_frac=args.repeat_frac)
     eng = idx.engine
     if rank == 0:
         log("index ready in %.1f s: l_pac=%d, occ blocks %.2f GB, SA %.2f GB" %
             (time.time() - t0, idx.l_pac, idx.blk_bytes / 1e9, idx.sa_bytes / 1e9))
 
-    # ---- reads: seeded per rank, same generator as the tests (2 % unmappable, 1 % subst., 0.1 % indel) ----
-    reads = idx.simulate_pairs(args.pairs, seed=args.seed + rank, read_len=args.read_len, frag_mean=max(400.0, 2.2 * args.read_len))
+    # ---- reads: seeded per rank and chunk, same generator as the tests (2 % unmappable, 1 % subst., 0.1 % indel) ----
+    # Config 1 is 1 M pairs: `--chunks` distinct chunks of `--pairs` pairs; step s aligns chunk s mod n_chunks, so the
+    # arenas, branch histories and cached index blocks of consecutive steps differ as they do in a real run.
+    n_chunks = max(1, args.chunks)
+    chunk_reads = [idx.simulate_pairs(args.pairs, seed=args.seed + 16 * rank + c, read_len=args.read_len, frag_mean=max(400.0, 2.2 * args.read_len))
+                   for c in range(n_chunks)]
     import hashlib
     import threading
     n_fly = max(1, min(args.in_flight, 4))
-    batches = [abi.SeqBatch(api.libc, reads) for _ in range(n_fly)]   # every caller thread owns its bseq1_t[] (and its .sam)
-    batch = batches[0]
+    # every caller thread owns a bseq1_t[] (and its .sam) per chunk
+    batches = [[abi.SeqBatch(api.libc, chunk_reads[c]) for c in range(n_chunks)] for _ in range(n_fly)]
     cores = int(lib.mi355x_host_cpus())
     opt = eng.opt(flag=abi.MEM_F_PE, n_threads=cores)
     lib_verbose = C.c_int.in_dll(eng.lib, "bwa_verbose")
@@ -101,47 +119,65 @@ def main():
     pending = []   # (thread, seqs[i].sam pointers) of finished steps; the caller (mpiBWA's writer thread, src/mainParallel.c:103-127) owns them
     lock = threading.Lock()
 
-    def run_steps(k_steps, acc):
-        """Exactly k_steps calls of mem_process_seqs, at most n_fly of them in flight."""
-        todo = iter(range(k_steps))
+    step_no = [0]   # steps handed out so far (all phases): step s aligns chunk s mod n_chunks
+
+    def run_steps(k_steps, acc, fly=None):
+        """Exactly k_steps calls of mem_process_seqs, at most `fly` (default n_fly) of them in flight."""
+        fly = n_fly if fly is None else fly
+        first = step_no[0]
+        step_no[0] += k_steps
+        todo = iter(range(first, first + k_steps))
 
         def worker(t):
             torch.cuda.set_device(dev)
             while True:
                 with lock:
-                    if next(todo, None) is None:
+                    s_ = next(todo, None)
+                    if s_ is None:
                         return
-                eng.process_batch(opt, batches[t])
+                c = s_ % n_chunks
+                b = batches[t][c]   # (its .sam pointers of an earlier, undrained step were copied into `pending`)
+                eng.process_batch(opt, b)
                 st = eng.stats()                                          # this thread's last call
                 with lock:
-                    pending.append((t, batches[t]._rec["sam"].copy()))    # hand the output over, one pointer per read
+                    pending.append((t, c, b._rec["sam"].copy()))          # hand the output over, one pointer per read
                     for k, v in st.items():
                         acc[k] = acc.get(k, 0) + v
 
-        th = [threading.Thread(target=worker, args=(t,)) for t in range(1, n_fly)]
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(1, fly)]
         for x in th:
             x.start()
         worker(0)
         for x in th:
             x.join()
 
-    digests = set()
+    digests = [set() for _ in range(n_chunks)]   # md5 of every step's SAM, per chunk
+    sam_bytes_seen = [0]
+    dg_lock = threading.Lock()
+
+    def collect_one(entry):
+        # concatenate + free one step's SAM strings, as mpiBWA's copy_buffer_thr does
+        t, c, ptrs = entry
+        b = batches[t][c]
+        b._rec["sam"][:] = ptrs
+        n = C.c_size_t(0)
+        p = lib.mi355x_collect_sam(b.arr, b.n, C.byref(n))
+        d = hashlib.md5(C.string_at(p, n.value)).hexdigest()
+        api.libc.free(C.c_void_p(p))
+        b._rec["sam"][:] = 0
+        with dg_lock:
+            digests[c].add(d)
+            sam_bytes_seen[0] += n.value
 
     def drain():
-        # concatenate + free every step's SAM strings, as mpiBWA's copy_buffer_thr does — outside the timed region,
-        # where the reference's writer thread runs concurrently with the next chunk
-        tot = 0
-        for t, ptrs in pending:
-            batches[t]._rec["sam"][:] = ptrs
-            n = C.c_size_t(0)
-            p = lib.mi355x_collect_sam(batches[t].arr, batches[t].n, C.byref(n))
-            tot += n.value
-            digests.add(hashlib.md5(C.string_at(p, n.value)).hexdigest())
-            api.libc.free(C.c_void_p(p))
+        # outside the timed region, where the reference's writer thread runs concurrently with the next chunk
+        before = sam_bytes_seen[0]
+        for e in list(pending):
+            collect_one(e)
         pending.clear()
-        return tot
+        return sam_bytes_seen[0] - before
 
-    run_steps(args.warmup * n_fly, {})   # every in-flight slot warms its own workspaces
+    run_steps(max(args.warmup, 1) * max(n_fly, n_chunks), {})   # every in-flight slot warms its own workspaces on every chunk
     drain()
     if world > 1:
         dist.barrier()
@@ -156,10 +192,13 @@ def main():
     elapsed = time.perf_counter() - t0
     host_cpu_s = time.process_time() - c0
     sam_bytes = drain()
-    # one more call with nothing else in flight, outside the timed region: the kernels' durations when they have the GPU
-    # to themselves (inside the timed region a launch shares the chip with the kernels of the other calls)
+    # the latency mode next to it, outside the timed region: one call in flight, every chunk once (the kernels' durations when
+    # they have the GPU to themselves; inside the timed region a launch shares the chip with the kernels of the other calls)
     alone = {}
-    run_steps(1, alone)
+    ta = time.perf_counter()
+    run_steps(n_chunks, alone, fly=1)
+    torch.cuda.synchronize()
+    alone_s = time.perf_counter() - ta
     drain()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -173,19 +212,29 @@ def main():
     # totals over the timed region divided by the number of launches (HIP events on the launching streams, pipeline.hip).
     ach = acc["smem_bytes"] / (acc["k_smem_ms"] * 1e-3) / 1e9 if acc.get("k_smem_ms") else 0.0
     n_launch = max(1, int(acc.get("n_sub", args.steps)))
-    # HBM traffic per launch: PMC counters cannot be collected inside this run, so the per-read figure measured by
-    # tools/pmc_smem.sh on this workload (profiles/r01_pmc_smem.json) is scaled to the reads of one launch
-    traffic = None
+    # HBM traffic per launch: PMC counters cannot be collected inside this run (rocprofv3 has to wrap the process), so the
+    # per-read figure measured by tools/pmc_smem.sh on this workload is scaled to the reads of one launch — but only while
+    # the summary under profiles/ was taken from the kernel sources as they are now (it records their sha256); otherwise null.
+    traffic, traffic_src = None, None
     try:
-        pj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_smem.json")))
-        if args.genome_mbp >= 3000:
+        here = os.path.dirname(os.path.abspath(__file__))
+        pj = json.load(open(os.path.join(here, "profiles", "r02_pmc_smem.json")))
+        now = kernel_sources_sha256(here)
+        if pj.get("kernel_sources_sha256") != now:
+            log("WARNING: profiles/r02_pmc_smem.json was measured on other kernel sources (%s..., now %s...): roofline.traffic = null; "
+                "re-run tools/pmc_smem.sh" % (str(pj.get("kernel_sources_sha256"))[:12], now[:12]))
+        elif args.genome_mbp >= 3000 and args.read_len == 150:
             traffic = int(pj["smem_kernel"]["traffic_bytes_per_read"] * 2 * args.pairs * args.steps / n_launch)
-    except Exception:
-        traffic = None
-    roofline = {"kernel": "smem_kernel", "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(ach / 8000.0, 4), "traffic": traffic,
+            traffic_src = "profiles/r02_pmc_smem.json (FETCH_SIZE pass of the same workload, per read) x reads per launch"
+    except Exception as e:
+        log("WARNING: no usable PMC summary for roofline.traffic: %r" % (e,))
+    tab = acc.get("smem_tab_bytes", 0)
+    roofline = {"kernel": "smem_kernel + smem_p3_kernel (one seeding launch = both)", "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0,
+                "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "launch_ms": round(acc["k_smem_ms"] / n_launch, 3), "algo_bytes_per_launch": int(acc["smem_bytes"] / n_launch),
-                "launches_per_step": round(n_launch / args.steps, 2)}
+                "launches_per_step": round(n_launch / args.steps, 2),
+                # the same with the occ blocks left out that the third pass takes from its jump table instead of fetching
+                "frac_without_jump_table_blocks": round((acc["smem_bytes"] - tab) / (acc["k_smem_ms"] * 1e-3) / 1e9 / 8000.0, 4) if acc.get("k_smem_ms") else None}
     if alone.get("k_smem_ms") and alone.get("n_sub"):
         a1 = alone["smem_bytes"] / (alone["k_smem_ms"] * 1e-3) / 1e9
         roofline["one_call_in_flight"] = {"launch_ms": round(alone["k_smem_ms"] / alone["n_sub"], 3), "achieved": round(a1, 1),
@@ -196,11 +245,14 @@ def main():
         "value": round(value, 4), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-        "config": {"workload": "2x%d bp PE reads vs seeded synthetic %.0f Mbp reference (GRCh38 absent on the box)" % (args.read_len, idx.l_pac / 1e6),
-                   "pairs_per_step_per_gpu": args.pairs, "reference_mbp": round(idx.l_pac / 1e6, 1),
+        "config": {"workload": "%d x %d pairs of 2x%d bp PE reads per GPU vs seeded synthetic %.0f Mbp reference (GRCh38 absent on the box; "
+                               "uniform base composition, %.0f %% of it in planted repeat families)" % (n_chunks, args.pairs, args.read_len, idx.l_pac / 1e6, 100 * args.repeat_frac),
+                   "pairs_per_step_per_gpu": args.pairs, "distinct_chunks": n_chunks, "reference_mbp": round(idx.l_pac / 1e6, 1),
                    "chunking": "one mem_process_seqs chunk per step (mpiBWA -K 1e8 semantics)", "parallelism": "reads sharded, 1 rank/GPU",
                    "calls_in_flight": n_fly},
         "sam_bytes_per_step": int(sam_bytes / args.steps),
+        "one_call_in_flight": {"value": round(2 * args.pairs * n_chunks * world / alone_s / 1e6, 4), "unit": "Mreads/s",
+                               "ms_per_step": round(alone_s / n_chunks * 1e3, 2), "steps": n_chunks},
         "host_cpu_s_per_step": round(host_cpu_s / args.steps, 3), "host_cpu_busy_frac": round(host_cpu_s / (elapsed * max(cores, 1)), 3),
         "roofline": roofline,
         "stage_ms_per_step": {k: round(acc[k] / args.steps, 2) for k in
@@ -210,26 +262,35 @@ def main():
             "c2a_kernel_GCUPS": round(acc["ext_cells"] / (acc["k_ext_ms"] * 1e-3) / 1e9, 2) if acc.get("k_ext_ms") else None},
     }
 
-    # ---- CPU baseline: the reference itself on this box's host cores, bounded sample, rank 0 at N=1 only ----
+    # ---- CPU baseline + parity: the reference itself on this box's host cores, every chunk once, rank 0 at N=1 only ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             from oracle import pyoracle as po
             if po.ref_available():
-                sample = reads[:min(args.cpu_sample_pairs or len(reads), len(reads))]
                 ref = po.RefIndex(idx.prefix)
                 C.c_int.in_dll(ref.lib, "bwa_verbose").value = 1
                 ropt = ref.opt(flag=abi.MEM_F_PE, n_threads=cores)
-                rb = abi.SeqBatch(po.libc, sample)
-                t0 = time.perf_counter()
-                ref.lib.mem_process_seqs(ropt, ref.bwt, ref.bns, ref.pac, 0, rb.n, rb.arr, None)
-                dt = time.perf_counter() - t0
-                want = rb.take_sam()
-                got = eng.process(opt, sample)
-                out["cpu_baseline"] = {"value": round(rb.n / dt / 1e6, 5), "unit": "Mreads/s", "cores": cores, "kind": "reference",
-                                       "sample": "%d pairs of the same reads, one chunk, reference mem_process_seqs -t %d (%.1f s)" % (len(sample), cores, dt)}
-                out["parity_on_sample"] = bool(got == want)
-                if len(sample) == len(reads):   # every step of the run (warm-up included) produced exactly this SAM
-                    out["all_steps_identical_to_checked_sam"] = bool(digests == {hashlib.md5(b"".join(got)).hexdigest()})
+                n_ref, t_ref, ok, same = 0, 0.0, True, True
+                for c in range(n_chunks):
+                    sample = chunk_reads[c][:min(args.cpu_sample_pairs or len(chunk_reads[c]), len(chunk_reads[c]))]
+                    rb = abi.SeqBatch(po.libc, sample)
+                    t0 = time.perf_counter()
+                    ref.lib.mem_process_seqs(ropt, ref.bwt, ref.bns, ref.pac, 0, rb.n, rb.arr, None)
+                    t_ref += time.perf_counter() - t0
+                    n_ref += rb.n
+                    want = rb.take_sam()
+                    got = eng.process(opt, sample)
+                    ok = ok and got == want
+                    if len(sample) == len(chunk_reads[c]):   # every step on this chunk (warm-up included) produced exactly this SAM
+                        same = same and digests[c] == {hashlib.md5(b"".join(want)).hexdigest()}
+                    else:
+                        same = None
+                out["cpu_baseline"] = {"value": round(n_ref / t_ref / 1e6, 5), "unit": "Mreads/s", "cores": cores, "kind": "reference",
+                                       "sample": "the %d chunks of the run (%d reads), one reference mem_process_seqs -t %d call each (%.1f s in all)" %
+                                                 (n_chunks, n_ref, cores, t_ref)}
+                out["parity_on_sample"] = bool(ok)
+                if same is not None:
+                    out["all_steps_identical_to_checked_sam"] = bool(same)
             else:
                 out["cpu_baseline"] = None
         except Exception as e:  # the baseline must never take the bench line down

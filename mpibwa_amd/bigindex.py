@@ -135,24 +135,42 @@ class BigIndex:
         return reads
 
 
-def make_or_get(workdir, genome_mbp=3100.0, seed=38, rank=0, world=1, local_rank=0, dist=None, log=None):
+def _load_packed_genome(prefix):
+    """The packed genome and contig lengths back from the node-local files rank 0 wrote (.pac mapped, not copied)."""
+    with open(prefix + ".ann") as f:
+        l_pac, n_seqs, _ = f.readline().split()
+        lens = []
+        for _ in range(int(n_seqs)):
+            f.readline()
+            lens.append(int(f.readline().split()[1]))
+    lens = np.array(lens, dtype=np.int64)
+    assert int(l_pac) == int(lens.sum())
+    pac = np.memmap(prefix + ".pac", dtype=np.uint8, mode="r")[:int(l_pac) // 4 + 1]
+    return pac, lens
+
+
+def make_or_get(workdir, genome_mbp=3100.0, seed=38, rank=0, world=1, local_rank=0, dist=None, log=None, repeat_frac=0.05):
     lib = api.load_library()
     lib.mi355x_index_build_gpu.restype = C.c_int
     lib.mi355x_index_build_gpu.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_char_p, C.POINTER(C.c_double)]
-    prefix = os.path.join(workdir, "synth_%dM_s%d_b%d.fa" % (int(genome_mbp), seed, BUILDER_VERSION))
-    t0 = time.time()
-    pac, lens = synth_packed_genome(genome_mbp * 1e6, seed=seed)   # every rank regenerates the same packed genome (host stages need it)
-    if log:
-        log("synthetic genome: %.1f Mbp in %d contigs, generated in %.1f s" % (lens.sum() / 1e6, len(lens), time.time() - t0))
+    tag = "" if repeat_frac == 0.05 else "_r%d" % int(round(repeat_frac * 100))
+    prefix = os.path.join(workdir, "synth_%dM_s%d%s_b%d.fa" % (int(genome_mbp), seed, tag, BUILDER_VERSION))
+    # the genome is generated ONCE per node: rank 0 writes it (with the index), every rank maps .pac from the node-local file
     if rank == 0 and not os.path.exists(prefix + ".ok"):
+        t0 = time.time()
+        pac, lens = synth_packed_genome(genome_mbp * 1e6, seed=seed, repeat_frac=repeat_frac)
+        if log:
+            log("synthetic genome: %.1f Mbp in %d contigs, generated in %.1f s" % (lens.sum() / 1e6, len(lens), time.time() - t0))
         write_meta_files(prefix, pac, lens)
         secs = C.c_double(0)
         lib.mi355x_index_build_gpu(local_rank, pac.ctypes.data, int(lens.sum()), prefix.encode(), C.byref(secs))
         open(prefix + ".ok", "w").write("built in %.1f s\n" % secs.value)   # only a completed build is ever reused
         if log:
             log("FM-index built on the GPU in %.1f s" % secs.value)
+        del pac
     if dist is not None:
         dist.barrier()
+    pac, lens = _load_packed_genome(prefix)
     # one rank per GPU.  Every rank maps the host side of the index from the node-local files (the host stages need pac
     # and the contig table); the device side is uploaded once by rank 0 and broadcast to the other GPUs over RCCL/xGMI.
     eng = api.Engine(prefix, device=local_rank, dist=dist, rank=rank)

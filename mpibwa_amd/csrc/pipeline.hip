@@ -402,7 +402,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	std::vector<uint64_t> pes_hist_v;
 	if (pe && !pes0 && pestat_can_count(opt)) pes_hist_v.assign(4 * ((size_t)opt->max_ins + 1), 0);
 	uint64_t *pes_hist = pes_hist_v.empty() ? nullptr : pes_hist_v.data();
-	struct P1 { double k_smem = 0, k_sa = 0, k_ext = 0, smem = 0, sa = 0, chain = 0, ext = 0, regs = 0; uint64_t smem_bytes = 0, sa_bytes = 0, cells = 0, n_ext = 0, n_intv = 0, n_seeds = 0, n_chains = 0; };
+	struct P1 { double k_smem = 0, k_sa = 0, k_ext = 0, smem = 0, sa = 0, chain = 0, ext = 0, regs = 0; uint64_t smem_bytes = 0, smem_tab_bytes = 0, sa_bytes = 0, cells = 0, n_ext = 0, n_intv = 0, n_seeds = 0, n_chains = 0; };
 	const int n_all = n;
 	auto phase1 = [&](int lo, int hi, Workspace &W, HostBuf &reg_arena, hipStream_t st, int n_thr, P1 &ps) {
 		const int n = hi - lo;
@@ -477,6 +477,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			cap *= 4;
 		}
 		ps.smem_bytes = cnt[1] * 64 + range_bases;
+		ps.smem_tab_bytes = cnt[4] * 64;
 		double t2 = now_ms();
 
 		// seed enumeration + SA lookup (+ chaining on the device)
@@ -793,7 +794,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	}
 	for (int k = 0; k < n_sub; ++k) {
 		STAT.k_smem_ms += ps[k].k_smem; STAT.k_sa_ms += ps[k].k_sa; STAT.k_ext_ms += ps[k].k_ext;
-		STAT.smem_bytes += ps[k].smem_bytes; STAT.sa_bytes += ps[k].sa_bytes; STAT.ext_cells += ps[k].cells; STAT.n_ext += ps[k].n_ext;
+		STAT.smem_bytes += ps[k].smem_bytes; STAT.smem_tab_bytes += ps[k].smem_tab_bytes; STAT.sa_bytes += ps[k].sa_bytes; STAT.ext_cells += ps[k].cells; STAT.n_ext += ps[k].n_ext;
 		STAT.n_intv += ps[k].n_intv; STAT.n_seeds += ps[k].n_seeds; STAT.n_chains += ps[k].n_chains;
 		// per-stage wall times: the sub-batches of a lane run back to back and the lanes side by side, so sum / lanes
 		STAT.smem_ms += ps[k].smem / n_lanes; STAT.sa_ms += ps[k].sa / n_lanes;

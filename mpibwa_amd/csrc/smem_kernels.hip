@@ -146,7 +146,7 @@ smem_p3_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__
 	u64 ik0 = 0, ik1 = 0, ik2 = 0;
 	u64 *myout = out;
 	const uint8_t *rbase = seq;
-	u32 nblk = 0;
+	u32 nblk = 0, nblk_tab = 0;   // occ blocks of this read's extensions; the part of them that the jump table stood in for
 	bool overflow = false, need = false;
 	ReadWin W;
 	W.reset();
@@ -179,7 +179,7 @@ smem_p3_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__
 		if (wq >= 0) { W.put(wq, wv, wkeep); wq = -1; }
 		if (mq) { nx_len = m_len; nx_off = m_off; mq = false; }
 		if (tq) {   // state after the first p3_k extensions of the k-mer at x, blocks-touched count included
-			ik0 = ta.x; ik1 = ta.y; ik2 = tb.x; nblk += (u32)tb.y;
+			ik0 = ta.x; ik1 = ta.y; ik2 = tb.x; nblk += (u32)tb.y; nblk_tab += (u32)tb.y;
 			i = x + fm.p3_k + 1; st = P_EXT; tq = false;
 		}
 		if (need) {
@@ -203,7 +203,7 @@ smem_p3_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__
 			else {
 				rd = r_next; len = nx_len; rbase = seq + nx_off;
 				myout = out + (size_t)rd * cap * 4;
-				nout = 0; x = 0; nblk = 0; overflow = false;
+				nout = 0; x = 0; nblk = 0; nblk_tab = 0; overflow = false;
 				W.reset();
 				if (len < sp.min_seed_len || sp.max_mem_intv <= 0) x = len;   // src/bwamem.c:260, :148
 				st = P_SKIP;
@@ -221,6 +221,7 @@ smem_p3_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__
 				if (x >= len) {   // the read is finished
 					nout_arr[rd] = nout;
 					if (nblk) atomicAdd(&counters[1], (u64)nblk);
+					if (nblk_tab) atomicAdd(&counters[4], (u64)nblk_tab);
 					if (overflow) atomicAdd(&counters[2], 1ull);
 					st = P_PICK;
 				} else if (use_tab && x + fm.p3_k < len) { st = P_KMER; t = 0; idx = 0; }
@@ -259,7 +260,7 @@ smem_p3_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__
 }
 
 // ---- launch ----------------------------------------------------------------------------------------------------------
-// counters[3] = next read must be zero; adds the occ blocks to counters[1] and overflowing reads to counters[2]
+// adds the occ blocks of the pass to counters[1] (those the jump table stood in for also to counters[4]) and overflowing reads to counters[2]
 void launch_smem_p3(void *stream, const FmDev &fm, const SmemParams &sp, int n_reads, const uint8_t *d_seq, const int64_t *d_off,
                     const int *d_len, int cap, uint64_t *d_out, int *d_nout, unsigned long long *d_counters)
 {
