@@ -18,7 +18,7 @@ EXPORTS = [
     "mi355x_index_upload", "mi355x_index_alloc", "mi355x_index_buffers", "mi355x_index_d2d", "mi355x_index_commit",
     "mi355x_finalize", "mi355x_index_build", "mi355x_index_build_gpu",
     "mi355x_smem_batch", "mi355x_sa_batch", "mi355x_sa_batch2", "mi355x_sa_dense_info", "mi355x_extend_batch", "mi355x_matesw_batch", "mi355x_chain_batch", "mi355x_fastq_scan", "mi355x_fastq_chunks", "mi355x_fastq_fill", "mi355x_last_stats", "mi355x_host_cpus", "mi355x_collect_sam", "mi355x_host_ksw_align2",
-    "bwa_set_rg", "bwa_insert_header", "bwa_idx2mem", "mi355x_write_map", "mi355x_init", "mi355x_init_bcast_seconds", "mi355x_global_batch",
+    "bwa_set_rg", "bwa_insert_header", "bwa_idx2mem", "mi355x_write_map", "mi355x_init", "mi355x_init_bcast_seconds", "mi355x_global_batch", "mi355x_device_count",
 ]
 
 
@@ -83,6 +83,7 @@ def load_library(build_if_missing=True):
     sig("mi355x_write_map", C.c_int, [C.c_char_p, C.c_char_p])
     sig("mi355x_init", C.c_int, [C.c_int, P(abi.bwaidx_t), P(mi355x_comm_t)])
     sig("mi355x_init_bcast_seconds", C.c_double, [])
+    sig("mi355x_device_count", C.c_int, [])
     sig("mi355x_global_batch", C.c_int, [P(abi.mem_opt_t), C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 7 +
         [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, P(C.c_double)])
     _LIB = lib
@@ -141,41 +142,42 @@ class Engine:
             self._upload_by_broadcast(device, dist, rank)
 
     def _upload_by_broadcast(self, device, dist, rank):
+        """One collective per index array, in place: every rank allocates the three device arrays, rank 0 fills its own from
+        host memory (one H2D), then torch.distributed.broadcast (nccl = RCCL over xGMI) runs directly on views of those
+        arrays — no staging tensor, no device-to-device copy, no synchronisation between pieces (they are queued back to
+        back on the collective's stream and pipeline along the ring); one synchronize at the end, then every rank expands
+        its own dense SA and jump table."""
         import time
         import torch
+        os.environ["MPIBWA_SA_DENSE"] = os.environ.get("MPIBWA_SA_DENSE", "1")
+        if self.lib.mi355x_index_alloc(device, self.bwt, self.bns) != 0:
+            raise RuntimeError("mi355x_index_alloc failed")
+        pv = [C.c_void_p() for _ in range(3)]
+        sv = [C.c_size_t() for _ in range(3)]
+        self.lib.mi355x_index_buffers(C.byref(pv[0]), C.byref(sv[0]), C.byref(pv[1]), C.byref(sv[1]), C.byref(pv[2]), C.byref(sv[2]))
         if rank == 0:
-            os.environ["MPIBWA_SA_DENSE"] = os.environ.get("MPIBWA_SA_DENSE", "1")
-            self.lib.mi355x_index_alloc(device, self.bwt, self.bns)
-            # rank 0 fills its buffers from the host copy (H2D once), the others get them over RCCL
-            sizes = [int(self.bwt.contents.bwt_size) * 4, int(self.bwt.contents.n_sa) * 8, int(self.bns.contents.l_pac) // 4 + 1]
-            srcs = [C.cast(self.bwt.contents.bwt, C.c_void_p), C.cast(self.bwt.contents.sa, C.c_void_p), C.cast(self.pac, C.c_void_p)]
-        else:
-            self.lib.mi355x_index_alloc(device, self.bwt, self.bns)
-            sizes = [int(self.bwt.contents.bwt_size) * 4, int(self.bwt.contents.n_sa) * 8, int(self.bns.contents.l_pac) // 4 + 1]
-            srcs = None
+            HIP = _hip()
+            srcs = [(C.cast(self.bwt.contents.bwt, C.c_void_p), int(self.bwt.contents.bwt_size) * 4),
+                    (C.cast(self.bwt.contents.sa, C.c_void_p), int(self.bwt.contents.n_sa) * 8),
+                    (C.cast(self.pac, C.c_void_p), int(self.bns.contents.l_pac) // 4 + 1)]
+            for which, (src, nbytes) in enumerate(srcs):
+                if HIP.hipMemcpy(C.c_void_p(pv[which].value), src, C.c_size_t(nbytes), 1) != 0:   # hipMemcpyHostToDevice
+                    raise RuntimeError("hipMemcpy H2D failed")
+
+        class _DevView:   # zero-copy torch view of a raw device allocation
+            def __init__(self, ptr, nbytes):
+                self.__cuda_array_interface__ = {"data": (ptr, False), "shape": (nbytes,), "typestr": "|u1", "version": 2}
         t0 = time.time()
-        for which, nbytes in enumerate(sizes):
-            # broadcast in 1 GiB pieces through a torch staging tensor (RCCL over xGMI), then a D2D copy into the index buffer
-            piece = 1 << 30
-            t = torch.empty(min(piece, nbytes), dtype=torch.uint8, device="cuda:%d" % device)
-            off = 0
-            pv = [C.c_void_p() for _ in range(3)]
-            sv = [C.c_size_t() for _ in range(3)]
-            self.lib.mi355x_index_buffers(C.byref(pv[0]), C.byref(sv[0]), C.byref(pv[1]), C.byref(sv[1]), C.byref(pv[2]), C.byref(sv[2]))
-            ptrs = [p.value for p in pv]
-            while off < nbytes:
-                n = min(piece, nbytes - off)
-                if rank == 0:
-                    host = (C.c_uint8 * n).from_address(srcs[which].value + off)
-                    t[:n].copy_(torch.frombuffer(host, dtype=torch.uint8))
-                dist.broadcast(t[:n], src=0)
-                torch.cuda.synchronize()
-                HIP = _hip()
-                dst = ptrs[which] + off
-                if HIP.hipMemcpy(C.c_void_p(dst), C.c_void_p(t.data_ptr()), C.c_size_t(n), 3) != 0:
-                    raise RuntimeError("hipMemcpy D2D failed")
-                off += n
+        piece = int(os.environ.get("MPIBWA_BCAST_PIECE_MB", "256")) << 20
+        views = []
+        for which in range(3):
+            v = torch.as_tensor(_DevView(pv[which].value, sv[which].value), device="cuda:%d" % device)
+            views.append(v)
+            for off in range(0, sv[which].value, piece):
+                dist.broadcast(v[off:off + piece], src=0)
+        torch.cuda.synchronize(device)
         self.bcast_seconds = time.time() - t0
+        del views
         if self.lib.mi355x_index_commit() != 0:
             raise RuntimeError("mi355x_index_commit failed")
         self.uploaded = True

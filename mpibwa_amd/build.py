@@ -50,7 +50,28 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+    build_driver(force=force, verbose=verbose)
     return OUT
+
+
+def build_driver(force=False, verbose=False):
+    """mpibwa_amd/mpibwa_gpu: the MPI host program (driver/mpibwa_gpu.c), when an MPI installation is around (MPI_HOME or the
+    image's MPICH under /opt/conda).  Plain C against include/mpibwa_amd.h; the system library directory goes first in its run
+    path so that the product library's libstdc++ is the system's, not an older one next to the MPI library."""
+    src = os.path.join(HERE, "driver", "mpibwa_gpu.c")
+    exe = os.path.join(HERE, "mpibwa_gpu")
+    home = os.environ.get("MPI_HOME", "/opt/conda")
+    inc, libdir = os.path.join(home, "include"), os.path.join(home, "lib")
+    if not (os.path.exists(os.path.join(inc, "mpi.h")) and os.path.exists(os.path.join(libdir, "libmpi.so"))):
+        return None
+    if force or _stale(exe, [src, OUT, os.path.join(HERE, "..", "include", "mpibwa_amd.h")]):
+        cmd = ["gcc", "-O2", "-std=gnu99", "-Wall", "-I", os.path.join(HERE, "..", "include"), "-I", inc, src, "-o", exe,
+               "-L", HERE, "-lmpibwa_amd", os.path.join(libdir, "libmpi.so"),
+               "-Wl,-rpath,/usr/lib/x86_64-linux-gnu:$ORIGIN:" + libdir, "-Wl,-rpath-link,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return exe
 
 
 if __name__ == "__main__":

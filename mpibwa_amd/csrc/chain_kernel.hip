@@ -34,14 +34,15 @@ namespace {
 typedef long long i64;
 
 #define CK_MAXCH 9
-#define CK_MAXSEEDS 64
+#define CK_MAXSEEDS 64         // first launch: every read, up to this many seeds
+#define CK_MAXSEEDS_BIG 255    // second launch: the reads the first one declined for their seed count only (seed numbers are bytes)
 enum { F_POS_LO = 0, F_POS_HI, F_FIRST_Q, F_LAST_R_LO, F_LAST_R_HI, F_LAST_Q, F_LAST_LEN, F_RID, F_N, F_W, F_KEPT, F_FIRSTOV, F_NFIELDS };
 
 struct Lds {
 	uint32_t *tab;    // [F_NFIELDS * CK_MAXCH][64]
-	uint8_t *cid;     // [CK_MAXSEEDS][64]  chain id of every seed (255 = in no chain)
+	uint8_t *cid;     // [MAXS + 1][64]     chain id of every seed (255 = in no chain)
 	uint8_t *ord;     // [16][64]           chain ids in tree order, later in filter order
-	uint8_t *tmp;     // [CK_MAXSEEDS][64]  scratch: members of one chain
+	uint8_t *tmp;     // [MAXS + 1][64]     scratch: members of one chain
 	int lane;
 	__device__ __forceinline__ uint32_t &f(int field, int id) const { return tab[(field * CK_MAXCH + id) * 64 + lane]; }
 	__device__ __forceinline__ i64 pos(int id) const { return (i64)((unsigned long long)f(F_POS_HI, id) << 32 | f(F_POS_LO, id)); }
@@ -63,6 +64,10 @@ __device__ __forceinline__ int ck_pos2rid(const i64 *__restrict__ ann_off, int n
 }
 __device__ __forceinline__ i64 ck_depos(i64 l_pac, i64 pos) { return pos >= l_pac ? (l_pac << 1) - 1 - pos : pos; }
 
+// MAXS: seeds per read the instantiation has LDS for.  RETRY: second launch — only the reads the first launch declined
+// because they have more than CK_MAXSEEDS seeds (a few per cent of 2x150 bp reads, with ~150 seeds each: they used to be
+// a quarter of the host's CPU time per chunk); reads with more than 9 chains stay with the host's B-tree either way.
+template <int MAXS, bool RETRY>
 __global__ void __launch_bounds__(64)
 chain_kernel(ChainParams P, int n_reads, const int *__restrict__ lens, const int *__restrict__ n_seeds, const int *__restrict__ l_rep,
              const i64 *__restrict__ seed_off, const unsigned long long *__restrict__ sa, const int32_t *__restrict__ qbl,
@@ -74,7 +79,7 @@ chain_kernel(ChainParams P, int n_reads, const int *__restrict__ lens, const int
 	L.lane = threadIdx.x;
 	L.tab = lds_raw;
 	L.cid = (uint8_t *)(lds_raw + F_NFIELDS * CK_MAXCH * 64);
-	L.ord = L.cid + CK_MAXSEEDS * 64;
+	L.ord = L.cid + (MAXS + 1) * 64;
 	L.tmp = L.ord + 16 * 64;
 	const int lane = threadIdx.x;
 	const int rd = blockIdx.x * 64 + lane;
@@ -82,8 +87,9 @@ chain_kernel(ChainParams P, int n_reads, const int *__restrict__ lens, const int
 	const int ns = n_seeds[rd], lq = lens[rd];
 	const i64 so = seed_off[rd];
 	const int *gap = tab, *noflt = tab + 5 * tab_stride;
-	if (ns == 0) { n_chains[rd] = 0; return; }
-	if (ns > CK_MAXSEEDS || !noflt[lq]) { n_chains[rd] = -1; return; }
+	if (RETRY) { if (n_chains[rd] != -1 || ns <= CK_MAXSEEDS) return; }
+	else if (ns == 0) { n_chains[rd] = 0; return; }
+	if (ns > MAXS || !noflt[lq]) { n_chains[rd] = -1; return; }
 	const i64 l_pac = P.l_pac;
 	auto S_R = [&](int k) -> i64 { return (i64)sa[so + k]; };
 	auto S_Q = [&](int k) -> int { return qbl[2 * (so + k)]; };
@@ -345,22 +351,28 @@ void launch_reg_pack(void *stream, int n_reads, const int *d_reg_beg, const int 
 	HIP_OK(hipGetLastError());
 }
 
-size_t chain_lds_bytes() { return (size_t)F_NFIELDS * CK_MAXCH * 64 * 4 + (size_t)(CK_MAXSEEDS + 16 + CK_MAXSEEDS) * 64; }
+static size_t chain_lds_bytes(int maxs) { return (size_t)F_NFIELDS * CK_MAXCH * 64 * 4 + (size_t)(2 * (maxs + 1) + 16) * 64; }
 
 void launch_chain(void *stream, const ChainParams &P, int n_reads, const int *d_len, const int *d_nseeds, const int *d_lrep,
                   const int64_t *d_seed_off, const uint64_t *d_sa, const int32_t *d_qbl, const int64_t *d_ann_off, const uint8_t *d_ann_alt,
                   int n_seqs, const int *d_tab, int tab_stride, DevChain *d_chains, DevSeed *d_seeds, unsigned int *d_srt, int *d_nchains)
 {
 	if (n_reads <= 0) return;
-	const size_t lds = chain_lds_bytes();
+	const size_t lds = chain_lds_bytes(CK_MAXSEEDS), lds_big = chain_lds_bytes(CK_MAXSEEDS_BIG);
 	static bool s_attr = false;
-	if (!s_attr && lds > 64 * 1024) {
-		HIP_OK(hipFuncSetAttribute((const void *)chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	if (!s_attr) {
+		if (lds > 64 * 1024) HIP_OK(hipFuncSetAttribute((const void *)chain_kernel<CK_MAXSEEDS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		if (lds_big > 64 * 1024) HIP_OK(hipFuncSetAttribute((const void *)chain_kernel<CK_MAXSEEDS_BIG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
 		s_attr = true;
 	}
-	hipLaunchKernelGGL(chain_kernel, dim3((n_reads + 63) / 64), dim3(64), lds, (hipStream_t)stream, P, n_reads, d_len, d_nseeds, d_lrep,
+	hipLaunchKernelGGL((chain_kernel<CK_MAXSEEDS, false>), dim3((n_reads + 63) / 64), dim3(64), lds, (hipStream_t)stream, P, n_reads, d_len, d_nseeds, d_lrep,
 	                   (const i64 *)d_seed_off, (const unsigned long long *)d_sa, d_qbl, (const i64 *)d_ann_off, d_ann_alt, n_seqs, d_tab, tab_stride,
 	                   d_chains, d_seeds, d_srt, d_nchains);
+	static const bool retry = getenv("MPIBWA_CHAIN_BIG") == nullptr || atoi(getenv("MPIBWA_CHAIN_BIG")) != 0;
+	if (retry)
+		hipLaunchKernelGGL((chain_kernel<CK_MAXSEEDS_BIG, true>), dim3((n_reads + 63) / 64), dim3(64), lds_big, (hipStream_t)stream, P, n_reads, d_len, d_nseeds,
+		                   d_lrep, (const i64 *)d_seed_off, (const unsigned long long *)d_sa, d_qbl, (const i64 *)d_ann_off, d_ann_alt, n_seqs, d_tab,
+		                   tab_stride, d_chains, d_seeds, d_srt, d_nchains);
 	HIP_OK(hipGetLastError());
 }
 

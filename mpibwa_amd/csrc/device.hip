@@ -146,6 +146,13 @@ static void maybe_expand_sa()
 	(void)hipFree(d_cnt); (void)hipEventDestroy(a); (void)hipEventDestroy(b);
 }
 
+// GPUs this process can see (0 when there is none: callers decide how many ranks share a device)
+extern "C" int mi355x_device_count(void)
+{
+	int n = 0;
+	return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
 extern "C" int mi355x_index_alloc(int local_rank, const bwt_t *bwt, const bntseq_t *bns)
 {
 	require_device(local_rank);

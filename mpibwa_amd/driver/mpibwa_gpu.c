@@ -1,0 +1,320 @@
+/* mpibwa_gpu.c — a thin MPI host program around the C ABI of libmpibwa_amd.so: one rank per GPU,
+ *
+ *     mpiexec -n N mpibwa_gpu mem [-t threads] [-K bases] [-C] [--dry-run] -o OUT PREFIX R1.fastq [R2.fastq]
+ *
+ * It does, with this repo's own code, what mpiBWA's main does around mem_process_seqs():
+ *   - every rank takes a byte slice of each FASTQ file, finds the first record boundary in it and scans its records
+ *     (offset discovery: src/parallel_aux.c:262-476, record scan :682-832);
+ *   - the chunk rule — a chunk takes reads until its base count EXCEEDS maxsiz, src/parallel_aux.c:1510-1546 — is a
+ *     running count over the whole file, so it is carried from rank to rank along a pipeline (:1553-1561, 1373-1737):
+ *     chunk boundaries do not depend on the number of ranks;
+ *   - the chunk table is replicated, chunks are handed out by an RMA fetch-and-add counter (src/mainParallel.c:1112-1119),
+ *     each chunk's bytes are read with MPI-IO, turned into bseq1_t (mi355x_fastq_fill), aligned (mem_process_seqs) and
+ *     its SAM text appended through the shared file pointer (MPI_File_write_shared, src/mainParallel.c:1390 ff.).
+ * Modes as in the reference: single end; pairs in two files of equal byte size (maxsiz = K/2 per file, R2 cut at R1's
+ * header offsets); pairs in files of different size (trimmed reads: maxsiz = K over both files, n_processed = reads the
+ * rank has already aligned).  The SAM body (all lines not starting with '@') is the reference's for the same -K.
+ * The index reaches the GPUs through mi355x_init(): the ranks of a node that have a GPU each get it by RCCL broadcast
+ * from the node's first rank; where ranks outnumber GPUs (tests on a one-GPU box) every rank uploads its own copy.
+ *
+ * Plain C99 + MPI; built by mpibwa_amd/build.py when an MPI installation is found (mpibwa_amd/mpibwa_gpu).
+ */
+#define _GNU_SOURCE
+#include <mpi.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#include "mpibwa_amd.h"
+
+#define DIE(...) do { fprintf(stderr, "[mpibwa_gpu] " __VA_ARGS__); fputc('\n', stderr); MPI_Abort(MPI_COMM_WORLD, 1); } while (0)
+#define MPI_OK(call) do { int e_ = (call); if (e_ != MPI_SUCCESS) DIE("%s failed (%s:%d)", #call, __FILE__, __LINE__); } while (0)
+
+static int g_rank, g_size;
+
+/* ---- one FASTQ file as this rank sees it ---- */
+typedef struct {
+	MPI_File fh;
+	MPI_Offset size;
+	int64_t n_local;        /* records that start in this rank's slice */
+	int64_t first_index;    /* global index of the first of them */
+	int64_t n_total;
+	int64_t *off;           /* absolute offset of every local record, + the end of the last one */
+	int32_t *bases;
+} fq_t;
+
+static void read_at(MPI_File fh, MPI_Offset at, char *buf, int64_t len)
+{
+	while (len > 0) {   /* MPI counts are ints */
+		int piece = len > (1 << 30) ? (1 << 30) : (int)len;
+		MPI_Status st;
+		MPI_OK(MPI_File_read_at(fh, at, buf, piece, MPI_BYTE, &st));
+		at += piece; buf += piece; len -= piece;
+	}
+}
+
+/* is there a record at p?  "@..\n<bases>\n+..\n<quals of the same length>" (a quality line may itself start with '@') */
+static int record_at(const char *p, const char *end)
+{
+	const char *l[5];
+	int k;
+	if (p >= end || *p != '@') return 0;
+	l[0] = p;
+	for (k = 1; k < 5; ++k) {
+		const char *q = memchr(l[k - 1], '\n', (size_t)(end - l[k - 1]));
+		if (!q) { if (k == 4) { l[4] = end + 1; break; } return -1; }   /* ran out of bytes (k == 4: a last line without newline) */
+		l[k] = q + 1;
+	}
+	if (k < 4) return -1;
+	if (*l[2] != '+') return 0;
+	return (l[2] - l[1]) == (l[4] - l[3]) ? 1 : 0;
+}
+
+/* first record starting at or after `lo` (absolute offset); `size` if there is none */
+static MPI_Offset first_record_from(MPI_File fh, MPI_Offset size, MPI_Offset lo)
+{
+	int64_t window = 1 << 16;
+	if (lo <= 0) return 0;
+	if (lo >= size) return size;
+	for (;;) {
+		/* the window starts one byte early: a record starts right behind a newline */
+		const MPI_Offset w0 = lo - 1;
+		const int64_t len = size - w0 < window ? (int64_t)(size - w0) : window;
+		const int at_eof = w0 + len >= size;
+		char *buf = malloc((size_t)len + 1);
+		read_at(fh, w0, buf, len);
+		int undecided = 0;
+		MPI_Offset found = -1;
+		for (int64_t i = 0; i + 1 < len; ++i) {
+			if (buf[i] != '\n') continue;
+			const int r = record_at(buf + i + 1, buf + len);
+			if (r == 1) { found = w0 + i + 1; break; }
+			if (r < 0 && !at_eof) { undecided = 1; break; }   /* the candidate runs out of the window: look at more bytes */
+		}
+		free(buf);
+		if (found >= 0) return found;
+		if (!undecided && at_eof) return size;
+		if (at_eof) return size;
+		window *= 4;
+	}
+}
+
+static void fq_open(fq_t *f, const char *path)
+{
+	memset(f, 0, sizeof *f);
+	MPI_OK(MPI_File_open(MPI_COMM_WORLD, path, MPI_MODE_RDONLY, MPI_INFO_NULL, &f->fh));
+	MPI_OK(MPI_File_get_size(f->fh, &f->size));
+	/* byte slices -> record slices: every rank finds the first record of its slice, its slice ends where the next one starts */
+	MPI_Offset lo = f->size / g_size * g_rank, start = first_record_from(f->fh, f->size, lo), next;
+	long long s = (long long)start, *all = malloc(sizeof(long long) * (size_t)(g_size + 1));
+	MPI_OK(MPI_Allgather(&s, 1, MPI_LONG_LONG, all, 1, MPI_LONG_LONG, MPI_COMM_WORLD));
+	all[g_size] = (long long)f->size;
+	next = (MPI_Offset)all[g_rank + 1];   /* (starts are non-decreasing: a slice without a record start is empty) */
+	if (next < start) next = start;
+	free(all);
+	/* scan the slice */
+	int64_t len = next - start, cap = len / 8 + 16;
+	char *buf = malloc((size_t)len + 1);
+	read_at(f->fh, start, buf, len);
+	f->off = malloc(sizeof(int64_t) * (size_t)(cap + 1));
+	f->bases = malloc(sizeof(int32_t) * (size_t)cap);
+	int64_t n = mi355x_fastq_scan(buf, len, cap, f->off, f->bases);
+	if (n < 0) DIE("%s: malformed FASTQ record at byte %lld", path, (long long)(start - n - 1));
+	free(buf);
+	f->n_local = n;
+	for (int64_t i = 0; i <= n; ++i) f->off[i] += start;
+	long long nl = n, before = 0, total = 0;
+	MPI_OK(MPI_Exscan(&nl, &before, 1, MPI_LONG_LONG, MPI_SUM, MPI_COMM_WORLD));
+	if (g_rank == 0) before = 0;
+	MPI_OK(MPI_Allreduce(&nl, &total, 1, MPI_LONG_LONG, MPI_SUM, MPI_COMM_WORLD));
+	f->first_index = before; f->n_total = total;
+}
+
+/* bases of records [i0, i1) of `f` (global indices) as this rank needs them for the chunk rule over both files: the two
+ * files are sliced by bytes, so the mate of a local R1 record may have been scanned by another rank */
+static int32_t *bases_for_range(const fq_t *f, int64_t i0, int64_t i1)
+{
+	int *cnt = malloc(sizeof(int) * (size_t)g_size), *dsp = malloc(sizeof(int) * (size_t)g_size);
+	long long nl = f->n_local;
+	long long *alln = malloc(sizeof(long long) * (size_t)g_size);
+	MPI_OK(MPI_Allgather(&nl, 1, MPI_LONG_LONG, alln, 1, MPI_LONG_LONG, MPI_COMM_WORLD));
+	long long tot = 0;
+	for (int r = 0; r < g_size; ++r) { if (alln[r] > 0x7fffffff || tot > 0x7fffffff) DIE("too many records for the gather"); cnt[r] = (int)alln[r]; dsp[r] = (int)tot; tot += alln[r]; }
+	int32_t *all = malloc(sizeof(int32_t) * (size_t)(tot + 1));
+	MPI_OK(MPI_Allgatherv(f->bases, (int)f->n_local, MPI_INT, all, cnt, dsp, MPI_INT, MPI_COMM_WORLD));
+	int32_t *out = malloc(sizeof(int32_t) * (size_t)(i1 - i0 + 1));
+	memcpy(out, all + i0, sizeof(int32_t) * (size_t)(i1 - i0));
+	free(all); free(cnt); free(dsp); free(alln);
+	return out;
+}
+
+typedef struct { int64_t first; long long off1, off2; } chunk_t;   /* first record, byte offsets of it in R1 / R2 */
+
+static void bcast_cb(void *buf, size_t bytes, int root, void *user) { MPI_Bcast(buf, (int)bytes, MPI_BYTE, root, *(MPI_Comm *)user); }
+
+int main(int argc, char **argv)
+{
+	MPI_Init(&argc, &argv);
+	MPI_Comm_rank(MPI_COMM_WORLD, &g_rank);
+	MPI_Comm_size(MPI_COMM_WORLD, &g_size);
+	int n_threads = 0, copy_comment = 0, dry = 0;
+	int64_t K = 0;
+	const char *out_path = 0, *pos[4];
+	int n_pos = 0;
+	if (argc < 2 || strcmp(argv[1], "mem") != 0) {
+		if (g_rank == 0) fprintf(stderr, "usage: mpiexec -n N %s mem [-t threads] [-K bases] [-C] [--dry-run] -o OUT PREFIX R1.fastq [R2.fastq]\n", argv[0]);
+		MPI_Finalize();
+		return 1;
+	}
+	for (int i = 2; i < argc; ++i) {
+		if (!strcmp(argv[i], "-t") && i + 1 < argc) n_threads = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-K") && i + 1 < argc) K = atoll(argv[++i]);
+		else if (!strcmp(argv[i], "-o") && i + 1 < argc) out_path = argv[++i];
+		else if (!strcmp(argv[i], "-C")) copy_comment = 1;
+		else if (!strcmp(argv[i], "--dry-run")) dry = 1;
+		else if (argv[i][0] == '-') DIE("unknown option %s", argv[i]);
+		else if (n_pos < 3) pos[n_pos++] = argv[i];
+	}
+	if (n_pos < 2 || (!out_path && !dry)) DIE("need -o OUT PREFIX R1 [R2]");
+	const char *prefix = pos[0];
+	const int paired = n_pos == 3;
+	mem_opt_t *opt = mem_opt_init();
+	if (n_threads > 0) opt->n_threads = n_threads;
+	if (paired) opt->flag |= MEM_F_PE;
+	if (K <= 0) K = (int64_t)opt->chunk_size * opt->n_threads;   /* src/mainParallel.c:635 */
+
+	/* ---- partition ---- */
+	fq_t f1, f2;
+	fq_open(&f1, pos[1]);
+	if (paired) {
+		fq_open(&f2, pos[2]);
+		if (f1.n_total != f2.n_total) DIE("the two FASTQ files hold %lld and %lld reads", (long long)f1.n_total, (long long)f2.n_total);
+	}
+	/* the reference takes the equal-size branch when both files have the same byte size (src/mainParallel.c:703-728) */
+	const int lockstep = paired && f1.size == f2.size, trimmed = paired && !lockstep;
+	const int64_t maxsiz = paired && lockstep ? K / 2 : K;
+	int32_t *b2 = trimmed ? bases_for_range(&f2, f1.first_index, f1.first_index + f1.n_local) : 0;
+	/* the running count travels down the ranks; every rank closes chunks inside its record range */
+	long long carry[2] = {0, 0};   /* bases in the open chunk, 1 if a chunk is open */
+	if (g_rank > 0) MPI_OK(MPI_Recv(carry, 2, MPI_LONG_LONG, g_rank - 1, 7, MPI_COMM_WORLD, MPI_STATUS_IGNORE));
+	int64_t cap = f1.n_local + 2, n_mine = 0;
+	int64_t *mine = malloc(sizeof(int64_t) * (size_t)cap);   /* global index of the first record of the chunks that START here */
+	{
+		long long counter = carry[0];
+		int open = (int)carry[1];
+		for (int64_t i = 0; i < f1.n_local; ++i) {
+			if (!open) { mine[n_mine++] = f1.first_index + i; open = 1; }
+			counter += f1.bases[i];
+			if (b2) counter += b2[i];
+			if (counter > maxsiz) { counter = 0; open = 0; }
+		}
+		carry[0] = counter; carry[1] = open;
+	}
+	if (g_rank + 1 < g_size) MPI_OK(MPI_Send(carry, 2, MPI_LONG_LONG, g_rank + 1, 7, MPI_COMM_WORLD));
+	/* replicate the chunk table: first record and its byte offset in R1; R2's offset comes from whoever scanned that record */
+	long long nm = n_mine, n_chunks = 0, before = 0;
+	MPI_OK(MPI_Allreduce(&nm, &n_chunks, 1, MPI_LONG_LONG, MPI_SUM, MPI_COMM_WORLD));
+	MPI_OK(MPI_Exscan(&nm, &before, 1, MPI_LONG_LONG, MPI_SUM, MPI_COMM_WORLD));
+	if (g_rank == 0) before = 0;
+	long long *tab = calloc((size_t)(n_chunks + 1) * 3, sizeof(long long)), *tab_all = calloc((size_t)(n_chunks + 1) * 3, sizeof(long long));
+	for (int64_t k = 0; k < n_mine; ++k) {
+		tab[3 * (before + k)] = mine[k];
+		tab[3 * (before + k) + 1] = f1.off[mine[k] - f1.first_index];
+	}
+	MPI_OK(MPI_Allreduce(tab, tab_all, (int)((n_chunks + 1) * 3), MPI_LONG_LONG, MPI_SUM, MPI_COMM_WORLD));
+	tab_all[3 * n_chunks] = f1.n_total; tab_all[3 * n_chunks + 1] = (long long)f1.size; tab_all[3 * n_chunks + 2] = paired ? (long long)f2.size : 0;
+	if (paired) {   /* offsets of the chunks' first records in R2 */
+		memset(tab, 0, sizeof(long long) * (size_t)(n_chunks + 1) * 3);
+		for (long long c = 0; c < n_chunks; ++c) {
+			long long idx = tab_all[3 * c];
+			if (idx >= f2.first_index && idx < f2.first_index + f2.n_local) tab[3 * c + 2] = f2.off[idx - f2.first_index];
+		}
+		long long *t2 = calloc((size_t)(n_chunks + 1) * 3, sizeof(long long));
+		MPI_OK(MPI_Allreduce(tab, t2, (int)((n_chunks + 1) * 3), MPI_LONG_LONG, MPI_SUM, MPI_COMM_WORLD));
+		for (long long c = 0; c < n_chunks; ++c) tab_all[3 * c + 2] = t2[3 * c + 2];
+		free(t2);
+	}
+	free(tab);
+	if (dry) {   /* the chunk table, for the partition tests */
+		if (g_rank == 0) {
+			printf("mode %s ranks %d chunks %lld reads %lld maxsiz %lld\n", !paired ? "se" : lockstep ? "pe" : "pe_trim", g_size, n_chunks, (long long)f1.n_total, (long long)maxsiz);
+			for (long long c = 0; c <= n_chunks; ++c) printf("chunk %lld first %lld off1 %lld off2 %lld\n", c, tab_all[3 * c], tab_all[3 * c + 1], tab_all[3 * c + 2]);
+		}
+		MPI_Finalize();
+		return 0;
+	}
+
+	/* ---- index: host copy from the bwa files, device copy through mi355x_init ---- */
+	bwaidx_t *idx = bwa_idx_load_from_disk(prefix, 7);
+	if (!idx) DIE("cannot load the index %s", prefix);
+	MPI_Comm node;
+	MPI_OK(MPI_Comm_split_type(MPI_COMM_WORLD, MPI_COMM_TYPE_SHARED, g_rank, MPI_INFO_NULL, &node));
+	int local_rank, local_size;
+	MPI_Comm_rank(node, &local_rank); MPI_Comm_size(node, &local_size);
+	const int n_dev = mi355x_device_count();
+	if (n_dev <= 0) DIE("no MI355X visible to rank %d", g_rank);
+	if (local_size <= n_dev && local_size > 1) {   /* one rank per GPU: one H2D on the node, RCCL broadcast to the other GPUs */
+		mi355x_comm_t comm = {local_rank, local_size, bcast_cb, &node};
+		mi355x_init(local_rank, idx, &comm);
+	} else mi355x_init(local_rank % n_dev, idx, 0);
+	bwa_verbose = g_rank == 0 ? 3 : 1;
+
+	/* ---- output: rank 0 writes the header, then everybody appends through the shared file pointer ---- */
+	MPI_File out;
+	if (g_rank == 0) {
+		FILE *fp = fopen(out_path, "w");
+		if (!fp) DIE("cannot create %s", out_path);
+		for (int i = 0; i < idx->bns->n_seqs; ++i) fprintf(fp, "@SQ\tSN:%s\tLN:%d\n", idx->bns->anns[i].name, idx->bns->anns[i].len);
+		fprintf(fp, "@PG\tID:mpibwa_gpu\tPN:mpibwa_gpu\tVN:r2\n");
+		fclose(fp);
+	}
+	MPI_Barrier(MPI_COMM_WORLD);
+	MPI_OK(MPI_File_open(MPI_COMM_WORLD, (char *)out_path, MPI_MODE_WRONLY | MPI_MODE_APPEND, MPI_INFO_NULL, &out));
+
+	/* ---- the chunk loop: next chunk by fetch-and-add on rank 0's counter ---- */
+	long long *counter_mem = 0;
+	MPI_Win win;
+	MPI_OK(MPI_Win_allocate(g_rank == 0 ? sizeof(long long) : 0, sizeof(long long), MPI_INFO_NULL, MPI_COMM_WORLD, &counter_mem, &win));
+	if (g_rank == 0) *counter_mem = 0;
+	MPI_Barrier(MPI_COMM_WORLD);
+	int64_t n_done = 0;
+	for (;;) {
+		long long one = 1, c = 0;
+		MPI_OK(MPI_Win_lock(MPI_LOCK_SHARED, 0, 0, win));
+		MPI_OK(MPI_Fetch_and_op(&one, &c, MPI_LONG_LONG, 0, 0, MPI_SUM, win));
+		MPI_OK(MPI_Win_unlock(0, win));
+		if (c >= n_chunks) break;
+		const int64_t count = tab_all[3 * (c + 1)] - tab_all[3 * c];
+		int64_t len1 = tab_all[3 * (c + 1) + 1] - tab_all[3 * c + 1], len2 = paired ? tab_all[3 * (c + 1) + 2] - tab_all[3 * c + 2] : 0;
+		char *buf1 = malloc((size_t)len1 + 1), *buf2 = paired ? malloc((size_t)len2 + 1) : 0;
+		read_at(f1.fh, tab_all[3 * c + 1], buf1, len1); buf1[len1] = 0;
+		if (paired) { read_at(f2.fh, tab_all[3 * c + 2], buf2, len2); buf2[len2] = 0; }
+		int64_t *o1 = malloc(sizeof(int64_t) * (size_t)(count + 1)), *o2 = paired ? malloc(sizeof(int64_t) * (size_t)(count + 1)) : 0;
+		int32_t *bb = malloc(sizeof(int32_t) * (size_t)(count + 1));
+		if (mi355x_fastq_scan(buf1, len1, count, o1, bb) != count) DIE("chunk %lld of R1 does not hold %lld records", c, (long long)count);
+		if (paired && mi355x_fastq_scan(buf2, len2, count, o2, bb) != count) DIE("chunk %lld of R2 does not hold %lld records", c, (long long)count);
+		const int n = (int)(count * (paired ? 2 : 1));
+		bseq1_t *seqs = calloc((size_t)n, sizeof(bseq1_t));
+		if (mi355x_fastq_fill(buf1, o1, buf2, o2, 0, count, copy_comment, lockstep, seqs) < 0) DIE("malformed record in chunk %lld", c);
+		/* n_processed: 0 for single end and equal-size pairs, the reads this rank has done for trimmed pairs (src/mainParallel.c:1314, 2355-2357, 3093) */
+		mem_process_seqs(opt, idx->bwt, idx->bns, idx->pac, trimmed ? n_done : 0, n, seqs, 0);
+		size_t sam_len = 0;
+		char *sam = mi355x_collect_sam(seqs, n, &sam_len);
+		for (size_t w = 0; w < sam_len; ) {
+			int piece = sam_len - w > (1u << 30) ? (1 << 30) : (int)(sam_len - w);
+			MPI_Status st;
+			MPI_OK(MPI_File_write_shared(out, sam + w, piece, MPI_BYTE, &st));
+			w += (size_t)piece;
+		}
+		free(sam); free(seqs); free(o1); free(o2); free(bb); free(buf1); free(buf2);
+		n_done += n;
+	}
+	MPI_Barrier(MPI_COMM_WORLD);
+	MPI_Win_free(&win);
+	MPI_File_close(&out);
+	MPI_File_close(&f1.fh);
+	if (paired) MPI_File_close(&f2.fh);
+	mi355x_finalize();
+	MPI_Finalize();
+	return 0;
+}

@@ -10,14 +10,19 @@ import torch.distributed as dist  # noqa: E402
 from mpibwa_amd import api, dist as D  # noqa: E402
 from golden_util import golden_index, load_reads, load_sam, sam_cases  # noqa: E402
 
-rank, world, _ = D.env_world()
-dist.init_process_group("gloo", rank=rank, world_size=world)
-torch.cuda.set_device(0)
+rank, world, local = D.env_world()
+backend = os.environ.get("BCAST_BACKEND", "gloo")
+dev = local % torch.cuda.device_count() if backend == "nccl" else 0
+torch.cuda.set_device(dev)
+if backend == "nccl":
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+else:
+    dist.init_process_group("gloo", rank=rank, world_size=world)
 d = os.environ["BCAST_DIR"]
 if rank == 0:
     golden_index(d)
 dist.barrier()
-eng = api.Engine(os.path.join(d, "gold.fa"), device=0, dist=dist, rank=rank)
+eng = api.Engine(os.path.join(d, "gold.fa"), device=dev, dist=dist, rank=rank)
 assert eng.bcast_seconds is not None
 kw = sam_cases()["pe_default"]
 out = b"".join(eng.process(eng.opt(**kw), load_reads("reads_pe150.tsv.gz")))

@@ -1,0 +1,81 @@
+"""mpibwa_amd/mpibwa_gpu (driver/mpibwa_gpu.c), the product's own MPI host program: its multi-rank FASTQ partition (byte
+slices -> record boundaries -> the chunk rule carried from rank to rank -> replicated chunk table) must give the chunk table
+of the single-process rule (mi355x_fastq_chunks, itself pinned to the reference's chunk structure in test_fastq.py) for any
+number of ranks.  CPU only: --dry-run stops before the index is touched.  The aligned output is checked in
+test_gpu_driver.py."""
+import gzip
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "mpibwa_amd", "mpibwa_gpu")
+EX = os.path.join(ROOT, "tests", "golden", "mpibwa_examples")
+
+
+def mpiexec():
+    for p in (shutil.which("mpiexec"), "/opt/conda/bin/mpiexec"):
+        if p and os.path.exists(p):
+            return p
+    return None
+
+
+def _dry(ranks, args, cwd):
+    env = dict(os.environ)
+    env.pop("LD_LIBRARY_PATH", None)
+    r = subprocess.run([mpiexec(), "-n", str(ranks), EXE, "mem", "--dry-run"] + args, capture_output=True, text=True, timeout=300, env=env, cwd=cwd)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    head = lines[0].split()
+    table = [tuple(int(x) for x in ln.split()[1::2]) for ln in lines[1:]]
+    return dict(zip(head[0::2], head[1::2])), table
+
+
+def _write_fastq(path, names, seqs, quals=None):
+    with open(path, "wb") as f:
+        for i, (n, s) in enumerate(zip(names, seqs)):
+            q = quals[i] if quals is not None else b"I" * len(s)
+            f.write(b"@" + n + b"\n" + s + b"\n+\n" + q + b"\n")
+
+
+@pytest.mark.skipif(mpiexec() is None, reason="no mpiexec in this container")
+def test_partition_is_the_single_process_chunk_rule_for_any_rank_count(built, tmp_path):
+    from mpibwa_amd import api, fastq
+    if not os.path.exists(EXE):
+        pytest.skip("mpibwa_gpu not built (no MPI installation)")
+    lib = api.load_library()
+    rng = np.random.default_rng(3)
+    # (a) the reference's example pair (equal sizes: lockstep mode), small -K -> many chunks
+    fq = []
+    for k in (1, 2):
+        dst = str(tmp_path / ("R%d.fastq" % k))
+        with gzip.open(os.path.join(EX, "HCC1187C_R%d_10K.fastq.gz" % k), "rb") as g, open(dst, "wb") as f:
+            f.write(g.read())
+        fq.append(dst)
+    # (b) ragged pairs: different lengths per mate, quality lines that start with '@' and '+', no final newline in R2
+    n = 3000
+    names = [b"q%d" % i for i in range(n)]
+    s1 = [bytes(rng.choice(list(b"ACGT"), int(rng.integers(30, 160))).tolist()) for _ in range(n)]
+    s2 = [bytes(rng.choice(list(b"ACGT"), int(rng.integers(30, 160))).tolist()) for _ in range(n)]
+    q1 = [bytes([64]) + bytes(rng.choice(list(b"@+IJ#"), len(s) - 1).tolist()) for s in s1]
+    t1, t2 = str(tmp_path / "T1.fastq"), str(tmp_path / "T2.fastq")
+    _write_fastq(t1, names, s1, q1)
+    _write_fastq(t2, names, s2)
+    with open(t2, "rb+") as f:
+        f.seek(-1, 2); f.truncate()
+    cases = [(fq, 1_000_000, "pe"), (fq, 200_000, "pe"), ([fq[0]], 300_000, "se"), ([t1, t2], 50_000, "pe_trim"), ([t1], 20_000, "se")]
+    for files, K, mode in cases:
+        src = fastq.FastqSource(lib, files[0], files[1] if len(files) > 1 else None, K=K)
+        assert src.mode == mode
+        want_first = [int(x) for x in src.starts]
+        want_off1 = [int(src.f1.off[i]) for i in want_first]
+        for ranks in (1, 2, 3, 5):
+            head, table = _dry(ranks, ["-K", str(K), "PREFIX_UNUSED"] + files, str(tmp_path))
+            assert head["mode"] == mode and int(head["chunks"]) == src.n_chunks and int(head["reads"]) == src.f1.n
+            assert [t[1] for t in table] == want_first, (files, K, ranks)
+            assert [t[2] for t in table] == want_off1
+            if len(files) > 1:
+                assert [t[3] for t in table] == [int(src.f2.off[i]) for i in want_first]

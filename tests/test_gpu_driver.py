@@ -1,0 +1,70 @@
+"""mpibwa_amd/mpibwa_gpu end to end on the GPU box: `mpiexec -n N mpibwa_gpu mem ...` on the reference's example data.
+One chunk (default -K with -t 8): the SAM body hashes to what the real mpiBWA wrote.  Several chunks handed out by the
+fetch-and-add counter to 1, 2 and 3 ranks (sharing the box's GPU): the sorted body is the single-process loop's
+(fastq.align_files, itself compared chunk by chunk with the compiled reference in test_gpu_examples.py)."""
+import gzip
+import hashlib
+import os
+import subprocess
+import sys
+import tarfile
+
+import pytest
+
+from test_driver import EXE, EX, mpiexec
+
+pytestmark = pytest.mark.gpu
+KNOWN_MD5 = "51ce7ba0592d4a199eac49526b6c9d8c"
+
+
+@pytest.fixture(scope="module")
+def example(tmp_path_factory, built):
+    d = tmp_path_factory.mktemp("drv")
+    with tarfile.open(os.path.join(EX, "hg19.small.tar.gz")) as t:
+        t.extractall(d)
+    fq = []
+    for k in (1, 2):
+        dst = str(d / ("R%d.fastq" % k))
+        with gzip.open(os.path.join(EX, "HCC1187C_R%d_10K.fastq.gz" % k), "rb") as g, open(dst, "wb") as f:
+            f.write(g.read())
+        fq.append(dst)
+    return str(d), os.path.join(str(d), "hg19.small.fa"), fq
+
+
+def _run(ranks, args, cwd):
+    env = dict(os.environ)
+    env.pop("LD_LIBRARY_PATH", None)
+    r = subprocess.run([mpiexec(), "-n", str(ranks), EXE, "mem"] + args, capture_output=True, text=True, timeout=900, env=env, cwd=cwd)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout[-2000:] + "\n" + r.stderr[-4000:])
+    assert r.returncode == 0
+
+
+def _body(path):
+    return [ln for ln in open(path, "rb").read().splitlines(keepends=True) if not ln.startswith(b"@")]
+
+
+@pytest.mark.skipif(mpiexec() is None or not os.path.exists(EXE), reason="mpibwa_gpu or mpiexec not present")
+def test_driver_reproduces_the_mpibwa_binary_and_is_rank_count_independent(example):
+    from mpibwa_amd import abi, api, fastq
+    d, prefix, fq = example
+    api.load_library().mi355x_finalize()
+    out = os.path.join(d, "one.sam")
+    _run(2, ["-t", "8", "-o", out, prefix] + fq, d)
+    body = _body(out)
+    assert len(body) == 20036 and hashlib.md5(b"".join(body)).hexdigest() == KNOWN_MD5
+    # several chunks: -K 1000000 -> 9902 + 9902 + 196 reads; any number of ranks gives the same records
+    eng = api.Engine(prefix, device=0)
+    want, counts = fastq.align_files(eng, eng.opt(flag=abi.MEM_F_PE), fq[0], fq[1], K=1_000_000)
+    assert counts == [9902, 9902, 196]
+    api.load_library().mi355x_finalize()
+    for ranks in (1, 3):
+        out = os.path.join(d, "k%d.sam" % ranks)
+        _run(ranks, ["-K", "1000000", "-o", out, prefix] + fq, d)
+        assert sorted(_body(out)) == sorted(want.splitlines(keepends=True)), ranks
+    # single end
+    se, _ = fastq.align_files(api.Engine(prefix, device=0), eng.opt(flag=0), fq[0], None, K=400_000)
+    api.load_library().mi355x_finalize()
+    out = os.path.join(d, "se.sam")
+    _run(2, ["-K", "400000", "-o", out, prefix, fq[0]], d)
+    assert sorted(_body(out)) == sorted(se.splitlines(keepends=True))
