@@ -230,7 +230,7 @@ __device__ __forceinline__ void aln_one(int rq, const AlnParams &P, const WxPara
 						const int sc = (int)(int8_t)__builtin_amdgcn_perm(shi, slo, (uint32_t)qb | 0x0c0c0c00u);
 						const int m = diag + sc;
 						const int g = act ? m - oe_ins + j * e_ins : ALN_NEG - (1 << 28);
-						const int incl = wx_scan_max_id(g, ALN_NEG - (1 << 28));
+						const int incl = wx_scan_max(g);
 						const int excl = wx_dpp<0x138, 0xf>(ALN_NEG - (1 << 28), incl);
 						int f = max(A, excl + e_ins) - j * e_ins;     // F(i,j)
 						uint8_t d = m >= e ? 0 : 1;

@@ -125,13 +125,6 @@ size_t reg_pack_tmp_bytes(int n_reads);
 void launch_reg_pack(void *stream, int n_reads, const int *d_reg_beg, const int *d_nregs, int *d_reg_pos, const DevReg *d_regs, DevReg *d_packed,
                      void *d_tmp, size_t tmp_bytes);
 
-// lane-per-read variant (c2a_lane.hip), same contract; needs counters[2] = 0 (next read) and scores below 2^13
-bool c2a_lane_fits(int max_len, int a);
-void launch_c2a_lane(void *stream, const C2aParams &P, const ExtParams &ep, int n_reads, const uint8_t *d_seq, const int64_t *d_off,
-                     const int *d_len, const int *d_chain_beg, const int *d_chain_cnt, const DevChain *d_chains, const DevSeed *d_seeds,
-                     unsigned int *d_srt, const int *d_reg_beg, DevReg *d_regs, int *d_nregs, const int *d_tab, int tab_stride, const uint8_t *d_pac,
-                     unsigned long long *d_counters, int max_len);
-
 // ---- final global re-alignment on the device (aln_kernel.hip) ----
 struct AlnReq {                  // one call of mem_reg2aln's DP loop (src/bwamem.c:1106-1122)
 	int64_t rb, re;

@@ -21,11 +21,19 @@
 // saturate in the byte flavour (qlen * a < 250 and shift = -min(mat)); a request whose scores could reach the 8-bit
 // ceiling is flagged and recomputed on the host.
 //
-// Mapping: one request per lane, 64 requests per wave, one wave per workgroup.  The row state of a lane — H(i-1,k), E(i,k)
-// the query base of position k and a segment-end flag packed in one dword (13 + 13 + 3 bits, bit 31) — lives in LDS as cell[k][lane], so the 64
-// lanes of a wave touch 64 consecutive dwords (no bank conflicts) and the whole DP runs out of LDS and registers.
-// HBM traffic is the target window (2 bits per row) and one u16 per row for the b[] pass.  The work is VALU-bound:
-// ~30 integer ops per cell.
+// Mapping (round 2): one request per QUAD of lanes, 16 requests per wave, one wave per workgroup.  The query positions of a
+// request are dealt to its four lanes in contiguous quarters, and the quad works as a skewed pipeline: lane j computes its
+// quarter of target row i at step i + j.  What a quarter needs from its left neighbour is what the neighbour held after the
+// last cell of the same row one step earlier — H(i-1) of that cell (the diagonal), both running F values and the running
+// row maximum — four registers handed over with DPP quad_perm, no LDS.  Lane 3 sees the finished row: row maximum into the
+// b[] scratch, best score / te / qe, the stop conditions (broadcast back through the quad).  Compared with the lane-per-
+// request mapping of round 1 (445 waves of 40 KB LDS for a launch of 28 000 requests: fewer waves than SIMDs, one wave per
+// SIMD, launch time = one lane's serial latency) a launch is four times as many waves of a quarter of the serial length
+// and 10 KB of LDS each, so every SIMD has work and several waves to hide LDS latency behind.
+// The row state of a position — H(i-1,k), E(i,k), the query base of position k and a segment-end flag packed in one dword
+// (13 + 13 + 3 bits, bit 31) — lives in LDS as cell[kk][lane] (kk = position inside the lane's quarter), so the 64 lanes of a
+// wave touch 64 consecutive dwords (no bank conflicts) and the whole DP runs out of LDS and registers.  HBM traffic is the
+// target window (2 bits per row) and one u16 per row for the b[] pass.  The work is VALU-bound: ~30 integer ops per cell.
 #include <hip/hip_runtime.h>
 #include "device.h"
 
@@ -52,31 +60,51 @@ __device__ __forceinline__ int msw_base(const uint8_t *__restrict__ pac, int64_t
 
 struct MswPassOut { int score, te, qe; };
 
-// One striped-SW pass for the 64 requests of the wave.  Per lane: `npos` positions already laid out in LDS (query codes,
-// H = E = 0), `tn` target rows, row i reads doubled-coordinate position t0 + i * tdir.
-// rows != nullptr: the row maxima are written to rows[i * row_stride] (the b[] list is rebuilt from them afterwards).
-__device__ __forceinline__ MswPassOut msw_pass(uint32_t *cell, const MswParams &P, const uint8_t *__restrict__ pac, bool live, int npos, int slen,
-                                               int tn, int64_t t0, int tdir, int endsc, int sat_limit, uint16_t *rows, size_t row_stride,
-                                               int *sat_hit)
+#define MSW_QP(a, b, c, d) ((a) | (b) << 2 | (c) << 4 | (d) << 6)
+template <int CTRL>
+__device__ __forceinline__ int msw_dpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+
+// query code of position k of a request: the mate as it is or reverse-complemented, N = 4, beyond the read = padding
+__device__ __forceinline__ uint32_t msw_code(const uint8_t *__restrict__ ms, int qlen, int is_rev, int k)
 {
-	const int lane = threadIdx.x;
+	if (k >= qlen) return MSW_PAD;
+	if (is_rev) { const uint32_t b = ms[qlen - 1 - k]; return b < 4 ? 3 - b : 4; }
+	const uint32_t c = ms[k];
+	return c > 4 ? 4 : c;
+}
+
+// One striped-SW pass for the 16 requests of the wave (a quad of lanes each).  `S` positions per lane already laid out in LDS
+// (query codes, H = E = 0; position k = j * S + kk sits at cell[kk * 64 + lane]), `tn` target rows, row i reads
+// doubled-coordinate position t0 + i * tdir.  rows != nullptr: lane 3 writes the row maxima to rows[i * row_stride] (the b[]
+// list is rebuilt from them afterwards).  The result is valid in every lane of the quad.
+__device__ __forceinline__ MswPassOut msw_pass(uint32_t *cell, const MswParams &P, const uint8_t *__restrict__ pac, bool live, int S, int tn,
+                                               int64_t t0, int tdir, int endsc, int sat_limit, uint16_t *rows, size_t row_stride, int *sat_hit)
+{
+	const int lane = threadIdx.x, j = lane & 3;
 	int gmax = 0, te = -1, qe = -1;
-	bool run = live && tn > 0;
+	bool run = live && tn > 0 && S > 0;
 	const int oe_del = P.o_del + P.e_del, oe_ins = P.o_ins + P.e_ins, e_del = P.e_del, e_ins = P.e_ins;
-	int tb_next = run ? msw_base(pac, P.l_pac, t0) : 0;
-	for (int i = 0; __any(run); ++i) {
+	// uniform trip count of the cell loop: the longest quarter in the wave
+	int Swave = run ? S : 0;
+	for (int o = 32; o; o >>= 1) Swave = max(Swave, __shfl_xor(Swave, o));
+	int co_diag = 0, co_fseg = 0, co_ffull = 0, co_key = 0;   // what this lane held after its last cell of the previous step
+	int tb_next = (run && j == 0) ? msw_base(pac, P.l_pac, t0) : 0;
+	for (int t = 0; __any(run); ++t) {
+		const int i = t - j;                                   // the row this lane works on in this step
+		const bool act = run && i >= 0 && i < tn;
 		const int tb = tb_next;
-		if (run && i + 1 < tn) tb_next = msw_base(pac, P.l_pac, t0 + (int64_t)(i + 1) * tdir);   // in flight during this row
+		if (run && i + 1 >= 0 && i + 1 < tn) tb_next = msw_base(pac, P.l_pac, t0 + (int64_t)(i + 1) * tdir);   // in flight during this step
 		// scores of this row's target base against query codes 0..3 (one byte each) and 4
 		const uint32_t slo = tb == 0 ? P.slo[0] : tb == 1 ? P.slo[1] : tb == 2 ? P.slo[2] : P.slo[3];
 		// ... and against code 4 in byte 0 of the high half; bytes 5..7 (codes 5, 6 and the padding code 7) score 0
 		const uint32_t shi = (uint32_t)(uint8_t)(tb == 0 ? P.s4[0] : tb == 1 ? P.s4[1] : tb == 2 ? P.s4[2] : P.s4[3]);
-		int diag = 0, fseg = 0, ffull = 0;
-		uint32_t key = 0;   // (row maximum << 16) | (0xffff - first position reaching it)
-		const int kmax = run ? npos : 0;
-		// uniform trip count: the longest row in the wave (positions are multiples of 8)
-		int kwave = kmax;
-		for (int o = 32; o; o >>= 1) kwave = max(kwave, __shfl_xor(kwave, o));
+		// hand-over from the left neighbour (its state after the same row, one step ago); lane 0 starts the row
+		const int ci_diag = msw_dpp<MSW_QP(0, 0, 1, 2)>(co_diag), ci_fseg = msw_dpp<MSW_QP(0, 0, 1, 2)>(co_fseg);
+		const int ci_ffull = msw_dpp<MSW_QP(0, 0, 1, 2)>(co_ffull), ci_key = msw_dpp<MSW_QP(0, 0, 1, 2)>(co_key);
+		int diag = j ? ci_diag : 0, fseg = j ? ci_fseg : 0, ffull = j ? ci_ffull : 0;
+		uint32_t key = j ? (uint32_t)ci_key : 0u;   // (row maximum << 16) | (0xffff - first position reaching it)
+		const int kbase = j * S;
+		const int kmax = act ? S : 0;
 		auto step = [&](uint32_t &w, int kk) {
 			const int hk = w & 0x1fff;
 			int e = (int)__builtin_amdgcn_ubfe(w, 13, 13);
@@ -84,7 +112,7 @@ __device__ __forceinline__ MswPassOut msw_pass(uint32_t *cell, const MswParams &
 			// byte q of {shi, slo}: one v_perm_b32 instead of a data-dependent branch per cell
 			const int s = (int)(int8_t)__builtin_amdgcn_perm(shi, slo, q | 0x0c0c0c00u);
 			const int h = max(max(diag + s, e), fseg);               // Hpre(i,k)
-			key = max(key, (uint32_t)h << 16 | (uint32_t)(0xffff - kk));
+			key = max(key, (uint32_t)h << 16 | (uint32_t)(0xffff - (kbase + kk)));
 			const int hfin = max(h, ffull);                          // H(i,k) after the lazy-F pass
 			e = max(max(e - e_del, h - oe_del), 0);
 			const int t2 = h - oe_ins;
@@ -94,41 +122,32 @@ __device__ __forceinline__ MswPassOut msw_pass(uint32_t *cell, const MswParams &
 			diag = hk;
 			w = (w & 0xfc000000u) | ((uint32_t)e << 13 | (uint32_t)hfin);
 		};
-		// software-pipelined, two register sets: the next four cells are in flight from LDS while four are computed (one
-		// wave per SIMD has nobody else to hide the LDS latency behind)
-		uint32_t wa[4], wb[4];
-#pragma unroll
-		for (int u = 0; u < 4; ++u) wa[u] = kmax > 0 ? cell[u * 64 + lane] : 0;
-		for (int k = 0; k < kwave; k += 8) {
+		for (int k = 0; k < Swave; k += 2) {   // quarters are even (the padded query length is a multiple of 8)
 			if (k < kmax) {
-#pragma unroll
-				for (int u = 0; u < 4; ++u) wb[u] = cell[(k + 4 + u) * 64 + lane];
-#pragma unroll
-				for (int u = 0; u < 4; ++u) step(wa[u], k + u);
-#pragma unroll
-				for (int u = 0; u < 4; ++u) cell[(k + u) * 64 + lane] = wa[u];
-				if (k + 8 < kmax) {
-#pragma unroll
-					for (int u = 0; u < 4; ++u) wa[u] = cell[(k + 8 + u) * 64 + lane];
-				}
-#pragma unroll
-				for (int u = 0; u < 4; ++u) step(wb[u], k + 4 + u);
-#pragma unroll
-				for (int u = 0; u < 4; ++u) cell[(k + 4 + u) * 64 + lane] = wb[u];
+				uint32_t w0 = cell[k * 64 + lane], w1 = cell[(k + 1) * 64 + lane];
+				step(w0, k); step(w1, k + 1);
+				cell[k * 64 + lane] = w0; cell[(k + 1) * 64 + lane] = w1;
 			}
 		}
-		if (run) {
+		if (act) { co_diag = diag; co_fseg = fseg; co_ffull = ffull; co_key = (int)key; }
+		// lane 3 has just finished row i: bookkeeping of the whole row, then the verdict goes back to the quad
+		int stop = 0;
+		if (act && j == 3) {
 			const int imax = (int)(key >> 16);
 			if (rows) rows[(size_t)i * row_stride] = (uint16_t)imax;
 			if (imax > gmax) {
 				gmax = imax; te = i; qe = 0xffff - (int)(key & 0xffff);
-				if (gmax >= sat_limit) { *sat_hit = 1; run = false; }
-				if (gmax >= endsc) run = false;
+				if (gmax >= sat_limit) { *sat_hit = 1; stop = 1; }
+				if (gmax >= endsc) stop = 1;
 			}
-			if (i + 1 >= tn) run = false;
+			if (i + 1 >= tn) stop = 1;
 		}
+		stop = msw_dpp<MSW_QP(3, 3, 3, 3)>(stop);
+		if (stop) run = false;
 	}
-	MswPassOut o = {gmax, te, qe};
+	MswPassOut o;
+	o.score = msw_dpp<MSW_QP(3, 3, 3, 3)>(gmax); o.te = msw_dpp<MSW_QP(3, 3, 3, 3)>(te); o.qe = msw_dpp<MSW_QP(3, 3, 3, 3)>(qe);
+	*sat_hit = msw_dpp<MSW_QP(3, 3, 3, 3)>(*sat_hit);
 	return o;
 }
 
@@ -136,9 +155,9 @@ __global__ __launch_bounds__(64) void msw_kernel(MswParams P, int n_req, const M
                                                  const int64_t *__restrict__ off, const int *__restrict__ lens, const uint8_t *__restrict__ pac,
                                                  MswRes *__restrict__ res, uint16_t *__restrict__ rows)
 {
-	extern __shared__ uint32_t cell[];   // [positions][64 lanes]
-	const int lane = threadIdx.x;
-	const int r = blockIdx.x * 64 + lane;
+	extern __shared__ uint32_t cell[];   // [positions of a quarter][64 lanes]
+	const int lane = threadIdx.x, j = lane & 3;
+	const int r = blockIdx.x * 16 + (lane >> 2);
 	const bool live = r < n_req;
 	MswReq rq;
 	rq.rb = rq.re = 0; rq.read = 0; rq.is_rev = 0;
@@ -147,28 +166,24 @@ __global__ __launch_bounds__(64) void msw_kernel(MswParams P, int n_req, const M
 	const int tlen = (int)(rq.re - rq.rb);
 	const bool byte_flavour = qlen * P.a < 250;          // KSW_XBYTE as mem_matesw sets it
 	const int PP = byte_flavour ? 16 : 8;
-	int slen = (qlen + PP - 1) / PP;
-	int npos = slen * PP;
+	const int slen = (qlen + PP - 1) / PP;
+	const int npos = slen * PP, S = npos >> 2;           // positions per lane (npos is a multiple of 8)
+	const uint8_t *ms = seq + (live ? off[rq.read] : 0);
 	// query codes -> LDS (reverse-complemented for the orientations that need it), H = E = 0
-	if (live) {
-		const uint8_t *ms = seq + off[rq.read];
-		for (int k = 0; k < npos; ++k) {
-			uint32_t c = MSW_PAD;
-			if (k < qlen) {
-				if (rq.is_rev) { uint32_t b = ms[qlen - 1 - k]; c = b < 4 ? 3 - b : 4; }
-				else { c = ms[k]; if (c > 4) c = 4; }
-			}
-			cell[k * 64 + lane] = c << 26 | ((k + 1) % slen == 0 ? 0x80000000u : 0u);
+	if (live)
+		for (int kk = 0; kk < S; ++kk) {
+			const int k = j * S + kk;
+			cell[kk * 64 + lane] = msw_code(ms, qlen, rq.is_rev, k) << 26 | ((k + 1) % slen == 0 ? 0x80000000u : 0u);
 		}
-	}
 	const int minsc = P.min_seed_len * P.a;              // KSW_XSUBO | min_seed_len * a
 	const int sat_limit = byte_flavour ? 255 - P.shift : 0x10000;
 	int sat = 0;
-	MswPassOut f = msw_pass(cell, P, pac, live, npos, slen, tlen, rq.rb, 1, 0x10000, sat_limit, live ? rows + r : nullptr, (size_t)n_req, &sat);
+	MswPassOut f = msw_pass(cell, P, pac, live, S, tlen, rq.rb, 1, 0x10000, sat_limit, live ? rows + r : nullptr, (size_t)n_req, &sat);
 	MswRes out;
 	out.score = f.score; out.te = f.te; out.qe = f.qe; out.score2 = -1; out.te2 = -1; out.tb = -1; out.qb = -1; out.flags = sat;
 	// b[]: runs of rows whose maximum reaches minsc; second best = best run outside te +- ceil(score / max)
-	if (live && !sat && f.te >= 0) {
+	// (the quad's own stores to rows[] a few lines up: same wave, same addresses, program order)
+	if (live && j == 0 && !sat && f.te >= 0) {
 		const int d = (f.score + P.max_sc - 1) / P.max_sc;
 		const int low = f.te - d, high = f.te + d;
 		int last_sc = -1, last_i = -1;
@@ -187,30 +202,26 @@ __global__ __launch_bounds__(64) void msw_kernel(MswParams P, int n_req, const M
 	const bool second = live && !sat && f.score >= minsc && f.qe >= 0 && f.te >= 0;
 	int qlen2 = second ? f.qe + 1 : 0;
 	if (second && f.qe >= qlen) qlen2 = 0;   // cannot happen (the maximum of a row is reached on a real base first); stay in bounds
-	const int slen2 = (qlen2 + PP - 1) / PP, npos2 = slen2 * PP;
-	if (qlen2 > 0) {
-		// reverse the codes of positions 0..qe in place, pad the rest, clear H and E
-		for (int k = 0; k < (qlen2 + 1) / 2; ++k) {
-			uint32_t a = (cell[k * 64 + lane] >> 26) & 7, b = (cell[(qlen2 - 1 - k) * 64 + lane] >> 26) & 7;
-			cell[k * 64 + lane] = b << 26;
-			cell[(qlen2 - 1 - k) * 64 + lane] = a << 26;
+	const int slen2 = (qlen2 + PP - 1) / PP, npos2 = slen2 * PP, S2 = npos2 >> 2;
+	if (qlen2 > 0)   // the codes of positions qe .. 0, padded, dealt to the quad again; H and E cleared
+		for (int kk = 0; kk < S2; ++kk) {
+			const int k = j * S2 + kk;
+			const uint32_t c = k < qlen2 ? msw_code(ms, qlen, rq.is_rev, qlen2 - 1 - k) : MSW_PAD;
+			cell[kk * 64 + lane] = c << 26 | ((k + 1) % slen2 == 0 ? 0x80000000u : 0u);
 		}
-		for (int k = qlen2; k < npos2; ++k) cell[k * 64 + lane] = MSW_PAD << 26;
-		for (int k = slen2 - 1; k < npos2; k += slen2) cell[k * 64 + lane] |= 0x80000000u;   // segment ends of the shorter query
-	}
 	int sat2 = 0;
-	MswPassOut g = msw_pass(cell, P, pac, qlen2 > 0, npos2, slen2, f.te + 1, rq.rb + f.te, -1, f.score, sat_limit, nullptr, 0, &sat2);
+	MswPassOut g = msw_pass(cell, P, pac, qlen2 > 0, S2, f.te + 1, rq.rb + f.te, -1, f.score, sat_limit, nullptr, 0, &sat2);
 	if (qlen2 > 0 && g.score == f.score) { out.tb = f.te - g.te; out.qb = f.qe - g.qe; }
 	if (second && qlen2 == 0) out.flags = 1;
 	if (sat2) out.flags = 1;
-	if (live) res[r] = out;
+	if (live && j == 0) res[r] = out;
 }
 
 } // namespace
 
 size_t msw_lds_bytes(int max_len)
 {
-	return (size_t)((max_len + 15) / 16 * 16) * 64 * 4;   // padded to 16 covers both lane widths
+	return (size_t)((max_len + 15) / 16 * 16 / 4) * 64 * 4;   // a quarter of the padded query per lane (padding to 16 covers both lane widths)
 }
 
 void launch_msw(void *stream, const MswParams &P, int n_req, const MswReq *d_req, const uint8_t *d_seq, const int64_t *d_off, const int *d_len,
@@ -224,7 +235,7 @@ void launch_msw(void *stream, const MswParams &P, int n_req, const MswReq *d_req
 		HIP_OK(hipFuncSetAttribute((const void *)msw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 		s_attr = lds;
 	}
-	const int blocks = (n_req + 63) / 64;
+	const int blocks = (n_req + 15) / 16;
 	hipLaunchKernelGGL(msw_kernel, dim3(blocks), dim3(64), lds, (hipStream_t)stream, P, n_req, d_req, d_seq, d_off, d_len, d_pac, d_res, d_rows);
 	HIP_OK(hipGetLastError());
 }

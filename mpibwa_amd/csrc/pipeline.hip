@@ -682,14 +682,9 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			ep.o_del = opt->o_del; ep.e_del = opt->e_del; ep.o_ins = opt->o_ins; ep.e_ins = opt->e_ins; ep.zdrop = opt->zdrop;
 			std::unique_lock<std::mutex> turn(g_c2a_turn);
 			ev_ext.start(st);
-			const char *c2a_env = getenv("MPIBWA_C2A");
-			const bool lane_c2a = c2a_env && !strcmp(c2a_env, "lane");   // experimental mapping, slower so far
-			if (lane_c2a && c2a_lane_fits(max_len, opt->a))      // one lane per read
-				launch_c2a_lane(st, cp, ep, n, d_seq, d_off_r, d_len_r, d_chain_beg, d_chain_cnt, d_chains, d_seeds, d_srt, d_reg_beg, d_regs, d_nregs,
-				                d_tab, TS, (const uint8_t *)ix.d_pac, d_cnt, max_len);
-			else                                                 // one wavefront per read (any read length)
-				launch_c2a(st, cp, ep, n, d_seq, d_off_r, d_len_r, d_chain_beg, d_chain_cnt, d_chains, d_seeds, d_srt, d_reg_beg, d_regs, d_nregs,
-				           d_tab, TS, (const uint8_t *)ix.d_pac, d_cnt, max_len, d_order);
+			// one wavefront per read (any read length)
+			launch_c2a(st, cp, ep, n, d_seq, d_off_r, d_len_r, d_chain_beg, d_chain_cnt, d_chains, d_seeds, d_srt, d_reg_beg, d_regs, d_nregs,
+			           d_tab, TS, (const uint8_t *)ix.d_pac, d_cnt, max_len, d_order);
 			ev_ext.stop(st);
 			// the regions sit in sparse per-read slots: prefix-sum + pack on the device, queued behind the kernel, then one
 			// copy of what is usually enough (2 regions per read); the rare rest follows once the total is known

@@ -43,12 +43,6 @@ __device__ __forceinline__ int wx_scan_max(int v)
 	             : "+v"(v));
 	return v;
 }
-// (kept for callers that pass their own identity: it is no longer needed for correctness)
-__device__ __forceinline__ int wx_scan_max_id(int v, int id)
-{
-	(void)id;
-	return wx_scan_max(v);
-}
 // value of the previous lane (lane 0 gets `first`)
 __device__ __forceinline__ int wx_prev_lane(int v, int first)
 {
