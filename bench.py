@@ -251,6 +251,7 @@ def main():
                    "chunking": "one mem_process_seqs chunk per step (mpiBWA -K 1e8 semantics)", "parallelism": "reads sharded, 1 rank/GPU",
                    "calls_in_flight": n_fly},
         "sam_bytes_per_step": int(sam_bytes / args.steps),
+        "sam_records_written_by_device_frac": round(acc.get("n_sam_dev", 0) / max(1, acc.get("n_reads", 1)), 4),
         "one_call_in_flight": {"value": round(2 * args.pairs * n_chunks * world / alone_s / 1e6, 4), "unit": "Mreads/s",
                                "ms_per_step": round(alone_s / n_chunks * 1e3, 2), "steps": n_chunks},
         "host_cpu_s_per_step": round(host_cpu_s / args.steps, 3), "host_cpu_busy_frac": round(host_cpu_s / (elapsed * max(cores, 1)), 3),

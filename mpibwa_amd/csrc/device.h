@@ -141,6 +141,25 @@ void launch_aln(void *stream, const AlnParams &P, const ExtParams &ep, int n_req
                 unsigned long long *d_counters, size_t pool_bytes, int max_len, int tcap, int *d_lists /* 3 * n_req ints of scratch */,
                 bool wide_only = false /* DP requests skip the narrow-band instantiation (stage tests) */);
 
+// ---- SAM text of confidently paired reads on the device (sam_kernel.hip) ----
+struct SamDesc {                 // one output line: the chosen hit of a read as mem_sam_pe's paired branch reports it
+	int64_t rb, re;              // region in the doubled coordinate
+	int32_t qb, qe;
+	int32_t req;                 // its CIGAR request, relative to the first request of the pair; < 0: the line is not the device's
+	int32_t rid, flag, mapq, score, sub;
+};
+struct SamParams {
+	int64_t l_pac;
+	int has_qual, rg_len;
+	char rg[256];                // bwa_rg_id
+};
+// d_req_base[pair] = first CIGAR request of the pair in d_hdr; out_len[r] = bytes of the record at arena + out_off[r],
+// -1 = the host must format the pair, -2 = not a line of the device
+void launch_sam_emit(void *stream, const SamParams &P, int n_reads, const SamDesc *d_desc, const int *d_req_base, const AlnHdr *d_hdr,
+                     const uint8_t *d_pool, const uint8_t *d_seq, const int64_t *d_off, const int *d_len, const uint8_t *d_qual,
+                     const uint8_t *d_names, const int *d_name_off, const int64_t *d_ann_off, const char *d_ann_names, const int *d_ann_name_off,
+                     uint8_t *d_arena, size_t arena_bytes, unsigned long long *d_arena_used, unsigned long long *d_out_off, int *d_out_len);
+
 // ---- mate-rescue local alignment on the device (msw_kernel.hip) ----
 struct MswReq {                  // one ksw_align2() call of mem_matesw (src/bwamem_pair.c:150-177)
 	int64_t rb, re;              // target window in the doubled coordinate, already clipped to the contig

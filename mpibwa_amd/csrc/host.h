@@ -147,6 +147,7 @@ struct KswResult { int score, te, qe, score2, te2, tb, qb; };   // kswr_t, src/k
 // the alignment itself (mode HOST) — used for regions the device flags, and by the unit tests of the host logic.
 struct AlnReqH { int64_t rb, re; int32_t read, qb, qe, w2, truesc, pad; };   // same layout as the device's AlnReq
 struct AlnHdrH { int32_t score, NM, n_cigar, md_len; uint32_t pool_off; int32_t flags; };
+struct SamDescH { int64_t rb, re; int32_t qb, qe, req, rid, flag, mapq, score, sub; };   // same layout as the device's SamDesc
 struct AlnCtx {
 	enum { HOST = 0, COLLECT = 1, REPLAY = 2 };
 	int mode = HOST;
@@ -154,6 +155,9 @@ struct AlnCtx {
 	const AlnHdrH *hdr = nullptr;           // REPLAY: results in the same order, starting at `cursor`
 	const uint8_t *pool = nullptr;
 	size_t cursor = 0;
+	// COLLECT, optional: where sam_pe_emit describes the two lines of a pair that the device can format (sam_kernel.hip);
+	// desc[e].req stays < 0 when the pair is not of that kind
+	SamDescH *desc = nullptr;
 	bool text() const { return mode != COLLECT; }
 };
 

@@ -454,6 +454,7 @@ void sam_pe_emit(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, 
 	const bool text = !ctx || ctx->text();
 	const int *z = P.z, *n_pri = P.n_pri;
 	HAln h[2];
+	const size_t req0 = (ctx && ctx->reqs) ? ctx->reqs->size() : 0;   // COLLECT: the pair's first CIGAR request
 	if (P.paired) {
 		std::vector<std::string> xa[2];
 		std::vector<char> has[2];
@@ -463,7 +464,9 @@ void sam_pe_emit(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, 
 		const HAln *aa[2][2];   // the lines of each read: the chosen hit, then possibly its best ALT hit
 		int n_aa[2] = {0, 0};
 		HAln g[2];
+		int h_req[2] = {-1, -1};   // COLLECT: the chosen hits' CIGAR requests, counted from the pair's first request
 		for (int i = 0; i < 2; ++i) {
+			if (!text && ctx->reqs) h_req[i] = (int)(ctx->reqs->size() - req0);
 			h[i] = reg2aln(opt, bns, pac, s[i].l_seq, s[i].seq, &a[i][z[i]], ctx, read0 + i, false);   // MAPQ comes from the pairing
 			h[i].mapq = P.q_se[i] & 0xff;
 			h[i].flag |= 0x40 << i | P.extra_flag;
@@ -478,7 +481,22 @@ void sam_pe_emit(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, 
 				aa[i][n_aa[i]++] = &g[i];
 			}
 		}
-		if (!text) return;
+		if (!text) {
+			// One line per read, nothing but the standard tags: the device writes these records (sam_kernel.hip).  What it
+			// needs besides the CIGAR results: the region, the flag bits and the numbers decided above.
+			if (ctx->desc && n_aa[0] == 1 && n_aa[1] == 1 && !h[0].has_xa && !h[1].has_xa && !(have_xa[0] && has[0][z[0]]) &&
+			    !(have_xa[1] && has[1][z[1]]) && h[0].alt_sc <= 0 && h[1].alt_sc <= 0 && !s[0].comment && !s[1].comment &&
+			    !(opt->flag & (MEM_F_ALL | MEM_F_REF_HDR)) && strcmp(s[0].name, s[1].name) == 0) {
+				for (int i = 0; i < 2; ++i) {
+					const HReg &r = a[i][z[i]];
+					SamDescH &d = ctx->desc[i];
+					d.rb = r.rb; d.re = r.re; d.qb = r.qb; d.qe = r.qe; d.rid = r.rid;
+					d.req = h_req[i];
+					d.flag = h[i].flag; d.mapq = (int32_t)h[i].mapq; d.score = h[i].score; d.sub = h[i].sub;
+				}
+			}
+			return;
+		}
 		static thread_local std::string str;   // keeps its capacity from pair to pair
 		str.clear();
 		for (int i = 0; i < n_aa[0]; ++i) aln2sam_pub(opt, bns, str, &s[0], n_aa[0], aa[0], i, &h[1]);

@@ -144,7 +144,9 @@ static void parallel_blocks(int n_threads, int n, int chunk, F f)
 	for (auto &t : th) t.join();
 }
 
-static std::mutex g_smem_turn, g_c2a_turn, g_pes_lock;
+static std::mutex g_smem_turn, g_c2a_turn_own, g_pes_lock;
+// MPIBWA_BIG_TURN=1: the two chip-filling kernels (seeding, extension) of all calls take turns on ONE mutex instead of one each
+static std::mutex &c2a_turn() { static const bool one = getenv("MPIBWA_BIG_TURN") != nullptr && atoi(getenv("MPIBWA_BIG_TURN")) != 0; return one ? g_smem_turn : g_c2a_turn_own; }
 
 static double now_ms()
 {
@@ -202,15 +204,34 @@ struct HostBuf {
 	void *ensure(size_t bytes) { if (bytes > cap) { free(p); cap = bytes + bytes / 4 + 4096; p = malloc(cap); if (!p) die("out of memory"); } return p; }
 };
 
-// grow-only page-locked host buffer: staging for the bulk H2D / D2H copies (full PCIe rate, no per-chunk page faults)
+// grow-only page-locked host buffer: staging for the bulk H2D / D2H copies (full PCIe rate, no per-chunk page faults).
+// The pages are ordinary heap pages registered with the runtime (hipHostRegister), NOT hipHostMalloc memory: what
+// hipHostMalloc returns on this platform is very slow for the CPU to read (it behaves like uncached memory: 2 500 cycles for
+// a 400-byte record), and the host stages read every result the GPU sends back.  MPIBWA_PIN=m selects hipHostMalloc (A/B).
 struct PinBuf {
 	void *p = nullptr; size_t cap = 0;
+	bool registered = false;
+	static bool use_register() { static const bool r = !(getenv("MPIBWA_PIN") && *getenv("MPIBWA_PIN") == 'm'); return r; }
+	void drop()
+	{
+		if (!p) return;
+		if (registered) { HIP_OK(hipHostUnregister(p)); free(p); }
+		else HIP_OK(hipHostFree(p));
+		p = nullptr; cap = 0;
+	}
 	void *ensure(size_t bytes)
 	{
 		if (bytes > cap) {
-			if (p) HIP_OK(hipHostFree(p));
-			cap = bytes + bytes / 4 + 4096;
-			HIP_OK(hipHostMalloc(&p, cap, hipHostMallocDefault));
+			drop();
+			cap = (bytes + bytes / 4 + 8192) & ~(size_t)4095;
+			if (use_register()) {
+				if (posix_memalign(&p, 4096, cap) != 0 || !p) die("out of memory");
+				HIP_OK(hipHostRegister(p, cap, hipHostRegisterDefault));
+				registered = true;
+			} else {
+				HIP_OK(hipHostMalloc(&p, cap, hipHostMallocDefault));
+				registered = false;
+			}
 		}
 		return p;
 	}
@@ -225,6 +246,9 @@ struct Workspace {
 	DevBuf mreq[2], mres[2], mrows[2], alist[2];
 	DevBuf seq, off, len, intv, nintv, cnt, scratch, nseeds, lrep, seed_off, rows, qbl, sa;
 	DevBuf chain_off, chains, seeds, srt, reg_off, regs, nregs, tab, areq, ahdr, apool, agap, acnt, areq2, ahdr2, apool2, acnt2;
+	// SAM text on the device (sam_kernel.hip): line descriptors, names / qualities of the chunk, contig names, output arena per part
+	DevBuf sdesc, sbase[2], squal, snames, snoff, sann_names, sann_noff, sarena[2], sused[2], sooff[2], solen[2];
+	PinBuf h_sdesc, h_names, h_noff, h_qual, h_sarena[2], h_sooff[2], h_solen[2], h_sbase[2];
 };
 static const int MAX_LANES = 4;
 // Everything one mem_process_seqs() call owns between its first and last line.  Four of them: four caller threads may be inside
@@ -680,7 +704,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			ExtParams ep;
 			memcpy(ep.mat, opt->mat, 25);
 			ep.o_del = opt->o_del; ep.e_del = opt->e_del; ep.o_ins = opt->o_ins; ep.e_ins = opt->e_ins; ep.zdrop = opt->zdrop;
-			std::unique_lock<std::mutex> turn(g_c2a_turn);
+			std::unique_lock<std::mutex> turn(c2a_turn());
 			ev_ext.start(st);
 			// one wavefront per read (any read length)
 			launch_c2a(st, cp, ep, n, d_seq, d_off_r, d_len_r, d_chain_beg, d_chain_cnt, d_chains, d_seeds, d_srt, d_reg_beg, d_regs, d_nregs,
@@ -840,6 +864,12 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		size_t pool_bytes = 0;
 		hipStream_t st = 0;
 		EvTimer ev;
+		// records written by sam_kernel: arena / offsets / lengths (host copies), for the reads 2 lo .. 2 hi of the part
+		bool sam_launched = false;
+		size_t arena_bytes = 0;
+		const uint8_t *sarena = nullptr;
+		const unsigned long long *sooff = nullptr;
+		const int *solen = nullptr;
 	};
 	Part parts[2];
 	hipStream_t *a_streams = C.a_streams;
@@ -854,6 +884,60 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	HIP_OK(hipMemcpyAsync(d_gap, gaptab.data(), gaptab.size() * 4, hipMemcpyHostToDevice, st));
 	HIP_OK(hipStreamSynchronize(st));
 	double plan_ms = 0, aln_wait_ms = 0;
+
+	// ---- SAM text of confidently paired reads on the device (sam_kernel.hip) ----
+	// The COLLECT pass describes the two lines of every pair that qualifies (AlnCtx::desc); the kernel runs right behind the
+	// CIGAR kernel of the part; the REPLAY pass only copies those records out of the arena and formats the rest itself.
+	static_assert(sizeof(SamDesc) == sizeof(SamDescH), "host/device record layouts differ");
+	bool gpu_sam = pe && gpu_aln && getenv("MPIBWA_HOST_SAM") == nullptr && !(opt->flag & (MEM_F_ALL | MEM_F_REF_HDR));
+	SamDescH *sdesc = nullptr;
+	SamParams sam_par;
+	const uint8_t *d_qual = nullptr, *d_names = nullptr;
+	const int *d_noff = nullptr, *d_ann_noff = nullptr;
+	const char *d_ann_names = nullptr;
+	if (gpu_sam) {
+		bool any_q = false, all_q = true;
+		for (int i = 0; i < n; ++i) { if (seqs[i].qual) any_q = true; else all_q = false; }
+		if (any_q && !all_q) gpu_sam = false;   // a mix of reads with and without qualities: the host formats the chunk
+		sam_par.l_pac = bns->l_pac; sam_par.has_qual = any_q ? 1 : 0;
+		sam_par.rg_len = (int)strnlen(bwa_rg_id, sizeof bwa_rg_id);
+		memset(sam_par.rg, 0, sizeof sam_par.rg);
+		memcpy(sam_par.rg, bwa_rg_id, (size_t)sam_par.rg_len);
+	}
+	if (gpu_sam) {
+		sdesc = (SamDescH *)W.h_sdesc.ensure((size_t)n * sizeof(SamDescH) + 64);
+		int *noff = (int *)W.h_noff.ensure((size_t)(n + 1) * 4 + 64);
+		std::vector<int> nlen(n);
+		parallel_for(n_thr, n, 8192, [&](int i) { sdesc[i].req = -1; nlen[i] = (int)strlen(seqs[i].name); });
+		noff[0] = 0;
+		for (int i = 0; i < n; ++i) noff[i + 1] = noff[i] + nlen[i];
+		uint8_t *names = (uint8_t *)W.h_names.ensure((size_t)noff[n] + 64);
+		uint8_t *hq = sam_par.has_qual ? (uint8_t *)W.h_qual.ensure(flat_bytes) : nullptr;
+		parallel_for(n_thr, n, 4096, [&](int i) {
+			memcpy(names + noff[i], seqs[i].name, (size_t)nlen[i]);
+			if (hq) memcpy(hq + off[i], seqs[i].qual, (size_t)seqs[i].l_seq);
+		});
+		uint8_t *dn = (uint8_t *)W.snames.ensure((size_t)noff[n] + 64);
+		int *dno = (int *)W.snoff.ensure((size_t)(n + 1) * 4);
+		HIP_OK(hipMemcpyAsync(dn, names, (size_t)noff[n], hipMemcpyHostToDevice, st));
+		HIP_OK(hipMemcpyAsync(dno, noff, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, st));
+		if (hq) {
+			uint8_t *dq = (uint8_t *)W.squal.ensure(flat_bytes);
+			HIP_OK(hipMemcpyAsync(dq, hq, flat_bytes, hipMemcpyHostToDevice, st));
+			d_qual = dq;
+		}
+		// contig names
+		std::vector<int> cno(bns->n_seqs + 1, 0);
+		for (int k = 0; k < bns->n_seqs; ++k) cno[k + 1] = cno[k] + (int)strlen(bns->anns[k].name);
+		std::vector<char> cn((size_t)cno[bns->n_seqs] + 1);
+		for (int k = 0; k < bns->n_seqs; ++k) memcpy(cn.data() + cno[k], bns->anns[k].name, (size_t)(cno[k + 1] - cno[k]));
+		char *dcn = (char *)W.sann_names.ensure(cn.size() + 64);
+		int *dcno = (int *)W.sann_noff.ensure(cno.size() * 4);
+		HIP_OK(hipMemcpyAsync(dcn, cn.data(), cn.size(), hipMemcpyHostToDevice, st));
+		HIP_OK(hipMemcpyAsync(dcno, cno.data(), cno.size() * 4, hipMemcpyHostToDevice, st));
+		HIP_OK(hipStreamSynchronize(st));
+		d_names = dn; d_noff = dno; d_ann_names = dcn; d_ann_noff = dcno;
+	}
 
 	// mate rescue on the device: list the local alignments the pairs of a part will ask for, run them in one launch
 	static_assert(sizeof(MswReq) == sizeof(MswReqH) && sizeof(MswRes) == sizeof(MswResH), "host/device record layouts differ");
@@ -951,6 +1035,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 					sam_pe_plan(opt, bns, pac, pes, (uint64_t)((n_processed >> 1) + i), &seqs[i << 1], &regs[i << 1], plans[i], waits ? &mc : nullptr,
 					            i << 1);
 					const unsigned long long c1 = s_cpusec ? __builtin_ia32_rdtsc() : 0;
+					ctx.desc = gpu_sam ? &sdesc[i << 1] : nullptr;
 					if (gpu_aln) sam_pe_emit(opt, bns, pac, pes, &seqs[i << 1], &regs[i << 1], plans[i], &ctx, i << 1);
 					if (s_cpusec) { tsc_plan_blk += c1 - c0; tsc_emitc_blk += __builtin_ia32_rdtsc() - c1; }
 				} else {
@@ -996,6 +1081,24 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		launch_aln(P.st, ap, ep, (int)n_req, d_req, d_seq, d_off, (const uint8_t *)ix.d_pac, d_gap, P.d_hdr, P.d_pool, P.d_cnt, P.pool_bytes, max_len,
 		           max_len + 256, d_lists);
 		P.ev.stop(P.st);   // results are fetched in finish(): a D2H copy into pageable memory would block the host here
+		if (gpu_sam) {   // the records of the part's qualifying pairs, queued right behind their CIGARs
+			const int r0 = P.lo << 1, nr = (P.hi - P.lo) << 1, nu = P.hi - P.lo;
+			SamDesc *d_desc = (SamDesc *)W.sdesc.ensure((size_t)n * sizeof(SamDesc));
+			int *hb = (int *)W.h_sbase[slot].ensure((size_t)(nu + 1) * 4 + 64);
+			for (int k = 0; k <= nu; ++k) hb[k] = (int)P.base[k];
+			int *d_base = (int *)W.sbase[slot].ensure((size_t)(nu + 1) * 4);
+			P.arena_bytes = (size_t)nr * (size_t)(2 * max_len + 320) + (1 << 20);
+			uint8_t *d_arena = (uint8_t *)W.sarena[slot].ensure(P.arena_bytes);
+			unsigned long long *d_used = (unsigned long long *)W.sused[slot].ensure(64);
+			unsigned long long *d_ooff = (unsigned long long *)W.sooff[slot].ensure((size_t)nr * 8);
+			int *d_olen = (int *)W.solen[slot].ensure((size_t)nr * 4);
+			HIP_OK(hipMemcpyAsync(d_desc + r0, sdesc + r0, (size_t)nr * sizeof(SamDesc), hipMemcpyHostToDevice, P.st));
+			HIP_OK(hipMemcpyAsync(d_base, hb, (size_t)(nu + 1) * 4, hipMemcpyHostToDevice, P.st));
+			HIP_OK(hipMemsetAsync(d_used, 0, 64, P.st));
+			launch_sam_emit(P.st, sam_par, nr, d_desc + r0, d_base, P.d_hdr, P.d_pool, d_seq, d_off + r0, d_len + r0, d_qual, d_names, d_noff + r0,
+			                d_ann_off, d_ann_names, d_ann_noff, d_arena, P.arena_bytes, d_used, d_ooff, d_olen);
+			P.sam_launched = true;
+		}
 	};
 	auto finish = [&](Part &P) {   // wait for B, fetch the pool
 		const size_t n_req = P.req.size();
@@ -1013,18 +1116,53 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		if (used) HIP_OK(hipMemcpyAsync(P.pool, P.d_pool, used, hipMemcpyDeviceToHost, P.st));
 		HIP_OK(hipStreamSynchronize(P.st));
 		STAT.n_aln += n_req;
+		if (P.sam_launched) {
+			const int nr = (P.hi - P.lo) << 1;
+			unsigned long long used = 0;
+			HIP_OK(hipMemcpyAsync(&used, W.sused[P.slot].p, 8, hipMemcpyDeviceToHost, P.st));
+			HIP_OK(hipStreamSynchronize(P.st));
+			used = std::min<unsigned long long>(used, P.arena_bytes);
+			uint8_t *ha = (uint8_t *)W.h_sarena[P.slot].ensure((size_t)used + 64);
+			unsigned long long *ho = (unsigned long long *)W.h_sooff[P.slot].ensure((size_t)nr * 8 + 64);
+			int *hl = (int *)W.h_solen[P.slot].ensure((size_t)nr * 4 + 64);
+			if (used) HIP_OK(hipMemcpyAsync(ha, W.sarena[P.slot].p, (size_t)used, hipMemcpyDeviceToHost, P.st));
+			HIP_OK(hipMemcpyAsync(ho, W.sooff[P.slot].p, (size_t)nr * 8, hipMemcpyDeviceToHost, P.st));
+			HIP_OK(hipMemcpyAsync(hl, W.solen[P.slot].p, (size_t)nr * 4, hipMemcpyDeviceToHost, P.st));
+			HIP_OK(hipStreamSynchronize(P.st));
+			P.sarena = ha; P.sooff = ho; P.solen = hl;
+		}
 		aln_wait_ms += now_ms() - ta;
 	};
 	double emit_ms = 0;
+	std::atomic<unsigned long long> n_sam_dev(0), tsc_devcopy(0);
 	auto replay = [&](Part &P) {   // C
 		const double ta = now_ms(), ca = cpu_sec(), sa_ = sys_sec();
 		const long pf = page_faults();
 		if (pe) {
-			parallel_for(n_thr, P.hi - P.lo, 128, [&](int k) {
-				const int i = P.lo + k;
-				AlnCtx ctx;
-				if (gpu_aln) { ctx.mode = AlnCtx::REPLAY; ctx.hdr = P.hdr; ctx.pool = P.pool; ctx.cursor = P.base[k]; }
-				sam_pe_emit(opt, bns, pac, pes, &seqs[i << 1], &regs[i << 1], plans[i], gpu_aln ? &ctx : nullptr, i << 1);
+			// per-block counters: a shared atomic bumped once per pair costs more than copying the pair's two records
+			parallel_blocks(n_thr, P.hi - P.lo, 128, [&](int, int, int k_lo, int k_hi) {
+				unsigned long long n_dev = 0, tsc = 0;
+				for (int k = k_lo; k < k_hi; ++k) {
+					const int i = P.lo + k;
+					if (P.solen && P.solen[2 * k] >= 0 && P.solen[2 * k + 1] >= 0) {   // both records were written by sam_kernel
+						const unsigned long long tq0 = s_cpusec ? __builtin_ia32_rdtsc() : 0;
+						for (int e = 0; e < 2; ++e) {
+							const int len = P.solen[2 * k + e];
+							char *sam = (char *)malloc((size_t)len + 1);   // ownership passes to the caller, who free()s it
+							if (!sam) die("out of memory");
+							memcpy(sam, P.sarena + P.sooff[2 * k + e], (size_t)len);
+							sam[len] = 0;
+							seqs[(i << 1) + e].sam = sam;
+						}
+						n_dev += 2;
+						if (s_cpusec) tsc += __builtin_ia32_rdtsc() - tq0;
+						continue;
+					}
+					AlnCtx ctx;
+					if (gpu_aln) { ctx.mode = AlnCtx::REPLAY; ctx.hdr = P.hdr; ctx.pool = P.pool; ctx.cursor = P.base[k]; }
+					sam_pe_emit(opt, bns, pac, pes, &seqs[i << 1], &regs[i << 1], plans[i], gpu_aln ? &ctx : nullptr, i << 1);
+				}
+				n_sam_dev += n_dev; tsc_devcopy += tsc;
 			});
 		} else {
 			parallel_for(n_thr, P.hi - P.lo, 256, [&](int k) {
@@ -1055,9 +1193,10 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		finish(parts[1]); replay(parts[1]);
 	}
 	STAT.plan_ms = plan_ms; STAT.aln_ms = aln_wait_ms; STAT.msw_ms = msw_ms; STAT.emit_ms = emit_ms;
+	STAT.n_sam_dev = n_sam_dev.load();
 	double t8 = now_ms();
 	hprof_report("sam stage");
-	if (s_cpusec) fprintf(stderr, "[plan Mcycles] sam_pe_plan %.0f  emit(collect) %.0f\n", tsc_plan.load() * 1e-6, tsc_emitc.load() * 1e-6);
+	if (s_cpusec) fprintf(stderr, "[plan Mcycles] sam_pe_plan %.0f  emit(collect) %.0f  device-record copy %.0f (%llu records)\n", tsc_plan.load() * 1e-6, tsc_emitc.load() * 1e-6, tsc_devcopy.load() * 1e-6, n_sam_dev.load());
 	if (g_hprof_on || s_cpusec)
 		fprintf(stderr, "[cpu-sec] encode+h2d %.3f  phase1 %.3f  pestat+sam %.3f (msw-collect %.3f, plan+collect %.3f, emit %.3f [sys %.3f, %ld page faults])  total %.3f  sys %.3f  wall %.3f\n",
 		        c1 - c_begin, c6 - c1, cpu_sec() - c6, cpu_msw, cpu_collect, cpu_emit, sys_emit, pf_emit, cpu_sec() - c_begin, sys_sec() - s_begin, (t8 - t_begin) * 1e-3);

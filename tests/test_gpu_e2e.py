@@ -160,6 +160,11 @@ def test_overlapped_sub_batches_and_host_cigar_paths(both, reads_pe, monkeypatch
     assert eng.process(eng.opt(flag=abi.MEM_F_PE), ra) == want
     monkeypatch.setenv("MPIBWA_SUBBATCH", "1")
     assert eng.process(eng.opt(flag=abi.MEM_F_PE), ra) == want
+    assert eng.stats()["n_sam_dev"] > len(want) // 2   # most records of this chunk were written by sam_kernel
+    monkeypatch.setenv("MPIBWA_HOST_SAM", "1")      # every record formatted by the host instead
+    assert eng.process(eng.opt(flag=abi.MEM_F_PE), ra) == want
+    assert eng.stats()["n_sam_dev"] == 0
+    monkeypatch.delenv("MPIBWA_HOST_SAM")
     monkeypatch.setenv("MPIBWA_HOST_CIGAR", "1")
     assert eng.process(eng.opt(flag=abi.MEM_F_PE), ra) == want
     monkeypatch.setenv("MPIBWA_HOST_CHAIN", "1")    # chaining of every read on the host instead of chain_kernel

@@ -39,4 +39,4 @@ for s, e, n in iv:
         k = n.split("(")[0].split("::")[-1][:24]
         per[k] = per.get(k, 0) + (e2 - s2)
 print("busiest 1 s window: GPU busy %.1f %%" % (100.0 * best / W))
-print("kernel ms inside it:", {k: round(v / 1e6, 1) for k, v in sorted(per.items(), key=lambda x: -x[1])[:8]})
+print("kernel ms inside it:", {k: round(v / 1e6, 1) for k, v in sorted(per.items(), key=lambda x: -x[1])[:14]})
