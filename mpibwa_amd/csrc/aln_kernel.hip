@@ -52,9 +52,15 @@ __device__ __forceinline__ int put_num(uint8_t *md, int len, int v, int lane)
 // Three instantiations, launched one after the other.  A classification pass (aln_classify_kernel) sorts the request numbers
 // into one list per kind first, and the waves of a kind walk their list with a grid-sized stride — nobody launches a
 // workgroup per request only to find that the request belongs to another variant.
-//   KIND 0  the requests that need no DP (same length, band 0: src/bwa.c:143-151) — four of five.  No direction matrix, so a
-//           workgroup takes 1.1 KB of LDS instead of 17 KB and the CU holds as many waves as it has slots for; the latency
-//           of the dependent fetches (request -> read offset -> bases) is what such a request costs.
+//   KIND 0  the requests whose query and reference window have the same length.  With band 0 the reference takes its no-DP
+//           shortcut (src/bwa.c:143-151); with a band it runs ksw_global2, but when the ungapped alignment loses no more than
+//           a + (o_del + e_del) + (o_ins + e_ins) against a perfect match — three mismatches under the default scores —
+//           the DP can only return that same alignment, in every round of mem_reg2aln's loop: a path with a gap has an
+//           insertion AND a deletion, so at most lq - 1 aligned columns of at most `a` each, and ksw_global2's traceback
+//           prefers the diagonal move on ties (src/ksw.c:551-554), which keeps it on the main diagonal whenever that is
+//           co-optimal.  Score, CIGAR (lqM), NM and MD are then those of the ungapped alignment, and the wave writes them
+//           without a direction matrix: 1.1 KB of LDS instead of 17 KB, as many waves as the CU has slots for.  The
+//           same-length requests that lose more are appended to the DP list.
 //   KIND 1  DP with a direction matrix of at most 32 columns per row (8.7 KB of LDS per wave: 16 waves per CU instead of 9 —
 //           a row is a chain of dependent LDS and cross-lane steps, so the waves per SIMD set the rate).  A request whose
 //           band outgrows that in one of mem_reg2aln's rounds is marked (flags = 2) and left to
@@ -70,13 +76,12 @@ __device__ __forceinline__ bool aln_invalid(const AlnParams &P, const AlnReq &R,
 	const bool bridging = R.rb < P.l_pac && R.re > P.l_pac;
 	return lq <= 0 || rlen64 <= 0 || bridging || lq > max_len || rlen64 > tcap;
 }
-__device__ __forceinline__ bool aln_no_dp(const AlnParams &P, const AlnReq &R, int max_len, int tcap)
+__device__ __forceinline__ bool aln_same_len(const AlnParams &P, const AlnReq &R, int max_len, int tcap)
 {
-	// stays so in every round of mem_reg2aln's loop
-	return !aln_invalid(P, R, max_len, tcap) && R.re - R.rb == R.qe - R.qb && (R.w2 < (P.w << 2) ? R.w2 : (P.w << 2)) == 0;
+	return !aln_invalid(P, R, max_len, tcap) && R.re - R.rb == R.qe - R.qb;
 }
 
-// request numbers -> lists[0 .. n_req) (no DP) and lists[n_req .. 2 n_req) (DP); one atomic per wave and list
+// request numbers -> lists[0 .. n_req) (same length: no DP, or not yet known) and the DP list; one atomic per wave and list
 // dp_kind: the list DP requests start in (1 = narrow variant first, the product's dispatch; 2 = straight to the full-size one)
 __global__ void __launch_bounds__(256) aln_classify_kernel(AlnParams P, int n_req, const AlnReq *__restrict__ reqs, int max_len, int tcap,
                                                            int *__restrict__ lists, unsigned long long *counters, int dp_kind)
@@ -84,7 +89,7 @@ __global__ void __launch_bounds__(256) aln_classify_kernel(AlnParams P, int n_re
 	const int rq = blockIdx.x * 256 + threadIdx.x;
 	const bool live = rq < n_req;
 	bool nodp = false;
-	if (live) nodp = aln_no_dp(P, reqs[rq], max_len, tcap);
+	if (live) nodp = aln_same_len(P, reqs[rq], max_len, tcap);
 	const unsigned long long below = (1ull << (threadIdx.x & 63)) - 1;
 	for (int pass = 0; pass < 2; ++pass) {
 		const bool mine = live && (nodp == (pass == 0));
@@ -102,7 +107,7 @@ template <int KIND>
 __device__ __forceinline__ void aln_one(int rq, const AlnParams &P, const WxParams &X, int n_req, const AlnReq *__restrict__ reqs,
                                         const uint8_t *__restrict__ seq, const int64_t *__restrict__ off, const uint8_t *__restrict__ pac,
                                         const int *__restrict__ gaptab, AlnHdr *__restrict__ hdr, uint8_t *__restrict__ pool,
-                                        unsigned long long *counters, unsigned long long pool_bytes, int max_len, int tcap, int *lists)
+                                        unsigned long long *counters, unsigned long long pool_bytes, int max_len, int tcap, int *lists, int dp_kind)
 {
 	extern __shared__ int lds_raw[];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -182,10 +187,18 @@ __device__ __forceinline__ void aln_one(int rq, const AlnParams &P, const WxPara
 	bool fallback = false;
 	for (int it = 0;; ) {
 		w2 = w2 < wmax4 ? w2 : wmax4;
-		if (FAST) {   // ungapped: no DP (src/bwa.c:143-151); lq == rlen && w2 == 0
+		if (FAST) {   // ungapped: lq == rlen, and either w2 == 0 (src/bwa.c:143-151) or the DP cannot do better (see above)
 			int s = 0;
 			for (int i = lane; i < lq; i += 64) s += X.mat[L.t[i] * 5 + L.q[i]];
 			score = wave_sum_int(s);
+			if (w2 != 0) {
+				int amax = X.mat[0];
+				for (int k = 1; k < 25; ++k) amax = X.mat[k] > amax ? X.mat[k] : amax;
+				if (amax <= 0 || (long long)lq * amax - score > (long long)amax + oe_del + oe_ins) {   // the DP decides: to its list
+					if (lane == 0) lists[(size_t)dp_kind * n_req + atomicAdd(&counters[ALN_CNT + dp_kind], 1ull)] = rq;
+					return;
+				}
+			}
 			n_cig = 1;
 			if (lane == 0) L.cig[0] = (uint32_t)lq << 4;
 			// the other lanes read it below: without this the compiler sinks their load into the else-side of the
@@ -362,14 +375,14 @@ template <int KIND>
 __global__ void __launch_bounds__(64 * ALN_WAVES)
 aln_kernel(AlnParams P, WxParams X, int n_req, const AlnReq *__restrict__ reqs, const uint8_t *__restrict__ seq,
            const int64_t *__restrict__ off, const uint8_t *__restrict__ pac, const int *__restrict__ gaptab, AlnHdr *__restrict__ hdr,
-           uint8_t *__restrict__ pool, unsigned long long *counters, unsigned long long pool_bytes, int max_len, int tcap, int *lists)
+           uint8_t *__restrict__ pool, unsigned long long *counters, unsigned long long pool_bytes, int max_len, int tcap, int *lists, int dp_kind)
 {
 	const int wave = threadIdx.x >> 6;
-	// KIND 2's list is filled by the KIND 1 launch before this one on the stream
+	// the lists of KIND 1 and 2 are added to by the launches before them on the stream
 	const int n = (int)counters[ALN_CNT + KIND];
 	const int *mine = lists + (size_t)KIND * n_req;
 	for (int k = blockIdx.x * ALN_WAVES + wave; k < n; k += gridDim.x * ALN_WAVES) {
-		aln_one<KIND>(KIND != 0 ? __builtin_amdgcn_readfirstlane(mine[k]) : mine[k], P, X, n_req, reqs, seq, off, pac, gaptab, hdr, pool, counters, pool_bytes, max_len, tcap, lists);
+		aln_one<KIND>(KIND != 0 ? __builtin_amdgcn_readfirstlane(mine[k]) : mine[k], P, X, n_req, reqs, seq, off, pac, gaptab, hdr, pool, counters, pool_bytes, max_len, tcap, lists, dp_kind);
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the wave's LDS slice is reused by its next request
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -418,11 +431,11 @@ void launch_aln(void *stream, const AlnParams &P, const ExtParams &ep, int n_req
 	hipLaunchKernelGGL(aln_classify_kernel, dim3((n_req + 255) / 256), dim3(256), 0, st, P, n_req, d_req, max_len, tcap, d_lists, d_counters,
 	                   wide_only ? 2 : 1);
 	hipLaunchKernelGGL(aln_kernel<0>, grid_for(shmem_fast), block, shmem_fast, st, P, X, n_req, d_req, d_seq, d_off, d_pac, d_gaptab, d_hdr, d_pool,
-	                   d_counters, (unsigned long long)pool_bytes, max_len, tcap, d_lists);
+	                   d_counters, (unsigned long long)pool_bytes, max_len, tcap, d_lists, wide_only ? 2 : 1);
 	hipLaunchKernelGGL(aln_kernel<1>, grid_for(shmem_small), block, shmem_small, st, P, X, n_req, d_req, d_seq, d_off, d_pac, d_gaptab, d_hdr, d_pool,
-	                   d_counters, (unsigned long long)pool_bytes, max_len, tcap, d_lists);
+	                   d_counters, (unsigned long long)pool_bytes, max_len, tcap, d_lists, wide_only ? 2 : 1);
 	hipLaunchKernelGGL(aln_kernel<2>, grid_for(shmem), block, shmem, st, P, X, n_req, d_req, d_seq, d_off, d_pac, d_gaptab, d_hdr, d_pool,
-	                   d_counters, (unsigned long long)pool_bytes, max_len, tcap, d_lists);
+	                   d_counters, (unsigned long long)pool_bytes, max_len, tcap, d_lists, wide_only ? 2 : 1);
 	if (hipGetLastError() != hipSuccess) die("aln_kernel: launch failed");
 }
 

@@ -1109,6 +1109,11 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		HIP_OK(hipMemcpyAsync(P.cnt, P.d_cnt, 64, hipMemcpyDeviceToHost, P.st));
 		HIP_OK(hipStreamSynchronize(P.st));
 		STAT.k_aln_ms += P.ev.ms();
+		if (s_cpusec) {
+			unsigned long long c[16];
+			HIP_OK(hipMemcpy(c, P.d_cnt, sizeof c, hipMemcpyDeviceToHost));
+			fprintf(stderr, "[aln lists] %zu requests: same-length %llu, narrow DP %llu, full DP %llu\n", n_req, c[8], c[9], c[10]);
+		}
 		size_t used = std::min<size_t>(P.cnt[0], P.pool_bytes);
 		P.hdr = (AlnHdrH *)W.h_ahdr[P.slot].ensure(n_req * sizeof(AlnHdr) + 64);
 		P.pool = (uint8_t *)W.h_apool[P.slot].ensure(used + 64);

@@ -22,6 +22,11 @@ def _flatten(reads):
     return out
 
 
+def _rc(a):
+    a = np.asarray(a, np.uint8)
+    return np.where(a > 3, 4, 3 - a)[::-1].astype(np.uint8)
+
+
 def test_smem_kernel_matches_oracle(engine, genome, reads_pe, reads_var):
     fm = po.OracleFM(genome["prefix"])
     seqs = _flatten(reads_pe) + _flatten(reads_var)
@@ -29,6 +34,14 @@ def test_smem_kernel_matches_oracle(engine, genome, reads_pe, reads_var):
     seqs += [np.array([0, 1, 2, 3] * 4, np.uint8), np.full(40, 4, np.uint8), np.zeros(150, np.uint8),
              np.concatenate([g[1000:1060], [4], g[1061:1150]]).astype(np.uint8), g[5000:5019].astype(np.uint8),
              np.where(g[9000:9400] > 3, 0, g[9000:9400]).astype(np.uint8)]
+    # the ends of the text and the junction between the strands (the text is the reference followed by its reverse complement)
+    first, last = np.asarray(genome["seqs"][0], np.uint8), np.asarray(genome["seqs"][-1], np.uint8)
+    if (first[:300] < 4).all() and (last[-300:] < 4).all():
+        head, tail = first[:150], last[-150:]
+        seqs += [head, _rc(head), tail, _rc(tail), first[:260], _rc(last[-260:]),
+                 np.concatenate([last[-75:], _rc(last[-75:])]), np.concatenate([_rc(first[:75]), first[:75]]),
+                 np.concatenate([last[-140:], _rc(last[-10:])]), np.concatenate([last[-200:], _rc(last[-100:])]),
+                 np.concatenate([[1], head[1:]]).astype(np.uint8), np.concatenate([tail[:-1], [2]]).astype(np.uint8)]
     opt = engine.opt()
     fm.reset_counters()
     got, ms, nbytes = engine.smem(opt, seqs, cap=512)
@@ -42,8 +55,8 @@ def test_smem_kernel_matches_oracle(engine, genome, reads_pe, reads_var):
         assert a.shape == b.shape, (len(s), a.shape, b.shape)
         assert (a == b).all()
         total_in += len(s)
-    # the device's own count of occ blocks equals the oracle's instrumented count (SURVEY §8d definition)
     n_intv = sum(len(a) for a in got)
+    # the device's own count of occ blocks equals the oracle's instrumented count (SURVEY §8d definition)
     assert nbytes == fm.fm.n_blocks * 64 + total_in + 32 * n_intv
 
 
@@ -321,11 +334,13 @@ def _pack2bit(ref):
 
 
 @pytest.mark.skipif(not po.ref_available(), reason="oracle/_ref/libbwaref.so not present")
-@pytest.mark.parametrize("which", [0, 1])
-def test_aln_kernel_matches_the_reference_gen_cigar2(engine, which):
+@pytest.mark.parametrize("which,scoring", [(0, None), (1, None), (0, (2, 2, 3, 1, 5, 2)), (0, (1, 9, 2, 1, 2, 1))])
+def test_aln_kernel_matches_the_reference_gen_cigar2(engine, which, scoring):
     """aln_kernel (all three instantiations: no-DP, narrow band with hand-off, full size) vs the reference's bwa_gen_cigar2
-    under mem_reg2aln's band-doubling loop (src/bwa.c:121-207, src/bwamem.c:1110-1120): score, NM, CIGAR, MD."""
-    rng = np.random.default_rng(31 + which)
+    under mem_reg2aln's band-doubling loop (src/bwa.c:121-207, src/bwamem.c:1110-1120): score, NM, CIGAR, MD.
+    The same-length requests with a band are answered without DP when the ungapped alignment cannot be beaten (aln_kernel.hip);
+    the other scoring schemes move that bound (a, b, o_del, e_del, o_ins, e_ins): 2 mismatches / none instead of 3."""
+    rng = np.random.default_rng(31 + which + (0 if scoring is None else 7 * scoring[1]))
     l_pac = 60000
     ref_seq = rng.integers(0, 4, size=l_pac).astype(np.uint8)
     ref_seq[7000:7400] = np.tile(ref_seq[7000:7004], 100)        # tandem repeat: gap placement must match
@@ -334,6 +349,10 @@ def test_aln_kernel_matches_the_reference_gen_cigar2(engine, which):
     ri = po.RefIndex.__new__(po.RefIndex)
     ri.lib = po.ref_lib()
     opt = engine.opt()
+    if scoring is not None:
+        o = opt.contents
+        o.a, o.b, o.o_del, o.e_del, o.o_ins, o.e_ins = scoring
+        engine.lib.bwa_fill_scmat(o.a, o.b, o.mat)
     reads, rb, re, qb, qe, w2, truesc = [], [], [], [], [], [], []
     for i in range(1500):
         lq = int(rng.choice([30, 76, 100, 150, 151, 250]))
@@ -359,7 +378,7 @@ def test_aln_kernel_matches_the_reference_gen_cigar2(engine, which):
             at1, at2 = sorted(int(x) for x in rng.integers(5, lq - 5, size=2))
             g = int(rng.integers(1, 6))
             q = np.concatenate([t[:at1], t[at1 + g:at2], rng.integers(0, 4, size=g).astype(np.uint8), t[at2:lq]])[:lq]
-        mm = rng.random(len(q)) < float(rng.choice([0, 0.01, 0.05]))
+        mm = rng.random(len(q)) < float(rng.choice([0, 0.01, 0.02, 0.05]))
         q[mm] = (q[mm] + 1) & 3
         if rng.random() < 0.05:
             q[int(rng.integers(0, len(q)))] = 4
@@ -375,13 +394,16 @@ def test_aln_kernel_matches_the_reference_gen_cigar2(engine, which):
         sc, cig, nm, md = ri.reg2aln_loop(opt, l_pac, pac, reads[i][qb[i]:qe[i]], rb[i], re[i], w2[i], truesc[i])
         if hdr[i, 4] != 0:     # band matrix beyond the LDS budget of the full-size instantiation: left to the library's host code
             n_declined += 1
-            assert (w2[i] >= 40 or abs((re[i] - rb[i]) - (qe[i] - qb[i])) >= 20) and qe[i] - qb[i] >= 140, (i, hdr[i], w2[i])
+            # (with cheap gaps and a 9-point mismatch an early, narrow round can need more CIGAR operations than the kernel
+            # keeps — 75 mismatches become 75 insertion + deletion pairs — although the last round needs nine: also declined)
+            if scoring is None:
+                assert (w2[i] >= 40 or abs((re[i] - rb[i]) - (qe[i] - qb[i])) >= 20) and qe[i] - qb[i] >= 140, (i, hdr[i], w2[i])
             continue
         assert cig is not None
         assert (hdr[i, 0], hdr[i, 1]) == (sc, nm), (i, hdr[i], sc, nm, w2[i])
         assert (cigs[i] == cig).all() and mds[i] == md, (i, cigs[i], cig, mds[i], md)
         n_dp += len(cig) > 1
-    assert n_dp > 500 and n_declined < 120
+    assert n_dp > 500 and n_declined < (120 if scoring is None else 300)
 
 
 def test_aln_kernel_on_golden_ksw_global2_vectors(engine):
