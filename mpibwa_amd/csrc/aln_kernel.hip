@@ -221,10 +221,14 @@ __device__ __forceinline__ void aln_one(int rq, const AlnParams &P, const WxPara
 				L.E[j] = ALN_NEG;
 			}
 			__builtin_amdgcn_wave_barrier();
+			int vslo = 0, vshi = 0;   // the scoring-matrix rows of the next 64 target bases, one per lane (as in wave_ext.cuh)
 			for (int i = 0; i < rlen; ++i) {
-				const int tb = __builtin_amdgcn_readfirstlane((int)L.t[i]);
-				const uint32_t slo = tb == 0 ? plo[0] : tb == 1 ? plo[1] : tb == 2 ? plo[2] : tb == 3 ? plo[3] : plo[4];
-				const uint32_t shi = tb == 0 ? phi[0] : tb == 1 ? phi[1] : tb == 2 ? phi[2] : tb == 3 ? phi[3] : phi[4];
+				if ((i & 63) == 0) {
+					const int tb = i + lane < rlen ? (int)L.t[i + lane] : 4;
+					vslo = (int)(tb == 0 ? plo[0] : tb == 1 ? plo[1] : tb == 2 ? plo[2] : tb == 3 ? plo[3] : plo[4]);
+					vshi = (int)(tb == 0 ? phi[0] : tb == 1 ? phi[1] : tb == 2 ? phi[2] : tb == 3 ? phi[3] : phi[4]);
+				}
+				const uint32_t slo = (uint32_t)__builtin_amdgcn_readlane(vslo, i & 63), shi = (uint32_t)__builtin_amdgcn_readlane(vshi, i & 63);
 				const int beg = i > w ? i - w : 0, end = i + w + 1 < lq ? i + w + 1 : lq;
 				const int hleft0 = beg == 0 ? -(X.o_del + e_del * (i + 1)) : ALN_NEG;
 				int A = ALN_NEG;   // running max of g_k + e_ins over the columns already done (F(i,beg) = -inf)

@@ -70,18 +70,36 @@ c2a_kernel(C2aParams P, WxParams X, int n_reads, const uint8_t *__restrict__ seq
 	if (slot >= n_reads) return;
 	// reads with the most seeds are started first, so that the kernel does not end on a few long-running reads
 	const int rd = uni(order ? order[slot] : slot);
-	int *H = lds + (size_t)wave * 2 * (max_len + 2);
-	int *E = H + (max_len + 2);
+	const WxLds L = wx_lds(lds + (size_t)wave * wx_lds_ints(max_len), max_len);
 	const int *gap = tab, *bound5 = tab + tab_stride, *bound3 = tab + 2 * tab_stride, *ceil95 = tab + 3 * tab_stride,
 	          *thr10 = tab + 4 * tab_stride;
 	const uint8_t *q = seq + off[rd];
 	const int lq = uni(lens[rd]);
 	DevReg *av = regs + reg_beg[rd];
 	int nav = 0;
-	unsigned long long cells = 0, n_ext = 0;
+	unsigned long long cells = 0, n_ext = 0, n_diff = 0;
 	const i64 l_pac = P.l_pac;
 	int max_sc = 1;   // largest entry of the scoring matrix: what one more column can add at most
 	for (int t = 0; t < 25; ++t) max_sc = X.mat[t] > max_sc ? X.mat[t] : max_sc;
+
+	// one ksw_extend2.  P.early: 1 = stop a row loop as soon as nothing the code below reads can change (wave_ext.cuh);
+	// 0 = every row the reference computes; 2 = both, and count the extensions whose used outputs differ
+	auto extend = [&](int qlen, auto qf, int tlen, auto tf, int wc, int h0, int clip) -> WxResult {
+		++n_ext;
+		for (int j = lane; j < qlen; j += 64) L.Qs[j] = (uint8_t)qf(j);
+		__builtin_amdgcn_wave_barrier();
+		if (P.early == 0) return wave_extend<false>(qlen, tlen, tf, X, wc, h0, L, cells, max_sc);
+		const WxResult r = wave_extend<true>(qlen, tlen, tf, X, wc, h0, L, cells, max_sc, clip);
+		if (P.early == 2) {
+			unsigned long long c2 = 0;
+			const WxResult f = wave_extend<false>(qlen, tlen, tf, X, wc, h0, L, c2, max_sc);
+			const bool loc_r = r.gscore <= 0 || r.gscore <= r.score - clip, loc_f = f.gscore <= 0 || f.gscore <= f.score - clip;
+			bool same = f.score == r.score && f.qle == r.qle && f.tle == r.tle && f.max_off == r.max_off && loc_r == loc_f;
+			if (same && !loc_f) same = f.gtle == r.gtle && f.gscore == r.gscore;
+			if (!same) ++n_diff;
+		}
+		return r;
+	};
 
 	const int ci_beg = uni(chain_beg[rd]), ci_cnt = uni(chain_cnt[rd]);
 	const int ci_end = ci_beg + (ci_cnt > 0 ? ci_cnt : 0);
@@ -173,9 +191,7 @@ c2a_kernel(C2aParams P, WxParams X, int n_reads, const uint8_t *__restrict__ seq
 					int prev = a.score;
 					aw0 = P.w << i;
 					int wc = aw0 < bound5[qlen] ? aw0 : bound5[qlen];
-					r = wave_extend<true>(qlen, [&](int j) { return q[s.qbeg - 1 - j]; }, tlen,
-					                      [&](int t) { return ref_base(pac, l_pac, s.rbeg - 1 - t); }, X, wc, s.len * P.a, H, E, cells, max_sc);
-					++n_ext;
+					r = extend(qlen, [&](int j) { return q[s.qbeg - 1 - j]; }, tlen, [&](int t) { return ref_base(pac, l_pac, s.rbeg - 1 - t); }, wc, s.len * P.a, P.pen_clip5);
 					a.score = r.score;
 					if (a.score == prev || r.max_off < (aw0 >> 1) + (aw0 >> 2)) break;
 				}
@@ -194,9 +210,7 @@ c2a_kernel(C2aParams P, WxParams X, int n_reads, const uint8_t *__restrict__ seq
 					int prev = a.score;
 					aw1 = P.w << i;
 					int wc = aw1 < bound3[qlen] ? aw1 : bound3[qlen];
-					r = wave_extend<true>(qlen, [&](int j) { return q[qe + j]; }, tlen,
-					                      [&](int t) { return ref_base(pac, l_pac, s.rbeg + s.len + t); }, X, wc, sc0, H, E, cells, max_sc);
-					++n_ext;
+					r = extend(qlen, [&](int j) { return q[qe + j]; }, tlen, [&](int t) { return ref_base(pac, l_pac, s.rbeg + s.len + t); }, wc, sc0, P.pen_clip3);
 					a.score = r.score;
 					if (a.score == prev || r.max_off < (aw1 >> 1) + (aw1 >> 2)) break;
 				}
@@ -223,6 +237,7 @@ c2a_kernel(C2aParams P, WxParams X, int n_reads, const uint8_t *__restrict__ seq
 		n_regs[rd] = nav;
 		atomicAdd(&counters[0], cells);
 		atomicAdd(&counters[1], n_ext);
+		if (n_diff) atomicAdd(&counters[3], n_diff);
 	}
 }
 
@@ -234,7 +249,7 @@ void launch_c2a(void *stream, const C2aParams &P, const ExtParams &ep, int n_rea
 	WxParams X;
 	for (int i = 0; i < 25; ++i) X.mat[i] = ep.mat[i];
 	X.o_del = ep.o_del; X.e_del = ep.e_del; X.o_ins = ep.o_ins; X.e_ins = ep.e_ins; X.zdrop = ep.zdrop;
-	size_t shmem = (size_t)C2A_WAVES * 2 * (max_len + 2) * sizeof(int);
+	size_t shmem = (size_t)C2A_WAVES * wx_lds_ints(max_len) * sizeof(int);
 	int n_blocks = (n_reads + C2A_WAVES - 1) / C2A_WAVES;
 	hipLaunchKernelGGL(c2a_kernel, dim3(n_blocks), dim3(64 * C2A_WAVES), shmem, (hipStream_t)stream, P, X, n_reads, d_seq, d_off,
 	                   d_len, d_chain_beg, d_chain_cnt, d_chains, d_seeds, d_srt, d_reg_beg, d_regs, d_nregs, d_tab, tab_stride, d_pac, d_counters,

@@ -144,6 +144,8 @@ static void parallel_blocks(int n_threads, int n, int chunk, F f)
 	for (auto &t : th) t.join();
 }
 
+// MPIBWA_C2A_EARLY: 1 (default) the extension row loops stop early, 0 they run the reference's rows, 2 both with a fatal error on any difference
+static int c2a_early_mode() { static const int m = getenv("MPIBWA_C2A_EARLY") ? atoi(getenv("MPIBWA_C2A_EARLY")) : 1; return m; }
 static std::mutex g_smem_turn, g_c2a_turn_own, g_pes_lock;
 // MPIBWA_BIG_TURN=1: the two chip-filling kernels (seeding, extension) of all calls take turns on ONE mutex instead of one each
 static std::mutex &c2a_turn() { static const bool one = getenv("MPIBWA_BIG_TURN") != nullptr && atoi(getenv("MPIBWA_BIG_TURN")) != 0; return one ? g_smem_turn : g_c2a_turn_own; }
@@ -701,6 +703,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			HIP_OK(hipMemcpyAsync(d_order, order, (size_t)n * 4, hipMemcpyHostToDevice, st));
 			C2aParams cp;
 			cp.l_pac = bns->l_pac; cp.a = opt->a; cp.w = opt->w; cp.pen_clip5 = opt->pen_clip5; cp.pen_clip3 = opt->pen_clip3;
+			cp.early = c2a_early_mode();
 			ExtParams ep;
 			memcpy(ep.mat, opt->mat, 25);
 			ep.o_del = opt->o_del; ep.e_del = opt->e_del; ep.o_ins = opt->o_ins; ep.e_ins = opt->e_ins; ep.zdrop = opt->zdrop;
@@ -727,6 +730,8 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			turn.unlock();
 			ps.k_ext = ev_ext.ms();
 			ps.cells = cnt[0]; ps.n_ext = cnt[1];
+			if (cp.early == 2 && cnt[3]) die("c2a_kernel: %llu of %llu extensions change when their row loops stop early", cnt[3], cnt[1]);
+			if (getenv("MPIBWA_CPUSEC")) fprintf(stderr, "[c2a] %llu extensions, %llu cells\n", cnt[1], cnt[0]);
 			for (int i = 0; i < n; ++i) reg_pos[i + 1] = reg_pos[i] + nregs[i];
 			const int64_t NR = reg_pos[n];
 			if (NR > guess) {

@@ -56,24 +56,52 @@ struct WxParams {
 
 struct WxResult { int score, qle, tle, gtle, gscore, max_off; };
 
-// QF(j)  -> query base 0..4 at column j  (evaluated per lane)
-// TF(i)  -> target base 0..4 at row i    (evaluated per lane for prefetching 64 rows at a time)
-// H, E   -> LDS (or global) arrays of qlen+1 ints owned by this wave
+// LDS of one wave: H and E (qlen + 2 cells, and a strip of pad so that the lanes of a row read and write a full strip without
+// bounds tests), the query bases (staged by the caller: one byte per column, + pad), and one write-only cell.
+struct WxLds { int *H, *E; uint8_t *Qs; int *dummy; };
+__host__ __device__ inline int wx_lds_ints(int max_qlen) { return 2 * (max_qlen + 2 + 64) + ((max_qlen + 64 + 3) >> 2) + 1; }
+__device__ __forceinline__ WxLds wx_lds(int *base, int max_qlen)
+{
+	WxLds L;
+	L.H = base; L.E = L.H + (max_qlen + 2 + 64);
+	L.Qs = (uint8_t *)(L.E + (max_qlen + 2 + 64));
+	L.dummy = (int *)(L.Qs + ((max_qlen + 64 + 3) & ~3));
+	return L;
+}
+
+// L.Qs[j] -> query base 0..4 at column j (staged by the caller)
+// TF(i)   -> target base 0..4 at row i    (evaluated per lane, 64 rows at a time)
 // `w` must already be clamped like src/ksw.c:395-407 (see wx_clamp_band on the host side).
 //
-// EARLY: stop as soon as no later row can change any output.  Every alignment path that reaches a later row leaves row i
-// through one of the stored cells — diagonally from eh[j].h into column j, or vertically from eh[j].e in column j — and
-// gains at most max_sc per remaining column, so
+// A row is worked in strips of 64 lanes counted from its first live column `beg`.  Lane L of a strip owns column
+// j = beg + L: it reads eh[j] = {H(i-1,j-1), E(i,j)}, and writes eh[j].h = h of column j - 1 (lane 0 of the row: the first-column
+// value h1 of src/ksw.c:420-424; the lane one past the last column: eh[end].h, src/ksw.c:447) and eh[j].e = its own E(i+1,j)
+// (one past the last column: 0) — so a strip reads and writes the same 64 cells, strips never touch each other's, and no
+// lane needs a bounds test: what lies past the row goes to the write-only cell.  The scoring-matrix rows of the next 64
+// target bases sit one per lane, a row takes its own with two v_readlane.  (The row loop was bound by the scalar unit:
+// 250 scalar instructions per row against 100 vector ones; this form has 50.)
+//
+// EARLY: stop as soon as no later row can change any output the caller uses.  Every alignment path that reaches a later row
+// leaves row i through one of the stored cells — diagonally from eh[j].h into column j, or vertically from eh[j].e in column j
+// — and gains at most max_sc per remaining column, so
 //     B = max_j max(eh[j].h + (qlen - j) * max_sc,  eh[j].e + (qlen - 1 - j) * max_sc)        (stale cells included)
-// bounds every later H, in particular every later row maximum and every later score at the query end.  When B <= max
-// and B < gscore the reference's remaining rows update neither (max, max_i, max_j, max_off) nor (gscore, max_ie); it only
-// goes on until the scores have decayed to zero, typically for as many rows again as the alignment itself.  The test
-// runs every 4th row once the query end has been reached.  Off: the row count (and the cell counter) match the reference.
-template <bool EARLY = false, typename QF, typename TF>
-__device__ __forceinline__ WxResult wave_extend(int qlen, QF qf, int tlen, TF tf, const WxParams &P, int w, int h0,
-                                                int *H, int *E, unsigned long long &cells, int max_sc = 1)
+// bounds every later H, in particular every later row maximum and every later score at the query end.
+//   (1) B <= max and B < gscore: the reference's remaining rows update neither (max, max_i, max_j, max_off) nor
+//       (gscore, max_ie); it only goes on until the scores have decayed to zero, typically for as many rows again as the
+//       alignment itself.
+//   (2) B <= max - clip and gscore <= max - clip (clip = the caller's clipping penalty, src/bwamem.c:722,755): the best cell is
+//       final, and whatever the score at the query end becomes it stays at or below max - clip, so the caller takes its
+//       local-alignment branch and reads score, qle, tle and max_off only — gscore and gtle may differ from the reference's,
+//       nobody looks.  This is what ends the extensions into sequence that does not match (a chimeric or clipped read, a
+//       seed in the wrong copy of a repeat): the reference computes rows until a score of ~100 has decayed to zero.
+// The test runs every 4th row once it can succeed.  Off (the default): row count, cell count and all six outputs are the reference's.
+template <bool EARLY = false, typename TF>
+__device__ __forceinline__ WxResult wave_extend(int qlen, int tlen, TF tf, const WxParams &P, int w, int h0, const WxLds &L,
+                                                unsigned long long &cells, int max_sc = 1, int clip = 0x3fffffff)
 {
 	const int lane = threadIdx.x & 63;
+	int *const H = L.H, *const E = L.E;
+	const uint8_t *const Qs = L.Qs;
 	// The extension's shape is the same in every lane, but it was read through vector loads: pin it to scalar registers,
 	// or the row loop's whole bookkeeping (band limits, live range, strip counts, loop tests) is compiled into vector
 	// instructions with exec-mask branches around them.
@@ -82,6 +110,7 @@ __device__ __forceinline__ WxResult wave_extend(int qlen, QF qf, int tlen, TF tf
 	w = __builtin_amdgcn_readfirstlane(w);
 	h0 = __builtin_amdgcn_readfirstlane(h0);
 	max_sc = __builtin_amdgcn_readfirstlane(max_sc);
+	clip = __builtin_amdgcn_readfirstlane(clip);
 	const int oe_del = P.o_del + P.e_del, oe_ins = P.o_ins + P.e_ins, e_del = P.e_del, e_ins = P.e_ins;
 	// first row (src/ksw.c:389-393)
 	for (int j = lane; j <= qlen; j += 64) {
@@ -99,9 +128,10 @@ __device__ __forceinline__ WxResult wave_extend(int qlen, QF qf, int tlen, TF tf
 	__builtin_amdgcn_wave_barrier();
 	int best = h0, best_i = -1, best_j = -1, best_ie = -1, gscore = -1, max_off = 0;
 	int beg = 0, end = qlen;
-	int tv = 0, tv_base = -64;
-	// the five rows of the scoring matrix as packed bytes in scalar registers: byte q of {hi, lo} = mat[t][q], so the
-	// score of a cell is one v_perm_b32 (+ sign extension) instead of a chain of four compares and selects
+	int tv_base = -64;
+	// the five rows of the scoring matrix as packed bytes: byte q of {hi, lo} = mat[t][q], so the score of a cell is one
+	// v_perm_b32 (+ sign extension) instead of a chain of four compares and selects
+	int vslo = 0, vshi = 0;
 	uint32_t plo[5], phi[5];
 #pragma unroll
 	for (int t = 0; t < 5; ++t) {
@@ -110,74 +140,66 @@ __device__ __forceinline__ WxResult wave_extend(int qlen, QF qf, int tlen, TF tf
 		phi[t] = (uint32_t)(uint8_t)P.mat[t * 5 + 4];
 	}
 	for (int i = 0; i < tlen; ++i) {
-		if (i - tv_base >= 64) { tv_base = i; tv = (i + lane < tlen) ? (int)tf(i + lane) : 4; }
-		const int tb = __builtin_amdgcn_readlane(tv, i - tv_base);
-		const uint32_t slo = tb == 0 ? plo[0] : tb == 1 ? plo[1] : tb == 2 ? plo[2] : tb == 3 ? plo[3] : plo[4];
-		const uint32_t shi = tb == 0 ? phi[0] : tb == 1 ? phi[1] : tb == 2 ? phi[2] : tb == 3 ? phi[3] : phi[4];
+		if (i - tv_base >= 64) {
+			tv_base = i;
+			const int tb = (i + lane < tlen) ? (int)tf(i + lane) : 4;
+			vslo = (int)(tb == 0 ? plo[0] : tb == 1 ? plo[1] : tb == 2 ? plo[2] : tb == 3 ? plo[3] : plo[4]);
+			vshi = (int)(tb == 0 ? phi[0] : tb == 1 ? phi[1] : tb == 2 ? phi[2] : tb == 3 ? phi[3] : phi[4]);
+		}
+		const uint32_t slo = (uint32_t)__builtin_amdgcn_readlane(vslo, i - tv_base), shi = (uint32_t)__builtin_amdgcn_readlane(vshi, i - tv_base);
 		if (beg < i - w) beg = i - w;
 		if (end > i + w + 1) end = i + w + 1;
 		if (end > qlen) end = qlen;
 		int hleft0 = 0;
 		if (beg == 0) { hleft0 = h0 - (P.o_del + e_del * (i + 1)); if (hleft0 < 0) hleft0 = 0; }
-		int rowkey = -1;                           // (row maximum) << 13 | its largest column
-		int lanekey = -1;                          // ... per lane over the strips of the row; one wave reduction per row
+		const int n_col = end - beg;               // negative: the band has moved past the live cells, the row is empty
+		int lanekey = -1;                          // (h << 13 | column), per lane over the strips of the row
 		int A = beg * e_ins;                       // F(i,beg) = 0
-		int h_carry = 0, h_last = hleft0;          // h of column 64*s-1; H[end] after the row
+		int h_carry = hleft0, h_last = hleft0;     // h of the column before the strip; h of the row's last column
 		int first_nz = end, last_nz = -1;          // first / last cell of [beg,end] with H or E non-zero after the row
-		if (beg < end) {
-			const int s0 = beg >> 6, s1 = (end - 1) >> 6;
-			int diag0 = H[s0 << 6];                // pre-read of the strip's first cell (see below)
-			for (int s = s0; s <= s1; ++s) {
-				const int j = (s << 6) + lane;
-				const bool act = j >= beg && j < end;
-				int diag = lane == 0 ? diag0 : (j <= qlen ? H[j] : 0);
-				int e = j <= qlen ? E[j] : 0;
-				// the last lane writes H[64(s+1)], which is the next strip's first diagonal: read it first
-				const int nxt = (s + 1) << 6;
-				if (nxt <= qlen) diag0 = H[nxt];
-				int qb = act ? (int)qf(j) : 4;
-				const int sc = (int)(int8_t)__builtin_amdgcn_perm(shi, slo, (uint32_t)qb | 0x0c0c0c00u);
-				int M = diag ? diag + sc : 0;
-				int tI = M - oe_ins; tI = tI > 0 ? tI : 0;
-				int g = act ? tI + j * e_ins : WX_NEG;
-				int incl = wx_scan_max(g);
-				int excl = wx_prev_lane(incl, WX_NEG);
-				int f = max(A, excl + e_ins) - j * e_ins;
-				int h = max(max(M, e), f);
-				int tD = M - oe_del; tD = tD > 0 ? tD : 0;
-				int en = max(e - e_del, tD);
-				if (j == beg) H[j] = hleft0;
-				if (act) { H[j + 1] = h; E[j] = en; }
-				A = max(A, __builtin_amdgcn_readlane(incl, 63) + e_ins);
-				// row maximum; the largest column wins ties: maximum of (h << 13 | column)
-				lanekey = max(lanekey, act ? (h << 13 | j) : -1);
-				// cells of this strip that are non-zero after the row: H[c] = h of column c-1, E[c] = en of column c
-				const unsigned long long bh = __ballot(act && h != 0), be = __ballot(act && en != 0);
-				unsigned long long nz = (bh << 1) | be;
-				if (h_carry != 0 && (s << 6) > beg) nz |= 1ull;
-				if ((beg >> 6) == s && hleft0 != 0) nz |= 1ull << (beg & 63);
-				if (nz) {
-					const int lo = (s << 6) + __ffsll((long long)nz) - 1, hi = (s << 6) + 63 - __clzll(nz);
-					if (lo < end && lo < first_nz) first_nz = lo;
-					if (hi > last_nz) last_nz = hi;
-				}
-				h_carry = __builtin_amdgcn_readlane(h, 63);
-				if (s == s1) h_last = __builtin_amdgcn_readlane(h, (end - 1) & 63);
+		for (int s0 = 0; s0 <= n_col; s0 += 64) {
+			const int j = beg + s0 + lane;
+			const bool act = s0 + lane < n_col, wr = s0 + lane <= n_col;
+			const int diag = H[j], e = E[j];
+			const int qraw = (int)Qs[j];
+			const int qb = act ? qraw : 4;
+			const int sc = (int)(int8_t)__builtin_amdgcn_perm(shi, slo, (uint32_t)qb | 0x0c0c0c00u);
+			const int M = (act && diag) ? diag + sc : 0;
+			int tI = M - oe_ins; tI = tI > 0 ? tI : 0;
+			const int g = act ? tI + j * e_ins : WX_NEG;
+			const int incl = wx_scan_max(g);
+			const int excl = wx_prev_lane(incl, WX_NEG);
+			const int f = max(A, excl + e_ins) - j * e_ins;
+			const int h = act ? max(max(M, e), f) : 0;
+			int tD = M - oe_del; tD = tD > 0 ? tD : 0;
+			const int en = act ? max(e - e_del, tD) : 0;
+			const int h_prev = wx_prev_lane(h, h_carry);
+			(wr ? H + j : L.dummy)[0] = h_prev;
+			(wr ? E + j : L.dummy)[0] = en;
+			A = max(A, __builtin_amdgcn_readlane(incl, 63) + e_ins);
+			lanekey = max(lanekey, act ? (h << 13 | j) : -1);   // the largest column wins ties
+			const unsigned long long nz = __ballot(wr && (h_prev | en) != 0);
+			if (nz) {
+				const int lo = beg + s0 + __ffsll((long long)nz) - 1, hi = beg + s0 + 63 - __clzll(nz);
+				if (lo < end && lo < first_nz) first_nz = lo;
+				if (hi > last_nz) last_nz = hi;
 			}
-			rowkey = __builtin_amdgcn_readlane(wx_scan_max(lanekey), 63);
-			if ((end & 63) == 0 && h_carry != 0 && end > last_nz) last_nz = end;   // cell `end` opens the next strip
-			cells += (unsigned long long)(end - beg);
-		} else {
-			if (lane == 0) H[end] = hleft0;        // empty range: eh[end].h = h1 (src/ksw.c:447)
-			if (hleft0 != 0) last_nz = end;
+			h_carry = __builtin_amdgcn_readlane(h, 63);
+			const int last = n_col - 1 - s0;       // the row's last column sits in this strip
+			if (last >= 0 && last < 64) h_last = __builtin_amdgcn_readlane(h, last);
 		}
-		if (lane == 0) E[end] = 0;
+		int rowkey = -1;
+		if (n_col > 0) {
+			rowkey = __builtin_amdgcn_readlane(wx_scan_max(lanekey), 63);
+			cells += (unsigned long long)n_col;
+		} else if (n_col < 0) {
+			if (lane == 0) { H[end] = hleft0; E[end] = 0; }   // src/ksw.c:447 with an empty range (the loop ends below: m == 0)
+		}
 		__builtin_amdgcn_wave_barrier();
-		const int h1 = h_last;
-		const int jfin = beg < end ? end : beg;    // value of the reference's column counter after its loop
+		const int jfin = n_col > 0 ? end : beg;    // value of the reference's column counter after its loop
 		if (jfin == qlen) {
-			if (h1 >= gscore) best_ie = i;
-			if (h1 > gscore) gscore = h1;
+			if (h_last >= gscore) best_ie = i;
+			if (h_last > gscore) gscore = h_last;
 		}
 		const int rowmax = rowkey < 0 ? 0 : rowkey >> 13, rowmax_j = rowkey < 0 ? -1 : rowkey & 8191;
 		if (rowmax == 0) break;
@@ -196,7 +218,8 @@ __device__ __forceinline__ WxResult wave_extend(int qlen, QF qf, int tlen, TF tf
 		const int ne = last_nz >= nb ? last_nz : nb - 1;
 		beg = nb;
 		end = ne + 2 < qlen ? ne + 2 : qlen;
-		if (EARLY && gscore >= 0 && (i & 3) == 3) {
+		// (the row maximum itself is one of the stored cells: B >= rowmax + (qlen - 1 - rowmax_j) * max_sc, a cheap test that (2) can hold)
+		if (EARLY && (i & 3) == 3 && (gscore >= 0 || rowmax + (qlen - 1 - rowmax_j) * max_sc <= best - clip)) {
 			int b = WX_NEG;
 			for (int j = lane; j <= qlen; j += 64) {
 				const int hv = j < qlen ? H[j] + (qlen - j) * max_sc : WX_NEG;
@@ -204,7 +227,8 @@ __device__ __forceinline__ WxResult wave_extend(int qlen, QF qf, int tlen, TF tf
 				b = max(b, max(hv, ev));
 			}
 			b = __builtin_amdgcn_readlane(wx_scan_max(b), 63);
-			if (b < gscore && b <= best) break;
+			if (gscore >= 0 && b < gscore && b <= best) break;         // (1)
+			if (b <= best - clip && gscore <= best - clip) break;      // (2)
 		}
 	}
 	WxResult r;
