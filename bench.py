@@ -262,6 +262,14 @@ def main():
             "sa_kernel_GBps": round(acc["sa_bytes"] / (acc["k_sa_ms"] * 1e-3) / 1e9, 1) if acc.get("k_sa_ms") else None,
             "c2a_kernel_GCUPS": round(acc["ext_cells"] / (acc["k_ext_ms"] * 1e-3) / 1e9, 2) if acc.get("k_ext_ms") else None},
     }
+    if acc.get("k_ext_ms"):
+        # second roofline: the extension kernel is bound by instruction issue, not by memory.  Ceiling: 256 CUs x 4 SIMDs issue one
+        # 64-lane vector instruction per 4 cycles at 2.4 GHz = 39.3 T lane-operations/s; the row loop of wave_ext.cuh spends 81 vector
+        # instructions on a strip of 64 cells (54 in the strip, 27 per row; counted in the ISA), i.e. 81 lane-operations
+        # per cell when every lane holds a live cell -> 485 GCUPS.  The achieved figure counts the cells the kernel computed.
+        g = acc["ext_cells"] / (acc["k_ext_ms"] * 1e-3) / 1e9
+        out["roofline_c2a"] = {"kernel": "c2a_kernel", "bound": "valu", "achieved": round(g, 1), "peak": 485.0, "unit": "GCUPS",
+                               "frac": round(g / 485.0, 4), "launch_ms_per_step": round(acc["k_ext_ms"] / args.steps, 2)}
 
     # ---- CPU baseline + parity: the reference itself on this box's host cores, every chunk once, rank 0 at N=1 only ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -31,10 +31,11 @@ __device__ __forceinline__ int wave_sum_int(int v)
 }
 
 struct AlnLds {
-	int *H, *E;
+	int *H, *E, *dummy;
 	uint8_t *q, *t, *z, *md;
 	uint32_t *cig;
 };
+#define ALN_PAD 64   // cells behind H / E (and bytes behind q) that the lanes of a strip may read past the row
 
 // decimal digits of v (v >= 0) appended at md[len...]; every lane runs it, lane 0 stores
 __device__ __forceinline__ int put_num(uint8_t *md, int len, int v, int lane)
@@ -118,16 +119,17 @@ __device__ __forceinline__ void aln_one(int rq, const AlnParams &P, const WxPara
 	if (FAST) {
 		const size_t per_wave = (size_t)2 * ((max_len + 3) & ~3) + ALN_MDCAP + 16;
 		uint8_t *base = (uint8_t *)lds_raw + (size_t)wave * per_wave;
-		L.H = L.E = nullptr; L.z = nullptr;
+		L.H = L.E = L.dummy = nullptr; L.z = nullptr;
 		L.cig = (uint32_t *)base;
 		L.q = base + 16;
 		L.t = L.q + ((max_len + 3) & ~3);
 		L.md = L.t + ((max_len + 3) & ~3);
 	} else {
-		const size_t per_wave = (size_t)2 * (max_len + 2) * 4 + ((max_len + 3) & ~3) + ((tcap + 3) & ~3) + ALN_ZCAP + ALN_MDCAP + ALN_CIGCAP * 4;
+		const size_t per_wave = (size_t)2 * (max_len + 2 + ALN_PAD) * 4 + 4 + ((max_len + 3) & ~3) + ((tcap + 3) & ~3) + ALN_ZCAP + ALN_MDCAP + ALN_CIGCAP * 4;
 		uint8_t *base = (uint8_t *)lds_raw + (size_t)wave * per_wave;
-		L.H = (int *)base; L.E = L.H + (max_len + 2);
-		L.cig = (uint32_t *)(L.E + (max_len + 2));
+		L.H = (int *)base; L.E = L.H + (max_len + 2 + ALN_PAD);
+		L.dummy = L.E + (max_len + 2 + ALN_PAD);
+		L.cig = (uint32_t *)(L.dummy + 1);
 		L.q = (uint8_t *)(L.cig + ALN_CIGCAP);
 		L.t = L.q + ((max_len + 3) & ~3);
 		L.z = L.t + ((tcap + 3) & ~3);
@@ -231,39 +233,41 @@ __device__ __forceinline__ void aln_one(int rq, const AlnParams &P, const WxPara
 				const uint32_t slo = (uint32_t)__builtin_amdgcn_readlane(vslo, i & 63), shi = (uint32_t)__builtin_amdgcn_readlane(vshi, i & 63);
 				const int beg = i > w ? i - w : 0, end = i + w + 1 < lq ? i + w + 1 : lq;
 				const int hleft0 = beg == 0 ? -(X.o_del + e_del * (i + 1)) : ALN_NEG;
+				const int n_row = end - beg;   // columns of the row (negative: the band has left the query)
 				int A = ALN_NEG;   // running max of g_k + e_ins over the columns already done (F(i,beg) = -inf)
+				int h_carry = hleft0;
 				uint8_t *zi = L.z + (size_t)i * n_col;
-				if (beg < end) {
-					const int s0 = beg >> 6, s1 = (end - 1) >> 6;
-					int diag0 = L.H[s0 << 6];
-					for (int s = s0; s <= s1; ++s) {
-						const int j = (s << 6) + lane;
-						const bool act = j >= beg && j < end;
-						int diag = lane == 0 ? diag0 : (j <= lq ? L.H[j] : 0);
-						int e = j <= lq ? L.E[j] : 0;
-						const int nxt = (s + 1) << 6;
-						if (nxt <= lq) diag0 = L.H[nxt];
-						const int qb = act ? (int)L.q[j] : 4;
-						const int sc = (int)(int8_t)__builtin_amdgcn_perm(shi, slo, (uint32_t)qb | 0x0c0c0c00u);
-						const int m = diag + sc;
-						const int g = act ? m - oe_ins + j * e_ins : ALN_NEG - (1 << 28);
-						const int incl = wx_scan_max(g);
-						const int excl = wx_dpp<0x138, 0xf>(ALN_NEG - (1 << 28), incl);
-						int f = max(A, excl + e_ins) - j * e_ins;     // F(i,j)
-						uint8_t d = m >= e ? 0 : 1;
-						int h = m >= e ? m : e;
-						if (h < f) { d = 2; h = f; }
-						int t = m - oe_del;
-						int e2 = e - e_del;
-						if (e2 > t) d |= 1 << 2; else e2 = t;
-						t = m - oe_ins;
-						if (f - e_ins > t) d |= 2 << 4;
-						if (j == beg) L.H[j] = hleft0;
-						if (act) { L.H[j + 1] = h; L.E[j] = e2; zi[j - beg] = d; }
-						A = max(A, __builtin_amdgcn_readlane(incl, 63) + e_ins);
-					}
-				} else if (lane == 0) L.H[end] = hleft0;
-				if (lane == 0) L.E[end] = ALN_NEG;
+				// strips of 64 lanes counted from the row's first column, as in wave_ext.cuh: lane k owns column beg + k, reads
+				// eh[j] and writes eh[j].h = h of column j - 1 (lane 0: the first-column value; one past the last column: eh[end].h)
+				// and eh[j].e — no bounds tests, what lies past the row goes to a write-only cell
+				for (int s0 = 0; s0 <= n_row; s0 += 64) {
+					const int j = beg + s0 + lane;
+					const bool act = s0 + lane < n_row, wr = s0 + lane <= n_row;
+					const int diag = L.H[j], e = L.E[j];
+					const int qraw = (int)L.q[j];
+					const int qb = act ? qraw : 4;
+					const int sc = (int)(int8_t)__builtin_amdgcn_perm(shi, slo, (uint32_t)qb | 0x0c0c0c00u);
+					const int m = diag + sc;
+					const int g = act ? m - oe_ins + j * e_ins : ALN_NEG - (1 << 28);
+					const int incl = wx_scan_max(g);
+					const int excl = wx_dpp<0x138, 0xf>(ALN_NEG - (1 << 28), incl);
+					const int f = max(A, excl + e_ins) - j * e_ins;     // F(i,j)
+					uint8_t d = m >= e ? 0 : 1;
+					int h = m >= e ? m : e;
+					if (h < f) { d = 2; h = f; }
+					int t = m - oe_del;
+					int e2 = e - e_del;
+					if (e2 > t) d |= 1 << 2; else e2 = t;
+					t = m - oe_ins;
+					if (f - e_ins > t) d |= 2 << 4;
+					const int h_prev = wx_dpp<0x138, 0xf>(h_carry, h);
+					(wr ? L.H + j : L.dummy)[0] = h_prev;
+					(wr ? L.E + j : L.dummy)[0] = act ? e2 : ALN_NEG;
+					(act ? zi + (j - beg) : (uint8_t *)L.dummy)[0] = d;
+					A = max(A, __builtin_amdgcn_readlane(incl, 63) + e_ins);
+					h_carry = __builtin_amdgcn_readlane(h, 63);
+				}
+				if (n_row < 0 && lane == 0) { L.H[end] = hleft0; L.E[end] = ALN_NEG; }
 				__builtin_amdgcn_wave_barrier();
 			}
 			score = L.H[lq];
@@ -396,7 +400,7 @@ aln_kernel(AlnParams P, WxParams X, int n_req, const AlnReq *__restrict__ reqs, 
 size_t aln_lds_per_block(int max_len, int tcap)
 {
 	const int ALN_ZCAP = aln_zcap(max_len);
-	size_t per_wave = (size_t)2 * (max_len + 2) * 4 + ((max_len + 3) & ~3) + ((tcap + 3) & ~3) + ALN_ZCAP + ALN_MDCAP + ALN_CIGCAP * 4;
+	size_t per_wave = (size_t)2 * (max_len + 2 + ALN_PAD) * 4 + 4 + ((max_len + 3) & ~3) + ((tcap + 3) & ~3) + ALN_ZCAP + ALN_MDCAP + ALN_CIGCAP * 4;
 	return per_wave * ALN_WAVES;
 }
 

@@ -146,9 +146,7 @@ static void parallel_blocks(int n_threads, int n, int chunk, F f)
 
 // MPIBWA_C2A_EARLY: 1 (default) the extension row loops stop early, 0 they run the reference's rows, 2 both with a fatal error on any difference
 static int c2a_early_mode() { static const int m = getenv("MPIBWA_C2A_EARLY") ? atoi(getenv("MPIBWA_C2A_EARLY")) : 1; return m; }
-static std::mutex g_smem_turn, g_c2a_turn_own, g_pes_lock;
-// MPIBWA_BIG_TURN=1: the two chip-filling kernels (seeding, extension) of all calls take turns on ONE mutex instead of one each
-static std::mutex &c2a_turn() { static const bool one = getenv("MPIBWA_BIG_TURN") != nullptr && atoi(getenv("MPIBWA_BIG_TURN")) != 0; return one ? g_smem_turn : g_c2a_turn_own; }
+static std::mutex g_smem_turn, g_c2a_turn, g_pes_lock;
 
 static double now_ms()
 {
@@ -206,34 +204,15 @@ struct HostBuf {
 	void *ensure(size_t bytes) { if (bytes > cap) { free(p); cap = bytes + bytes / 4 + 4096; p = malloc(cap); if (!p) die("out of memory"); } return p; }
 };
 
-// grow-only page-locked host buffer: staging for the bulk H2D / D2H copies (full PCIe rate, no per-chunk page faults).
-// The pages are ordinary heap pages registered with the runtime (hipHostRegister), NOT hipHostMalloc memory: what
-// hipHostMalloc returns on this platform is very slow for the CPU to read (it behaves like uncached memory: 2 500 cycles for
-// a 400-byte record), and the host stages read every result the GPU sends back.  MPIBWA_PIN=m selects hipHostMalloc (A/B).
+// grow-only page-locked host buffer: staging for the bulk H2D / D2H copies (full PCIe rate, no per-chunk page faults)
 struct PinBuf {
 	void *p = nullptr; size_t cap = 0;
-	bool registered = false;
-	static bool use_register() { static const bool r = !(getenv("MPIBWA_PIN") && *getenv("MPIBWA_PIN") == 'm'); return r; }
-	void drop()
-	{
-		if (!p) return;
-		if (registered) { HIP_OK(hipHostUnregister(p)); free(p); }
-		else HIP_OK(hipHostFree(p));
-		p = nullptr; cap = 0;
-	}
 	void *ensure(size_t bytes)
 	{
 		if (bytes > cap) {
-			drop();
-			cap = (bytes + bytes / 4 + 8192) & ~(size_t)4095;
-			if (use_register()) {
-				if (posix_memalign(&p, 4096, cap) != 0 || !p) die("out of memory");
-				HIP_OK(hipHostRegister(p, cap, hipHostRegisterDefault));
-				registered = true;
-			} else {
-				HIP_OK(hipHostMalloc(&p, cap, hipHostMallocDefault));
-				registered = false;
-			}
+			if (p) HIP_OK(hipHostFree(p));
+			cap = bytes + bytes / 4 + 4096;
+			HIP_OK(hipHostMalloc(&p, cap, hipHostMallocDefault));
 		}
 		return p;
 	}
@@ -707,7 +686,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			ExtParams ep;
 			memcpy(ep.mat, opt->mat, 25);
 			ep.o_del = opt->o_del; ep.e_del = opt->e_del; ep.o_ins = opt->o_ins; ep.e_ins = opt->e_ins; ep.zdrop = opt->zdrop;
-			std::unique_lock<std::mutex> turn(c2a_turn());
+			std::unique_lock<std::mutex> turn(g_c2a_turn);
 			ev_ext.start(st);
 			// one wavefront per read (any read length)
 			launch_c2a(st, cp, ep, n, d_seq, d_off_r, d_len_r, d_chain_beg, d_chain_cnt, d_chains, d_seeds, d_srt, d_reg_beg, d_regs, d_nregs,
