@@ -35,18 +35,180 @@ typedef long long i64;
 
 #define CK_MAXCH 9
 #define CK_MAXSEEDS 64         // first launch: every read, up to this many seeds
-#define CK_MAXSEEDS_BIG 255    // second launch: the reads the first one declined for their seed count only (seed numbers are bytes)
-enum { F_POS_LO = 0, F_POS_HI, F_FIRST_Q, F_LAST_R_LO, F_LAST_R_HI, F_LAST_Q, F_LAST_LEN, F_RID, F_N, F_W, F_KEPT, F_FIRSTOV, F_NFIELDS };
+#define CK_MAXSEEDS_BIG 255    // second and third launch: the reads the first one declined (seed numbers are bytes)
+#define CK_MAXCH_GEN 255       // third launch: chains per read (chain numbers are bytes, 255 = none)
+#define CK_MAXNODES 128        // ... and B-tree nodes per read (255 keys in nodes of >= 4 need 64 leaves + their parents)
+enum { F_POS_LO = 0, F_POS_HI, F_FIRST_Q, F_LAST_R_LO, F_LAST_R_HI, F_LAST_Q, F_LAST_LEN, F_RID, F_N, F_W, F_KEPT, F_FIRSTOV, F_NFIELDS,
+       F_HEAD = F_NFIELDS, F_TAIL, F_NFIELDS_GEN };
 
-struct Lds {
+// ---- where a read's working set lives ----
+// StoreLds: the reads the reference's ordered map keeps in ONE node (at most 9 chains): everything in LDS, [..][lane].
+// StoreGen: up to 255 chains: the same fields in a per-read slice of an HBM scratch buffer, plus the seeds of a chain as a
+//           linked list in arrival order (the weight and emission loops of a read with 150 seeds and 50 chains would otherwise
+//           scan all seeds once per chain) and the nodes of the B-tree.
+struct StoreLds {
+	static constexpr int MAXCH = CK_MAXCH;
+	static constexpr bool GENERAL = false;
 	uint32_t *tab;    // [F_NFIELDS * CK_MAXCH][64]
-	uint8_t *cid;     // [MAXS + 1][64]     chain id of every seed (255 = in no chain)
-	uint8_t *ord;     // [16][64]           chain ids in tree order, later in filter order
-	uint8_t *tmp;     // [MAXS + 1][64]     scratch: members of one chain
+	uint8_t *cid_;    // [MAXS + 1][64]     chain id of every seed (255 = in no chain)
+	uint8_t *ord_;    // [16][64]           chain ids in tree order, later in filter order
+	uint8_t *tmp_;    // [MAXS + 1][64]     scratch: members of one chain
 	int lane;
 	__device__ __forceinline__ uint32_t &f(int field, int id) const { return tab[(field * CK_MAXCH + id) * 64 + lane]; }
-	__device__ __forceinline__ i64 pos(int id) const { return (i64)((unsigned long long)f(F_POS_HI, id) << 32 | f(F_POS_LO, id)); }
-	__device__ __forceinline__ i64 last_r(int id) const { return (i64)((unsigned long long)f(F_LAST_R_HI, id) << 32 | f(F_LAST_R_LO, id)); }
+	__device__ __forceinline__ uint8_t &cid(int k) const { return cid_[k * 64 + lane]; }
+	__device__ __forceinline__ uint8_t &ord(int k) const { return ord_[k * 64 + lane]; }
+	__device__ __forceinline__ uint8_t &tmp(int k) const { return tmp_[k * 64 + lane]; }
+};
+struct GenNode { uint8_t internal, n, key[2 * 5 - 1], child[2 * 5], pad[3]; };   // the reference's node: t = 5, up to 9 keys (src/kbtree.h, 512-byte nodes of 40-byte chains)
+struct StoreGen {
+	static constexpr int MAXCH = CK_MAXCH_GEN;
+	static constexpr bool GENERAL = true;
+	uint32_t *tab;    // [F_NFIELDS_GEN][CK_MAXCH_GEN]
+	uint8_t *cid_, *ord_, *tmp_, *next_;   // [256] each
+	GenNode *nodes;   // [CK_MAXNODES]
+	__device__ __forceinline__ uint32_t &f(int field, int id) const { return tab[field * CK_MAXCH_GEN + id]; }
+	__device__ __forceinline__ uint8_t &cid(int k) const { return cid_[k]; }
+	__device__ __forceinline__ uint8_t &ord(int k) const { return ord_[k]; }
+	__device__ __forceinline__ uint8_t &tmp(int k) const { return tmp_[k]; }
+	__device__ __forceinline__ uint8_t &next(int k) const { return next_[k]; }
+};
+constexpr size_t CK_GEN_BYTES = ((size_t)F_NFIELDS_GEN * CK_MAXCH_GEN * 4 + 4 * 256 + CK_MAXNODES * sizeof(GenNode) + 255) & ~(size_t)255;
+
+template <class S> __device__ __forceinline__ i64 st_pos(const S &L, int id) { return (i64)((unsigned long long)L.f(F_POS_HI, id) << 32 | L.f(F_POS_LO, id)); }
+template <class S> __device__ __forceinline__ i64 st_last_r(const S &L, int id) { return (i64)((unsigned long long)L.f(F_LAST_R_HI, id) << 32 | L.f(F_LAST_R_LO, id)); }
+
+// ---- the ordered map of mem_chain (src/bwamem.c:263, 288-300; src/kbtree.h) ----
+// One node: a sorted array with the B-tree's rules for equal keys (a new key goes right behind the first key that is not
+// smaller ... stepped back; a lookup that hits equal keys returns the first of them).
+struct MapArray {
+	int n = 0;
+	template <class S> __device__ __forceinline__ int lower(const S &L, i64 pos) const   // closest chain at or before pos, or -1
+	{
+		int f = 0;
+		while (f < n && st_pos(L, L.ord(f)) < pos) ++f;
+		const int li = (f < n && st_pos(L, L.ord(f)) == pos) ? f : f - 1;
+		return li >= 0 ? (int)L.ord(li) : -1;
+	}
+	template <class S> __device__ __forceinline__ bool put(const S &L, int id, i64 pos)
+	{
+		if (n == S::MAXCH) return false;   // the reference's root node would split here
+		int f = 0;
+		while (f < n && st_pos(L, L.ord(f)) < pos) ++f;
+		const int li = (f < n && st_pos(L, L.ord(f)) == pos) ? f : f - 1;
+		for (int t = n; t > li + 1; --t) L.ord(t) = L.ord(t - 1);
+		L.ord(li + 1) = (uint8_t)id;
+		++n;
+		return true;
+	}
+	template <class S> __device__ __forceinline__ void in_order(const S &) const {}   // ord already is
+};
+// The B-tree itself (kb_intervalp / kb_putp of src/kbtree.h with t = 5), because with equal keys what a lookup returns
+// depends on where the splits put them.
+struct MapBtree {
+	int n = 0, n_nodes = 0, root = 0;
+	bool full = false;
+	template <class S> __device__ __forceinline__ int make(const S &L)
+	{
+		if (n_nodes == CK_MAXNODES) { full = true; return 0; }
+		GenNode &x = L.nodes[n_nodes];
+		x.internal = 0; x.n = 0;
+		return n_nodes++;
+	}
+	// index of the last key <= pos in the node (-1: none); *r = sign(pos - that key's successor rule) as __kb_getp_aux
+	template <class S> __device__ __forceinline__ int locate(const S &L, const GenNode &x, i64 pos, int *r) const
+	{
+		int begin = 0, end = x.n;
+		if (x.n == 0) return -1;
+		while (begin < end) {
+			const int mid = (begin + end) >> 1;
+			if (st_pos(L, x.key[mid]) < pos) begin = mid + 1;
+			else end = mid;
+		}
+		if (begin == x.n) { *r = 1; return x.n - 1; }
+		const i64 kp = st_pos(L, x.key[begin]);
+		*r = (kp < pos) - (pos < kp);
+		if (*r < 0) --begin;
+		return begin;
+	}
+	template <class S> __device__ __forceinline__ int lower(const S &L, i64 pos) const
+	{
+		if (n == 0) return -1;
+		int low = -1, r = 0, xi = root;
+		for (;;) {
+			const GenNode &x = L.nodes[xi];
+			const int i = locate(L, x, pos, &r);
+			if (i >= 0 && r == 0) return x.key[i];
+			if (i >= 0) low = x.key[i];
+			if (!x.internal) return low;
+			xi = x.child[i + 1];
+		}
+	}
+	template <class S> __device__ __forceinline__ void split(const S &L, int xi, int i, int yi)
+	{
+		const int zi = make(L);
+		if (full) return;
+		GenNode &x = L.nodes[xi], &y = L.nodes[yi], &z = L.nodes[zi];
+		z.internal = y.internal;
+		z.n = 4;
+		for (int k = 0; k < 4; ++k) z.key[k] = y.key[5 + k];
+		if (y.internal) for (int k = 0; k < 5; ++k) z.child[k] = y.child[5 + k];
+		y.n = 4;
+		for (int k = x.n; k > i; --k) x.child[k + 1] = x.child[k];
+		x.child[i + 1] = (uint8_t)zi;
+		for (int k = x.n - 1; k >= i; --k) x.key[k + 1] = x.key[k];
+		x.key[i] = y.key[4];
+		++x.n;
+	}
+	template <class S> __device__ __forceinline__ bool put(const S &L, int id, i64 pos)
+	{
+		if (n == S::MAXCH) return false;
+		if (n_nodes == 0) root = make(L);
+		int r = root, rr = 0;
+		if (L.nodes[r].n == 9) {
+			const int si = make(L);
+			if (full) return false;
+			root = si; L.nodes[si].internal = 1; L.nodes[si].n = 0;
+			L.nodes[si].child[0] = (uint8_t)r;
+			split(L, si, 0, r);
+			if (full) return false;
+			r = si;
+		}
+		int xi = r;
+		while (L.nodes[xi].internal) {
+			int i = locate(L, L.nodes[xi], pos, &rr) + 1;
+			if (L.nodes[L.nodes[xi].child[i]].n == 9) {
+				split(L, xi, i, L.nodes[xi].child[i]);
+				if (full) return false;
+				if (st_pos(L, L.nodes[xi].key[i]) < pos) ++i;
+			}
+			xi = L.nodes[xi].child[i];
+		}
+		GenNode &x = L.nodes[xi];
+		const int i = locate(L, x, pos, &rr);
+		for (int k = x.n - 1; k > i; --k) x.key[k + 1] = x.key[k];
+		x.key[i + 1] = (uint8_t)id;
+		++x.n;
+		++n;
+		return true;
+	}
+	template <class S> __device__ __forceinline__ void in_order(const S &L) const   // chain ids in key order into ord[]
+	{
+		if (n == 0) return;
+		int sn[8], si[8], sp = 0, out = 0;   // node, children already entered (a tree of <= 255 keys with >= 4 per node is at most 4 levels deep)
+		sn[0] = root; si[0] = 0;
+		while (sp >= 0) {
+			const GenNode &x = L.nodes[sn[sp]];
+			if (!x.internal) {
+				for (int k = 0; k < x.n; ++k) L.ord(out++) = x.key[k];
+				--sp;
+				continue;
+			}
+			const int i = si[sp];
+			if (i > 0 && i <= x.n) L.ord(out++) = x.key[i - 1];   // back from child i - 1: its separator key
+			if (i <= x.n) { si[sp] = i + 1; ++sp; sn[sp] = x.child[i]; si[sp] = 0; }
+			else --sp;
+		}
+	}
 };
 
 __device__ __forceinline__ int ck_pos2rid(const i64 *__restrict__ ann_off, int n_seqs, i64 l_pac, i64 pos_f)
@@ -64,48 +226,111 @@ __device__ __forceinline__ int ck_pos2rid(const i64 *__restrict__ ann_off, int n
 }
 __device__ __forceinline__ i64 ck_depos(i64 l_pac, i64 pos) { return pos >= l_pac ? (l_pac << 1) - 1 - pos : pos; }
 
-// MAXS: seeds per read the instantiation has LDS for.  RETRY: second launch — only the reads the first launch declined
-// because they have more than CK_MAXSEEDS seeds (a few per cent of 2x150 bp reads, with ~150 seeds each: they used to be
-// a quarter of the host's CPU time per chunk); reads with more than 9 chains stay with the host's B-tree either way.
-template <int MAXS, bool RETRY>
-__global__ void __launch_bounds__(64)
-chain_kernel(ChainParams P, int n_reads, const int *__restrict__ lens, const int *__restrict__ n_seeds, const int *__restrict__ l_rep,
-             const i64 *__restrict__ seed_off, const unsigned long long *__restrict__ sa, const int32_t *__restrict__ qbl,
-             const i64 *__restrict__ ann_off, const uint8_t *__restrict__ ann_alt, int n_seqs, const int *__restrict__ tab, int tab_stride,
-             DevChain *__restrict__ chains, DevSeed *__restrict__ seeds, unsigned int *__restrict__ srt, int *__restrict__ n_chains)
+// the unstable sort of mem_chain_flt for any n: ks_introsort (src/ksort.h:176-226) on the chain ids in ord[0, n), "less" =
+// heavier first — median-of-three quicksort with an explicit stack, ranges of <= 16 left to one final insertion sort, comb
+// sort when the depth budget runs out (sortutil.h is the host's statement of the same)
+template <class S, class LT>
+__device__ __forceinline__ void ck_insertion(const S &L, int s, int t, LT lt)   // [s, t)
 {
-	extern __shared__ uint32_t lds_raw[];
-	Lds L;
-	L.lane = threadIdx.x;
-	L.tab = lds_raw;
-	L.cid = (uint8_t *)(lds_raw + F_NFIELDS * CK_MAXCH * 64);
-	L.ord = L.cid + (MAXS + 1) * 64;
-	L.tmp = L.ord + 16 * 64;
-	const int lane = threadIdx.x;
-	const int rd = blockIdx.x * 64 + lane;
-	if (rd >= n_reads) return;
-	const int ns = n_seeds[rd], lq = lens[rd];
-	const i64 so = seed_off[rd];
-	const int *gap = tab, *noflt = tab + 5 * tab_stride;
-	if (RETRY) { if (n_chains[rd] != -1 || ns <= CK_MAXSEEDS) return; }
-	else if (ns == 0) { n_chains[rd] = 0; return; }
-	if (ns > MAXS || !noflt[lq]) { n_chains[rd] = -1; return; }
+	for (int i = s + 1; i < t; ++i)
+		for (int j = i; j > s && lt(L.ord(j), L.ord(j - 1)); --j) { const uint8_t x = L.ord(j); L.ord(j) = L.ord(j - 1); L.ord(j - 1) = x; }
+}
+template <class S, class LT>
+__device__ __forceinline__ void ck_comb(const S &L, int a, int n, LT lt)
+{
+	const double shrink = 1.2473309501039786540366528676643;
+	int gap = n;
+	bool swapped;
+	do {
+		if (gap > 2) {
+			gap = (int)((double)gap / shrink);
+			if (gap == 9 || gap == 10) gap = 11;
+		}
+		swapped = false;
+		for (int i = a; i < a + n - gap; ++i) {
+			const int j = i + gap;
+			if (lt(L.ord(j), L.ord(i))) { const uint8_t x = L.ord(i); L.ord(i) = L.ord(j); L.ord(j) = x; swapped = true; }
+		}
+	} while (swapped || gap > 2);
+	if (gap != 1) ck_insertion(L, a, a + n, lt);
+}
+template <class S, class LT>
+__device__ __forceinline__ void ck_introsort(const S &L, int n, LT lt)
+{
+	if (n < 2) return;
+	if (n == 2) {
+		if (lt(L.ord(1), L.ord(0))) { const uint8_t x = L.ord(0); L.ord(0) = L.ord(1); L.ord(1) = x; }
+		return;
+	}
+	int d = 2;
+	while ((1 << d) < n) ++d;
+	int fs[16], ft[16], fd[16], sp = 0;   // only ranges of more than 16 elements are pushed, the smaller side is worked first
+	int s = 0, t = n - 1;
+	d <<= 1;
+	for (;;) {
+		if (s < t) {
+			if (--d == 0) {
+				ck_comb(L, s, t - s + 1, lt);
+				t = s;
+				continue;
+			}
+			int i = s, j = t, k = i + ((j - i) >> 1) + 1;
+			if (lt(L.ord(k), L.ord(i))) { if (lt(L.ord(k), L.ord(j))) k = j; }
+			else k = lt(L.ord(j), L.ord(i)) ? i : j;
+			const uint8_t pivot = L.ord(k);
+			if (k != t) { const uint8_t x = L.ord(k); L.ord(k) = L.ord(t); L.ord(t) = x; }
+			for (;;) {
+				do ++i; while (lt(L.ord(i), pivot));
+				do --j; while (i <= j && lt(pivot, L.ord(j)));
+				if (j <= i) break;
+				const uint8_t x = L.ord(i); L.ord(i) = L.ord(j); L.ord(j) = x;
+			}
+			{ const uint8_t x = L.ord(i); L.ord(i) = L.ord(t); L.ord(t) = x; }
+			if (i - s > t - i) {
+				if (i - s > 16) { fs[sp] = s; ft[sp] = i - 1; fd[sp] = d; ++sp; }
+				s = t - i > 16 ? i + 1 : t;
+			} else {
+				if (t - i > 16) { fs[sp] = i + 1; ft[sp] = t; fd[sp] = d; ++sp; }
+				t = i - s > 16 ? i - 1 : s;
+			}
+		} else {
+			if (sp == 0) { ck_insertion(L, 0, n, lt); return; }
+			--sp;
+			s = fs[sp]; t = ft[sp]; d = fd[sp];
+		}
+	}
+}
+
+// mem_chain + mem_chain_flt + emission for ONE read (one lane).  Returns the number of kept chains, or -1: host path.
+template <class S, class MAP>
+__device__ __forceinline__ int chain_read(const S &L, const ChainParams &P, int rd, int ns, int lq, i64 so, const int *__restrict__ l_rep,
+                                          const unsigned long long *__restrict__ sa, const int32_t *__restrict__ qbl, const i64 *__restrict__ ann_off,
+                                          const uint8_t *__restrict__ ann_alt, int n_seqs, const int *__restrict__ gap, DevChain *__restrict__ chains,
+                                          DevSeed *__restrict__ seeds, unsigned int *__restrict__ srt)
+{
 	const i64 l_pac = P.l_pac;
 	auto S_R = [&](int k) -> i64 { return (i64)sa[so + k]; };
 	auto S_Q = [&](int k) -> int { return qbl[2 * (so + k)]; };
 	auto S_L = [&](int k) -> int { return qbl[2 * (so + k) + 1]; };
-	auto CID = [&](int k) -> uint8_t & { return L.cid[k * 64 + lane]; };
-	auto ORD = [&](int k) -> uint8_t & { return L.ord[k * 64 + lane]; };
-	auto TMP = [&](int k) -> uint8_t & { return L.tmp[k * 64 + lane]; };
+	// the seeds of chain `id` in arrival order
+	auto members = [&](int id, auto fn) {
+		if constexpr (S::GENERAL) {
+			for (int k = (int)L.f(F_HEAD, id); k != 255; k = L.next(k)) fn(k);
+		} else {
+			for (int k = 0; k < ns; ++k)
+				if (L.cid(k) == id) fn(k);
+		}
+	};
 
 	// ---------------- mem_chain: seeds into the ordered map ----------------
+	MAP map;
 	int n_ch = 0;
 	i64 c_lo = 0, c_hi = -1;
 	int c_rid = -1;
 	for (int k = 0; k < ns; ++k) {
 		const i64 rb = S_R(k);
 		const int qb = S_Q(k), len = S_L(k);
-		CID(k) = 255;
+		L.cid(k) = 255;
 		int rid;
 		if (rb >= c_lo && rb + len <= c_hi && len > 0) rid = c_rid;
 		else {   // bns_intv2rid, src/bntseq.c:365-376
@@ -123,14 +348,11 @@ chain_kernel(ChainParams P, int n_reads, const int *__restrict__ lens, const int
 			}
 		}
 		if (rid < 0) continue;   // bridges two contigs or the strand boundary
-		// closest chain at or before the seed: first key >= pos, stepped back unless equal (kb_intervalp, single node)
-		int f = 0;
-		while (f < n_ch && L.pos(ORD(f)) < rb) ++f;
-		const int li = (f < n_ch && L.pos(ORD(f)) == rb) ? f : f - 1;
+		const int id0 = map.lower(L, rb);   // closest chain at or before the seed (kb_intervalp)
 		bool merged = false;
-		if (li >= 0) {   // test_and_merge
-			const int id = ORD(li);
-			const i64 first_r = L.pos(id), last_r = L.last_r(id);
+		if (id0 >= 0) {   // test_and_merge
+			const int id = id0;
+			const i64 first_r = st_pos(L, id), last_r = st_last_r(L, id);
 			const int first_q = (int)L.f(F_FIRST_Q, id), last_q = (int)L.f(F_LAST_Q, id), last_len = (int)L.f(F_LAST_LEN, id);
 			const int qend = last_q + last_len;
 			const i64 rend = last_r + last_len;
@@ -142,94 +364,71 @@ chain_kernel(ChainParams P, int n_reads, const int *__restrict__ lens, const int
 						L.f(F_LAST_R_LO, id) = (uint32_t)rb; L.f(F_LAST_R_HI, id) = (uint32_t)((unsigned long long)rb >> 32);
 						L.f(F_LAST_Q, id) = (uint32_t)qb; L.f(F_LAST_LEN, id) = (uint32_t)len;
 						L.f(F_N, id) += 1;
-						CID(k) = (uint8_t)id;
+						L.cid(k) = (uint8_t)id;
+						if constexpr (S::GENERAL) { L.next((int)L.f(F_TAIL, id)) = (uint8_t)k; L.next(k) = 255; L.f(F_TAIL, id) = (uint32_t)k; }
 						merged = true;
 					}
 				}
 			}
 		}
 		if (merged) continue;
-		if (n_ch == CK_MAXCH) { n_chains[rd] = -1; return; }   // the reference's root node would split here: host path
 		const int id = n_ch;
+		if (id >= S::MAXCH) return -1;
+		// (the record first: the map compares positions through it)
 		L.f(F_POS_LO, id) = (uint32_t)rb; L.f(F_POS_HI, id) = (uint32_t)((unsigned long long)rb >> 32);
 		L.f(F_FIRST_Q, id) = (uint32_t)qb;
 		L.f(F_LAST_R_LO, id) = (uint32_t)rb; L.f(F_LAST_R_HI, id) = (uint32_t)((unsigned long long)rb >> 32);
 		L.f(F_LAST_Q, id) = (uint32_t)qb; L.f(F_LAST_LEN, id) = (uint32_t)len;
 		L.f(F_RID, id) = (uint32_t)rid; L.f(F_N, id) = 1;
-		CID(k) = (uint8_t)id;
-		for (int t = n_ch; t > li + 1; --t) ORD(t) = ORD(t - 1);   // the new key goes right behind position li
-		ORD(li + 1) = (uint8_t)id;
+		if constexpr (S::GENERAL) { L.f(F_HEAD, id) = L.f(F_TAIL, id) = (uint32_t)k; L.next(k) = 255; }
+		if (!map.put(L, id, rb)) return -1;   // more chains (or tree nodes) than this launch keeps: host path
+		L.cid(k) = (uint8_t)id;
 		++n_ch;
 	}
+	map.in_order(L);
 
 	// ---------------- mem_chain_flt ----------------
 	int n = 0;
 	for (int t = 0; t < n_ch; ++t) {
-		const int id = ORD(t);
+		const int id = L.ord(t);
 		// mem_chain_weight: seed coverage of the query, of the reference, the smaller one
 		i64 end = 0;
 		int w = 0, wq;
-		for (int k = 0; k < ns; ++k) {
-			if (CID(k) != id) continue;
+		members(id, [&](int k) {
 			const int qb = S_Q(k), len = S_L(k);
 			if (qb >= end) w += len;
 			else if (qb + len > end) w += (int)(qb + len - end);
 			end = end > qb + len ? end : qb + len;
-		}
+		});
 		wq = w; w = 0; end = 0;
-		for (int k = 0; k < ns; ++k) {
-			if (CID(k) != id) continue;
+		members(id, [&](int k) {
 			const i64 rb = S_R(k);
 			const int len = S_L(k);
 			if (rb >= end) w += len;
 			else if (rb + len > end) w += (int)(rb + len - end);
 			end = end > rb + len ? end : rb + len;
-		}
+		});
 		w = w < wq ? w : wq;
 		w = w < 1 << 30 ? w : (1 << 30) - 1;
 		const uint32_t w29 = (uint32_t)w & 0x1fffffffu;
 		L.f(F_W, id) = w29; L.f(F_KEPT, id) = 0; L.f(F_FIRSTOV, id) = 0xffffffffu;
 		if ((int)w29 < P.min_chain_weight) continue;
-		ORD(n++) = (uint8_t)id;
+		L.ord(n++) = (uint8_t)id;
 	}
-	if (n == 0) { n_chains[rd] = 0; return; }
-	auto W = [&](int t) -> int { return (int)L.f(F_W, ORD(t)); };
-	auto LT = [&](int a_id, int b_id) -> bool { return (int)L.f(F_W, a_id) > (int)L.f(F_W, b_id); };   // "less" of the descending sort
-	if (n == 2) {
-		if (LT(ORD(1), ORD(0))) { uint8_t t = ORD(0); ORD(0) = ORD(1); ORD(1) = t; }
-	} else if (n > 2) {
-		// one median-of-three partition pass over the whole range (what ks_introsort does before it hands ranges of <= 17
-		// elements to the insertion sort)
-		{
-			int i = 0, j = n - 1, k = i + ((j - i) >> 1) + 1;
-			if (LT(ORD(k), ORD(i))) { if (LT(ORD(k), ORD(j))) k = j; }
-			else k = LT(ORD(j), ORD(i)) ? i : j;
-			const uint8_t pivot = ORD(k);
-			if (k != n - 1) { uint8_t t = ORD(k); ORD(k) = ORD(n - 1); ORD(n - 1) = t; }
-			for (;;) {
-				do ++i; while (LT(ORD(i), pivot));
-				do --j; while (i <= j && LT(pivot, ORD(j)));
-				if (j <= i) break;
-				uint8_t t = ORD(i); ORD(i) = ORD(j); ORD(j) = t;
-			}
-			uint8_t t = ORD(i); ORD(i) = ORD(n - 1); ORD(n - 1) = t;
-		}
-		for (int i = 1; i < n; ++i)   // __ks_insertsort
-			for (int j = i; j > 0 && LT(ORD(j), ORD(j - 1)); --j) { uint8_t t = ORD(j); ORD(j) = ORD(j - 1); ORD(j - 1) = t; }
-	}
-	(void)W;
-	// pairwise overlap marking; TMP holds the positions (in ORD) of the chains kept so far
-	auto BEG = [&](int t) -> int { return (int)L.f(F_FIRST_Q, ORD(t)); };
-	auto END = [&](int t) -> int { const int id = ORD(t); return (int)L.f(F_LAST_Q, id) + (int)L.f(F_LAST_LEN, id); };
-	auto ALT = [&](int t) -> int { return ann_alt[L.f(F_RID, ORD(t))]; };
+	if (n == 0) return 0;
+	ck_introsort(L, n, [&](int a_id, int b_id) -> bool { return (int)L.f(F_W, a_id) > (int)L.f(F_W, b_id); });   // "less" of the descending sort
+	// pairwise overlap marking; tmp holds the positions (in ord) of the chains kept so far
+	auto BEG = [&](int t) -> int { return (int)L.f(F_FIRST_Q, L.ord(t)); };
+	auto END = [&](int t) -> int { const int id = L.ord(t); return (int)L.f(F_LAST_Q, id) + (int)L.f(F_LAST_LEN, id); };
+	auto ALT = [&](int t) -> int { return ann_alt[L.f(F_RID, L.ord(t))]; };
 	int n_kept = 0;
-	L.f(F_KEPT, ORD(0)) = 3;
-	TMP(n_kept++) = 0;
+	L.f(F_KEPT, L.ord(0)) = 3;
+	L.tmp(n_kept++) = 0;
 	for (int i = 1; i < n; ++i) {
 		bool large_ovlp = false;
 		int kk;
 		for (kk = 0; kk < n_kept; ++kk) {
-			const int j = TMP(kk);
+			const int j = L.tmp(kk);
 			const int b_max = BEG(j) > BEG(i) ? BEG(j) : BEG(i);
 			const int e_min = END(j) < END(i) ? END(j) : END(i);
 			if (e_min > b_max && (!ALT(j) || ALT(i))) {
@@ -237,30 +436,30 @@ chain_kernel(ChainParams P, int n_reads, const int *__restrict__ lens, const int
 				const int min_l = li_ < lj_ ? li_ : lj_;
 				if ((float)(e_min - b_max) >= (float)min_l * P.mask_level && min_l < P.max_chain_gap) {
 					large_ovlp = true;
-					if (L.f(F_FIRSTOV, ORD(j)) == 0xffffffffu) L.f(F_FIRSTOV, ORD(j)) = (uint32_t)i;
-					const int wi = (int)L.f(F_W, ORD(i)), wj = (int)L.f(F_W, ORD(j));
+					if (L.f(F_FIRSTOV, L.ord(j)) == 0xffffffffu) L.f(F_FIRSTOV, L.ord(j)) = (uint32_t)i;
+					const int wi = (int)L.f(F_W, L.ord(i)), wj = (int)L.f(F_W, L.ord(j));
 					if ((float)wi < (float)wj * P.drop_ratio && wj - wi >= P.min_seed_len << 1) break;
 				}
 			}
 		}
 		if (kk == n_kept) {
-			TMP(n_kept++) = (uint8_t)i;
-			L.f(F_KEPT, ORD(i)) = large_ovlp ? 2 : 3;
+			L.tmp(n_kept++) = (uint8_t)i;
+			L.f(F_KEPT, L.ord(i)) = large_ovlp ? 2 : 3;
 		}
 	}
 	for (int kk = 0; kk < n_kept; ++kk) {
-		const uint32_t fo = L.f(F_FIRSTOV, ORD(TMP(kk)));
-		if (fo != 0xffffffffu) L.f(F_KEPT, ORD(fo)) = 1;
+		const uint32_t fo = L.f(F_FIRSTOV, L.ord(L.tmp(kk)));
+		if (fo != 0xffffffffu) L.f(F_KEPT, L.ord(fo)) = 1;
 	}
 	{
 		int i = 0, cnt = 0;
 		for (; i < n; ++i) {   // at most max_chain_extend chains with kept = 1 or 2 are extended
-			const uint32_t kp = L.f(F_KEPT, ORD(i));
+			const uint32_t kp = L.f(F_KEPT, L.ord(i));
 			if (kp == 0 || kp == 3) continue;
 			if (++cnt >= P.max_chain_extend) break;
 		}
 		for (; i < n; ++i)
-			if (L.f(F_KEPT, ORD(i)) < 3) L.f(F_KEPT, ORD(i)) = 0;
+			if (L.f(F_KEPT, L.ord(i)) < 3) L.f(F_KEPT, L.ord(i)) = 0;
 	}
 
 	// ---------------- emit the kept chains and their seeds ----------------
@@ -268,25 +467,24 @@ chain_kernel(ChainParams P, int n_reads, const int *__restrict__ lens, const int
 	int n_out = 0;
 	i64 cursor = so;
 	for (int t = 0; t < n; ++t) {
-		const int id = ORD(t);
+		const int id = L.ord(t);
 		if (L.f(F_KEPT, id) == 0) continue;
 		// members in arrival order, then sorted by (length, arrival index): keys are distinct
 		int cs = 0;
-		for (int k = 0; k < ns; ++k)
-			if (CID(k) == id) TMP(cs++) = (uint8_t)k;
-		// TMP was also the kept list: it is no longer needed at this point
+		members(id, [&](int k) { L.tmp(cs++) = (uint8_t)k; });
+		// tmp was also the kept list: it is no longer needed at this point
 		for (int a = 1; a < cs; ++a) {
-			const uint8_t v = TMP(a);
+			const uint8_t v = L.tmp(a);
 			const int lv = S_L(v);
 			int b = a;
-			while (b > 0 && S_L(TMP(b - 1)) > lv) { TMP(b) = TMP(b - 1); --b; }   // stable: equal lengths keep arrival order
-			TMP(b) = v;
+			while (b > 0 && S_L(L.tmp(b - 1)) > lv) { L.tmp(b) = L.tmp(b - 1); --b; }   // stable: equal lengths keep arrival order
+			L.tmp(b) = v;
 		}
 		const int rid = (int)L.f(F_RID, id);
-		const i64 first_r = L.pos(id);
+		const i64 first_r = st_pos(L, id);
 		i64 lo = l_pac << 1, hi = 0;
 		for (int a = 0; a < cs; ++a) {
-			const int k = TMP(a);
+			const int k = L.tmp(a);
 			DevSeed ds;
 			ds.rbeg = S_R(k); ds.qbeg = S_Q(k); ds.len = S_L(k);
 			seeds[cursor + a] = ds;
@@ -315,7 +513,72 @@ chain_kernel(ChainParams P, int n_reads, const int *__restrict__ lens, const int
 		++n_out;
 		cursor += cs;
 	}
-	n_chains[rd] = n_out;
+	return n_out;
+}
+
+// MAXS: seeds per read the instantiation has LDS for.  RETRY: second launch — only the reads the first launch declined
+// because they have more than CK_MAXSEEDS seeds (a few per cent of 2x150 bp reads, with ~150 seeds each).
+template <int MAXS, bool RETRY>
+__global__ void __launch_bounds__(64)
+chain_kernel(ChainParams P, int n_reads, const int *__restrict__ lens, const int *__restrict__ n_seeds, const int *__restrict__ l_rep,
+             const i64 *__restrict__ seed_off, const unsigned long long *__restrict__ sa, const int32_t *__restrict__ qbl,
+             const i64 *__restrict__ ann_off, const uint8_t *__restrict__ ann_alt, int n_seqs, const int *__restrict__ tab, int tab_stride,
+             DevChain *__restrict__ chains, DevSeed *__restrict__ seeds, unsigned int *__restrict__ srt, int *__restrict__ n_chains)
+{
+	extern __shared__ uint32_t lds_raw[];
+	StoreLds L;
+	L.lane = threadIdx.x;
+	L.tab = lds_raw;
+	L.cid_ = (uint8_t *)(lds_raw + F_NFIELDS * CK_MAXCH * 64);
+	L.ord_ = L.cid_ + (MAXS + 1) * 64;
+	L.tmp_ = L.ord_ + 16 * 64;
+	const int rd = blockIdx.x * 64 + threadIdx.x;
+	if (rd >= n_reads) return;
+	const int ns = n_seeds[rd], lq = lens[rd];
+	const int *gap = tab, *noflt = tab + 5 * tab_stride;
+	if (RETRY) { if (n_chains[rd] != -1 || ns <= CK_MAXSEEDS) return; }
+	else if (ns == 0) { n_chains[rd] = 0; return; }
+	if (ns > MAXS || !noflt[lq]) { n_chains[rd] = -1; return; }
+	n_chains[rd] = chain_read<StoreLds, MapArray>(L, P, rd, ns, lq, seed_off[rd], l_rep, sa, qbl, ann_off, ann_alt, n_seqs, gap, chains, seeds, srt);
+}
+
+// Third launch, two kernels: list the reads both single-node launches declined (more than 9 chains) and that the general
+// kernel has room for, then chain them with the reference's B-tree, a lane per read, the working set in an HBM slice.
+__global__ void __launch_bounds__(256)
+chain_pick_kernel(int n_reads, const int *__restrict__ lens, const int *__restrict__ n_seeds, const int *__restrict__ n_chains,
+                  const int *__restrict__ noflt, int cap, int *__restrict__ list, unsigned int *__restrict__ count)
+{
+	const int rd = blockIdx.x * 256 + threadIdx.x;
+	const bool mine = rd < n_reads && n_chains[rd] == -1 && n_seeds[rd] <= CK_MAXSEEDS_BIG && noflt[lens[rd]] != 0;
+	const unsigned long long m = __ballot(mine);
+	if (!m) return;
+	const int lane = threadIdx.x & 63, lead = __ffsll((long long)m) - 1;
+	unsigned int base = 0;
+	if (lane == lead) base = atomicAdd(count, (unsigned int)__popcll(m));
+	base = __shfl(base, lead);
+	const unsigned int at = base + (unsigned int)__popcll(m & ((1ull << lane) - 1));
+	if (mine && at < (unsigned int)cap) list[at] = rd;
+}
+
+__global__ void __launch_bounds__(64)
+chain_general_kernel(ChainParams P, const int *__restrict__ list, const unsigned int *__restrict__ count, int cap, const int *__restrict__ lens,
+                     const int *__restrict__ n_seeds, const int *__restrict__ l_rep, const i64 *__restrict__ seed_off,
+                     const unsigned long long *__restrict__ sa, const int32_t *__restrict__ qbl, const i64 *__restrict__ ann_off,
+                     const uint8_t *__restrict__ ann_alt, int n_seqs, const int *__restrict__ tab, uint8_t *__restrict__ scratch,
+                     DevChain *__restrict__ chains, DevSeed *__restrict__ seeds, unsigned int *__restrict__ srt, int *__restrict__ n_chains)
+{
+	const int t = blockIdx.x * 64 + threadIdx.x;
+	const int n_list = (int)(*count < (unsigned int)cap ? *count : (unsigned int)cap);
+	if (t >= n_list) return;
+	const int rd = list[t];
+	uint8_t *base = scratch + (size_t)t * CK_GEN_BYTES;
+	StoreGen L;
+	L.tab = (uint32_t *)base;
+	L.cid_ = base + (size_t)F_NFIELDS_GEN * CK_MAXCH_GEN * 4;
+	L.ord_ = L.cid_ + 256; L.tmp_ = L.ord_ + 256; L.next_ = L.tmp_ + 256;
+	L.nodes = (GenNode *)(L.next_ + 256);
+	n_chains[rd] = chain_read<StoreGen, MapBtree>(L, P, rd, n_seeds[rd], lens[rd], seed_off[rd], l_rep, sa, qbl, ann_off, ann_alt, n_seqs, tab, chains,
+	                                               seeds, srt);
 }
 
 // regions from their per-read slots into one dense array (reg_pos = exclusive prefix of n_regs)
@@ -353,9 +616,14 @@ void launch_reg_pack(void *stream, int n_reads, const int *d_reg_beg, const int 
 
 static size_t chain_lds_bytes(int maxs) { return (size_t)F_NFIELDS * CK_MAXCH * 64 * 4 + (size_t)(2 * (maxs + 1) + 16) * 64; }
 
+size_t chain_general_bytes(int cap) { return (size_t)cap * CK_GEN_BYTES + (size_t)cap * 4 + 256; }
+
+// d_gen / gen_cap: scratch of chain_general_bytes(gen_cap) for the third launch (reads with more than 9 chains, up to 255
+// seeds and chains, at most gen_cap of them per call); null / 0: those reads keep n_chains = -1 (host path).
 void launch_chain(void *stream, const ChainParams &P, int n_reads, const int *d_len, const int *d_nseeds, const int *d_lrep,
                   const int64_t *d_seed_off, const uint64_t *d_sa, const int32_t *d_qbl, const int64_t *d_ann_off, const uint8_t *d_ann_alt,
-                  int n_seqs, const int *d_tab, int tab_stride, DevChain *d_chains, DevSeed *d_seeds, unsigned int *d_srt, int *d_nchains)
+                  int n_seqs, const int *d_tab, int tab_stride, DevChain *d_chains, DevSeed *d_seeds, unsigned int *d_srt, int *d_nchains,
+                  void *d_gen, int gen_cap)
 {
 	if (n_reads <= 0) return;
 	const size_t lds = chain_lds_bytes(CK_MAXSEEDS), lds_big = chain_lds_bytes(CK_MAXSEEDS_BIG);
@@ -365,14 +633,26 @@ void launch_chain(void *stream, const ChainParams &P, int n_reads, const int *d_
 		if (lds_big > 64 * 1024) HIP_OK(hipFuncSetAttribute((const void *)chain_kernel<CK_MAXSEEDS_BIG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
 		s_attr = true;
 	}
-	hipLaunchKernelGGL((chain_kernel<CK_MAXSEEDS, false>), dim3((n_reads + 63) / 64), dim3(64), lds, (hipStream_t)stream, P, n_reads, d_len, d_nseeds, d_lrep,
+	hipStream_t st = (hipStream_t)stream;
+	hipLaunchKernelGGL((chain_kernel<CK_MAXSEEDS, false>), dim3((n_reads + 63) / 64), dim3(64), lds, st, P, n_reads, d_len, d_nseeds, d_lrep,
 	                   (const i64 *)d_seed_off, (const unsigned long long *)d_sa, d_qbl, (const i64 *)d_ann_off, d_ann_alt, n_seqs, d_tab, tab_stride,
 	                   d_chains, d_seeds, d_srt, d_nchains);
-	static const bool retry = getenv("MPIBWA_CHAIN_BIG") == nullptr || atoi(getenv("MPIBWA_CHAIN_BIG")) != 0;
-	if (retry)
-		hipLaunchKernelGGL((chain_kernel<CK_MAXSEEDS_BIG, true>), dim3((n_reads + 63) / 64), dim3(64), lds_big, (hipStream_t)stream, P, n_reads, d_len, d_nseeds,
+	static const int big = getenv("MPIBWA_CHAIN_BIG") ? atoi(getenv("MPIBWA_CHAIN_BIG")) : 2;   // 0: first launch only, 1: + 255 seeds, 2: + the B-tree kernel
+	if (big >= 1)
+		hipLaunchKernelGGL((chain_kernel<CK_MAXSEEDS_BIG, true>), dim3((n_reads + 63) / 64), dim3(64), lds_big, st, P, n_reads, d_len, d_nseeds,
 		                   d_lrep, (const i64 *)d_seed_off, (const unsigned long long *)d_sa, d_qbl, (const i64 *)d_ann_off, d_ann_alt, n_seqs, d_tab,
 		                   tab_stride, d_chains, d_seeds, d_srt, d_nchains);
+	if (big >= 2 && d_gen && gen_cap > 0) {
+		uint8_t *scratch = (uint8_t *)d_gen;
+		int *list = (int *)(scratch + (size_t)gen_cap * CK_GEN_BYTES);
+		unsigned int *count = (unsigned int *)(list + gen_cap);
+		HIP_OK(hipMemsetAsync(count, 0, 4, st));
+		hipLaunchKernelGGL(chain_pick_kernel, dim3((n_reads + 255) / 256), dim3(256), 0, st, n_reads, d_len, d_nseeds, (const int *)d_nchains,
+		                   d_tab + 5 * tab_stride, gen_cap, list, count);
+		hipLaunchKernelGGL(chain_general_kernel, dim3((gen_cap + 63) / 64), dim3(64), 0, st, P, (const int *)list, (const unsigned int *)count, gen_cap, d_len,
+		                   d_nseeds, d_lrep, (const i64 *)d_seed_off, (const unsigned long long *)d_sa, d_qbl, (const i64 *)d_ann_off, d_ann_alt, n_seqs,
+		                   d_tab, scratch, d_chains, d_seeds, d_srt, d_nchains);
+	}
 	HIP_OK(hipGetLastError());
 }
 

@@ -536,8 +536,12 @@ extern "C" int64_t mi355x_chain_batch(const mem_opt_t *opt, const bntseq_t *bns,
 		ChainParams kp;
 		kp.l_pac = bns->l_pac; kp.w = opt->w; kp.max_chain_gap = opt->max_chain_gap; kp.min_chain_weight = opt->min_chain_weight;
 		kp.min_seed_len = opt->min_seed_len; kp.max_chain_extend = opt->max_chain_extend; kp.mask_level = opt->mask_level; kp.drop_ratio = opt->drop_ratio;
-		launch_chain(0, kp, n_reads, d_len, d_ns, d_lrep, d_so, d_sa, d_qbl, d_ao, d_aa, bns->n_seqs, d_tab, TS, d_ch, d_sd, d_srt, d_nch);
+		void *d_gen = nullptr;
+		const int gen_cap = std::min(n_reads, 4096);
+		HIP_OK(hipMalloc(&d_gen, chain_general_bytes(gen_cap)));
+		launch_chain(0, kp, n_reads, d_len, d_ns, d_lrep, d_so, d_sa, d_qbl, d_ao, d_aa, bns->n_seqs, d_tab, TS, d_ch, d_sd, d_srt, d_nch, d_gen, gen_cap);
 		HIP_OK(hipDeviceSynchronize());
+		(void)hipFree(d_gen);
 		HIP_OK(hipMemcpy(nch.data(), d_nch, n_reads * 4, hipMemcpyDeviceToHost));
 		HIP_OK(hipMemcpy((void *)chains.data(), d_ch, S * sizeof(DevChain), hipMemcpyDeviceToHost));
 		HIP_OK(hipMemcpy((void *)seeds.data(), d_sd, S * sizeof(DevSeed), hipMemcpyDeviceToHost));

@@ -220,7 +220,7 @@ struct PinBuf {
 
 struct Workspace {
 	PinBuf h_nch, h_cbeg, h_ccnt, h_rbeg, h_nseeds, h_lrep, h_nintv;
-	DevBuf nch, chain_cnt, reg_pos, regs_packed, ann_off, ann_alt, pack_tmp, order;
+	DevBuf nch, chain_cnt, reg_pos, regs_packed, ann_off, ann_alt, pack_tmp, order, chain_gen;
 	PinBuf h_order;
 	PinBuf h_regs2;
 	PinBuf h_flat, h_sa, h_qbl, h_chains, h_seeds, h_srt, h_regs, h_nregs, h_mreq[2], h_mres[2], h_ahdr[2], h_apool[2];
@@ -523,8 +523,11 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 				kp.l_pac = bns->l_pac; kp.w = opt->w; kp.max_chain_gap = opt->max_chain_gap; kp.min_chain_weight = opt->min_chain_weight;
 				kp.min_seed_len = opt->min_seed_len; kp.max_chain_extend = opt->max_chain_extend;
 				kp.mask_level = opt->mask_level; kp.drop_ratio = opt->drop_ratio;
+				// third launch (reads with more than 9 chains): room for a sixth of the reads, the rest of them stays with the host
+				const int gen_cap = std::min(n, std::max(4096, n / 6));
+				void *d_gen = W.chain_gen.ensure(chain_general_bytes(gen_cap));
 				launch_chain(st, kp, n, d_len_r, d_nseeds, d_lrep, d_seed_off, d_sa, d_qbl, d_ann_off, d_ann_alt, bns->n_seqs, d_tab, TS, d_chains, d_seeds,
-				             d_srt, d_nch);
+				             d_srt, d_nch, d_gen, gen_cap);
 				nch = (int *)W.h_nch.ensure((size_t)n * 4 + 8);
 				HIP_OK(hipMemcpyAsync(nch, d_nch, (size_t)n * 4, hipMemcpyDeviceToHost, st));
 			}

@@ -12,6 +12,8 @@ def adversarial_interval_sets(rng, n_cases, l_pac, offs, n_seqs):
         lq = int(rng.choice([100, 150, 151, 250]))
         mode = rng.random()
         n_anchor = int(rng.integers(1, 4)) if mode < 0.6 else int(rng.integers(3, 14))
+        if mode > 0.96:
+            n_anchor = int(rng.integers(15, 90))            # dozens of chains: the ordered map grows past one node, then past two levels
         anchors = []
         for _ in range(n_anchor):
             k = int(rng.integers(0, n_seqs))
@@ -24,6 +26,8 @@ def adversarial_interval_sets(rng, n_cases, l_pac, offs, n_seqs):
         if rng.random() < 0.05 and n_seqs > 1:
             anchors[0] = offs[int(rng.integers(1, n_seqs))] - 10   # seeds bridging two contigs
         n_iv = int(rng.integers(1, 16)) if mode < 0.9 else int(rng.integers(30, 50))
+        if mode > 0.96:
+            n_iv = int(rng.integers(60, 110))
         ivs = {}
         for _ in range(n_iv):
             qb = int(rng.integers(0, lq - 19))
@@ -34,7 +38,7 @@ def adversarial_interval_sets(rng, n_cases, l_pac, offs, n_seqs):
                 shift = int(rng.choice([0, 0, 0, 1, -1, 3, 120, 20000]))
                 hits.append(min(max(a + qb + shift, 0), 2 * l_pac - ln - 1))
             ivs[(qb, qb + ln)] = hits
-        if rng.random() < 0.3:                               # equal weights: disjoint seeds of the same length
+        if rng.random() < 0.3 and mode <= 0.96:              # equal weights: disjoint seeds of the same length
             ivs = {((30 * j) % (lq - 25), (30 * j) % (lq - 25) + 25): [min(max(anchors[j % len(anchors)] + 30 * j + (0 if j % 2 else 7), 0), 2 * l_pac - 26)]
                    for j in range(int(rng.integers(3, 9)))}
         cases.append((lq, [(qb, qe, h) for (qb, qe), h in ivs.items()]))

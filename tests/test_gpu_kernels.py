@@ -242,9 +242,10 @@ def test_matesw_kernel_matches_reference_ksw_align2(engine):
 
 
 def test_chain_kernel_matches_host_chaining(engine, genome):
-    """chain_kernel == the host's restatement of mem_chain + mem_chain_flt (kbtree rules for equal keys, the introsort's
-    partition pass, float compares) on adversarial seed sets: equal positions, equal weights, up to 9 chains, > 9 chains and
-    > 64 seeds (which the kernel must decline), both strands, seeds bridging contigs."""
+    """The three chaining launches (one tree node / 255 seeds / the B-tree kernel for up to 255 chains) == the host's restatement
+    of mem_chain + mem_chain_flt (kbtree rules for equal keys and splits, the introsort, float compares) on adversarial seed sets:
+    equal positions, equal weights, up to 9 chains, dozens of chains, > 64 seeds, > 255 seeds (declined), both strands, seeds
+    bridging contigs."""
     rng = np.random.default_rng(77)
     opt = engine.opt()
     l_pac = int(engine.bns.contents.l_pac)
@@ -268,6 +269,9 @@ def test_chain_kernel_matches_host_chaining(engine, genome):
         if rng.random() < 0.05:
             anchors[0] = offs[int(rng.integers(1, n_seqs))] - 10 if n_seqs > 1 else anchors[0]   # seeds bridging two contigs
         ns = int(rng.integers(1, 30)) if mode < 0.9 else int(rng.integers(60, 90))
+        if mode > 0.96:       # dozens of chains, up to and beyond what the B-tree kernel takes
+            anchors = anchors + [int(rng.integers(0, 2 * l_pac - 400)) for _ in range(int(rng.integers(15, 120)))]
+            ns = int(rng.integers(120, 300))
         sd = []
         for _ in range(ns):
             a = anchors[int(rng.integers(0, len(anchors)))]
@@ -275,7 +279,7 @@ def test_chain_kernel_matches_host_chaining(engine, genome):
             ln = int(rng.integers(19, min(lq - qb, 80) + 1))
             shift = int(rng.choice([0, 0, 0, 1, -1, 3, 120, 20000]))
             sd.append((min(max(a + qb + shift, 0), 2 * l_pac - ln - 1), qb, ln))
-        if rng.random() < 0.3:                    # equal weights: several disjoint seeds of the same length
+        if rng.random() < 0.3 and mode <= 0.96:   # equal weights: several disjoint seeds of the same length
             ln = 25
             sd = [(min(max(anchors[j % len(anchors)] + 30 * j + (0 if j % 2 else 7), 0), 2 * l_pac - ln - 1), (30 * j) % (lq - 25), ln)
                   for j in range(int(rng.integers(3, 9)))]
@@ -283,22 +287,24 @@ def test_chain_kernel_matches_host_chaining(engine, genome):
         lens.append(lq); lrep.append(int(rng.integers(0, lq))); seedsets.append(sd)
     dev = engine.chains(opt, lens, lrep, seedsets, 0)
     host = engine.chains(opt, lens, lrep, seedsets, 1)
-    n_dev = n_declined = n_multi = 0
+    n_dev = n_declined = n_multi = n_big = 0
     for d, h, sd in zip(dev, host, seedsets):
         if d is None:
             n_declined += 1
+            assert len(sd) > 255 or len({s[0] - s[1] for s in sd}) > 200, (len(sd), "declined without reason")
             continue
         assert d == h, (sd, d, h)
         n_dev += 1
         n_multi += len(h) >= 3
-    assert n_dev > 2500 and n_declined > 100 and n_multi > 200
+        n_big += len(sd) > 100
+    assert n_dev > 3800 and n_declined > 10 and n_multi > 200 and n_big > 40
 
 
 @pytest.mark.skipif(not po.chain_inject_available(), reason="oracle/_ref/libchaininj.so not present")
 def test_chain_kernel_matches_the_reference_mem_chain(engine, genome):
     """chain_kernel vs the reference's OWN mem_chain + mem_chain_flt (src/bwamem.c:251-385), which oracle/chain_inject.c
-    lets run on chosen seed sets: equal positions, equal weights, up to 9 chains, more than 9 chains / 64 seeds (the kernel
-    must decline those and the library's host path must get them right), both strands, contig-bridging seeds."""
+    lets run on chosen seed sets: equal positions, equal weights, up to 9 chains, dozens of chains (the B-tree kernel), more than
+    255 seeds (declined: the library's host path must get them right), both strands, contig-bridging seeds."""
     rng = np.random.default_rng(78)
     ref = po.RefIndex(genome["prefix"])
     opt, ropt = engine.opt(), ref.opt()
@@ -310,18 +316,20 @@ def test_chain_kernel_matches_the_reference_mem_chain(engine, genome):
     lrep = [0] * len(lens)
     dev = engine.chains(opt, lens, lrep, seedsets, 0)
     host = engine.chains(opt, lens, lrep, seedsets, 1)
-    n_dev = n_declined = n_multi = 0
+    n_dev = n_declined = n_multi = n_big = 0
     for d, h, w, sd in zip(dev, host, want, seedsets):
         hh = [(c[0], c[5], c[6]) for c in h]
         assert hh == w, ("host path", sd, hh, w)
         if d is None:
             n_declined += 1
+            assert len(sd) > 255, (len(sd), "declined without reason")
             continue
         dd = [(c[0], c[5], c[6]) for c in d]
         assert dd == w, ("chain_kernel", sd, dd, w)
         n_dev += 1
         n_multi += len(w) >= 3
-    assert n_dev > 1800 and n_declined > 50 and n_multi > 150
+        n_big += len(sd) > 100
+    assert n_dev > 2800 and n_multi > 150 and n_big > 40
 
 
 def _pack2bit(ref):
