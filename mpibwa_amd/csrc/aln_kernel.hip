@@ -69,6 +69,7 @@ __device__ __forceinline__ int put_num(uint8_t *md, int len, int v, int lane)
 #define ALN_PENDING 2
 // counters[]: [0] bytes of the result pool handed out, [ALN_CNT + k] length of the request list of kind k
 #define ALN_CNT 8
+#define ALN_SLAB 1024u
 
 __device__ __forceinline__ bool aln_invalid(const AlnParams &P, const AlnReq &R, int max_len, int tcap)
 {
@@ -108,7 +109,8 @@ template <int KIND>
 __device__ __forceinline__ void aln_one(int rq, const AlnParams &P, const WxParams &X, int n_req, const AlnReq *__restrict__ reqs,
                                         const uint8_t *__restrict__ seq, const int64_t *__restrict__ off, const uint8_t *__restrict__ pac,
                                         const int *__restrict__ gaptab, AlnHdr *__restrict__ hdr, uint8_t *__restrict__ pool,
-                                        unsigned long long *counters, unsigned long long pool_bytes, int max_len, int tcap, int *lists, int dp_kind)
+                                        unsigned long long *counters, unsigned long long pool_bytes, int max_len, int tcap, int *lists, int dp_kind,
+                                        unsigned long long &slab_at, unsigned &slab_left)
 {
 	extern __shared__ int lds_raw[];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -364,8 +366,15 @@ __device__ __forceinline__ void aln_one(int rq, const AlnParams &P, const WxPara
 	// ---- hand the record over: [cigar u32 x n][md bytes] in the pool ----
 	const unsigned need = (unsigned)n_cig * 4 + (((unsigned)md_len + 3) & ~3u);
 	unsigned long long at = 0;
-	if (lane == 0) at = atomicAdd(&counters[0], (unsigned long long)need);
-	at = __shfl(at, 0);
+	// the pool is handed out in slabs of ALN_SLAB bytes per wave: one atomic on the pool cursor per ~25 requests instead of one per
+	// request (an atomic on one address costs ~10 ns of a queue the whole chip shares: 680 000 of them were half of this stage)
+	if (need <= slab_left) { at = slab_at; slab_at += need; slab_left -= need; }
+	else {
+		const unsigned take = need > ALN_SLAB ? need : ALN_SLAB;
+		if (lane == 0) at = atomicAdd(&counters[0], (unsigned long long)take);
+		at = __shfl(at, 0);
+		slab_at = at + need; slab_left = take - need;
+	}
 	if (at + need > pool_bytes) {
 		out.flags = 1;
 		if (lane == 0) hdr[rq] = out;
@@ -389,8 +398,11 @@ aln_kernel(AlnParams P, WxParams X, int n_req, const AlnReq *__restrict__ reqs, 
 	// the lists of KIND 1 and 2 are added to by the launches before them on the stream
 	const int n = (int)counters[ALN_CNT + KIND];
 	const int *mine = lists + (size_t)KIND * n_req;
+	unsigned long long slab_at = 0;
+	unsigned slab_left = 0;
 	for (int k = blockIdx.x * ALN_WAVES + wave; k < n; k += gridDim.x * ALN_WAVES) {
-		aln_one<KIND>(KIND != 0 ? __builtin_amdgcn_readfirstlane(mine[k]) : mine[k], P, X, n_req, reqs, seq, off, pac, gaptab, hdr, pool, counters, pool_bytes, max_len, tcap, lists, dp_kind);
+		aln_one<KIND>(KIND != 0 ? __builtin_amdgcn_readfirstlane(mine[k]) : mine[k], P, X, n_req, reqs, seq, off, pac, gaptab, hdr, pool, counters, pool_bytes, max_len, tcap, lists, dp_kind,
+		              slab_at, slab_left);
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the wave's LDS slice is reused by its next request
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

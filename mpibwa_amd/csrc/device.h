@@ -104,7 +104,9 @@ struct C2aParams {
 	int a, w, pen_clip5, pen_clip3;
 	int early;    // 1: row loops end as soon as no output the kernel reads can change (wave_ext.cuh); 0: the reference's rows; 2: both, differences counted
 };
-// counters[] of c2a_kernel: [0] DP cells computed, [1] extensions, [3] (early = 2) extensions whose used outputs differ
+// counters of c2a_kernel: C2A_STAT_SLOTS lines of 8 u64 (zeroed by the caller, summed by the caller): [0] DP cells computed, [1] extensions,
+// [2] extensions answered without DP, [3] (early = 2) extensions whose used outputs differ
+#define C2A_STAT_SLOTS 256
 void launch_c2a(void *stream, const C2aParams &P, const ExtParams &ep, int n_reads, const uint8_t *d_seq, const int64_t *d_off,
                 const int *d_len, const int *d_chain_beg, const int *d_chain_cnt, const DevChain *d_chains, const DevSeed *d_seeds, unsigned int *d_srt,
                 const int *d_reg_beg, DevReg *d_regs, int *d_nregs, const int *d_tab, int tab_stride, const uint8_t *d_pac, unsigned long long *d_counters,

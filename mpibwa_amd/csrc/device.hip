@@ -631,7 +631,7 @@ extern "C" int mi355x_global_batch(const mem_opt_t *opt, int64_t l_pac, const ui
 		int g = max_ins > max_del ? max_ins : max_del;
 		gaptab[l] = g > 1 ? g : 1;
 	}
-	const size_t pool_bytes = (size_t)n_req * (4 * 96 + 768) + (1 << 20);
+	const size_t pool_bytes = (size_t)n_req * (4 * 96 + 768) + ((size_t)48 << 20);
 	uint8_t *d_seq, *d_pac, *d_pool; int64_t *d_off; AlnReq *d_req; AlnHdr *d_hdr; int *d_gap, *d_lists; unsigned long long *d_cnt;
 	HIP_OK(hipMalloc(&d_seq, flat.size())); HIP_OK(hipMalloc(&d_pac, l_pac / 4 + 16)); HIP_OK(hipMalloc(&d_pool, pool_bytes));
 	HIP_OK(hipMalloc(&d_off, (size_t)(n_reads + 1) * 8)); HIP_OK(hipMalloc(&d_req, (size_t)n_req * sizeof(AlnReq)));

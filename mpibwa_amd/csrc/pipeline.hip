@@ -220,7 +220,8 @@ struct PinBuf {
 
 struct Workspace {
 	PinBuf h_nch, h_cbeg, h_ccnt, h_rbeg, h_nseeds, h_lrep, h_nintv;
-	DevBuf nch, chain_cnt, reg_pos, regs_packed, ann_off, ann_alt, pack_tmp, order, chain_gen;
+	DevBuf nch, chain_cnt, reg_pos, regs_packed, ann_off, ann_alt, pack_tmp, order, chain_gen, c2a_stat;
+	PinBuf h_c2a_stat;
 	PinBuf h_order;
 	PinBuf h_regs2;
 	PinBuf h_flat, h_sa, h_qbl, h_chains, h_seeds, h_srt, h_regs, h_nregs, h_mreq[2], h_mres[2], h_ahdr[2], h_apool[2];
@@ -671,7 +672,8 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			if (NC) HIP_OK(hipMemcpyAsync(d_chains + base, hchains, (size_t)NC * sizeof(DevChain), hipMemcpyHostToDevice, st));
 			if (NS) HIP_OK(hipMemcpyAsync(d_seeds + base, hseeds, (size_t)NS * sizeof(DevSeed), hipMemcpyHostToDevice, st));
 			if (NS) HIP_OK(hipMemcpyAsync(d_srt + base, hsrt, (size_t)NS * 4, hipMemcpyHostToDevice, st));
-			HIP_OK(hipMemsetAsync(d_cnt, 0, 256, st));
+			unsigned long long *d_c2a_stat = (unsigned long long *)W.c2a_stat.ensure(C2A_STAT_SLOTS * 64);
+			HIP_OK(hipMemsetAsync(d_c2a_stat, 0, C2A_STAT_SLOTS * 64, st));
 			// launch order: reads by decreasing number of seeds (counting sort), the long-running ones first
 			int *order = (int *)W.h_order.ensure((size_t)n * 4 + 8);
 			{
@@ -693,7 +695,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			ev_ext.start(st);
 			// one wavefront per read (any read length)
 			launch_c2a(st, cp, ep, n, d_seq, d_off_r, d_len_r, d_chain_beg, d_chain_cnt, d_chains, d_seeds, d_srt, d_reg_beg, d_regs, d_nregs,
-			           d_tab, TS, (const uint8_t *)ix.d_pac, d_cnt, max_len, d_order);
+			           d_tab, TS, (const uint8_t *)ix.d_pac, d_c2a_stat, max_len, d_order);
 			ev_ext.stop(st);
 			// the regions sit in sparse per-read slots: prefix-sum + pack on the device, queued behind the kernel, then one
 			// copy of what is usually enough (2 regions per read); the rare rest follows once the total is known
@@ -704,16 +706,18 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			void *d_tmp = W.pack_tmp.ensure(tmp_bytes);
 			launch_reg_pack(st, n, d_reg_beg, d_nregs, d_reg_pos, d_regs, d_packed, d_tmp, tmp_bytes);
 			hregs = (DevReg *)W.h_regs.ensure((size_t)guess * sizeof(DevReg) + 8);
-			HIP_OK(hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, st));
+			unsigned long long *stat_h = (unsigned long long *)W.h_c2a_stat.ensure(C2A_STAT_SLOTS * 64);
+			HIP_OK(hipMemcpyAsync(stat_h, d_c2a_stat, C2A_STAT_SLOTS * 64, hipMemcpyDeviceToHost, st));
 			HIP_OK(hipMemcpyAsync(nregs, d_nregs, (size_t)n * 4, hipMemcpyDeviceToHost, st));
 			HIP_OK(hipMemcpyAsync(hregs, d_packed, (size_t)guess * sizeof(DevReg), hipMemcpyDeviceToHost, st));
 			stream_wait(st);
 			HIP_OK(hipGetLastError());
 			turn.unlock();
 			ps.k_ext = ev_ext.ms();
+			for (int k = 0; k < 4; ++k) { cnt[k] = 0; for (int sl = 0; sl < C2A_STAT_SLOTS; ++sl) cnt[k] += stat_h[sl * 8 + k]; }
 			ps.cells = cnt[0]; ps.n_ext = cnt[1];
 			if (cp.early == 2 && cnt[3]) die("c2a_kernel: %llu of %llu extensions change when their row loops stop early", cnt[3], cnt[1]);
-			if (getenv("MPIBWA_CPUSEC")) fprintf(stderr, "[c2a] %llu extensions, %llu cells\n", cnt[1], cnt[0]);
+			if (getenv("MPIBWA_CPUSEC")) fprintf(stderr, "[c2a] %llu extensions, %llu without DP, %llu cells, kernel %.2f ms\n", cnt[1], cnt[2], cnt[0], ev_ext.ms());
 			for (int i = 0; i < n; ++i) reg_pos[i + 1] = reg_pos[i] + nregs[i];
 			const int64_t NR = reg_pos[n];
 			if (NR > guess) {
@@ -1051,7 +1055,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		if (!gpu_aln || n_req == 0) return;
 		static_assert(sizeof(AlnReq) == sizeof(AlnReqH) && sizeof(AlnHdr) == sizeof(AlnHdrH), "host/device record layouts differ");
 		P.st = a_streams[slot];
-		P.pool_bytes = n_req * 96 + (1 << 20);
+		P.pool_bytes = n_req * 96 + ((size_t)48 << 20);   // + room for the partly used last slab of every wave (aln_kernel.hip: ALN_SLAB)
 		AlnReq *d_req = (AlnReq *)(slot ? W.areq2 : W.areq).ensure(n_req * sizeof(AlnReq));
 		P.d_hdr = (AlnHdr *)(slot ? W.ahdr2 : W.ahdr).ensure(n_req * sizeof(AlnHdr));
 		P.d_pool = (uint8_t *)(slot ? W.apool2 : W.apool).ensure(P.pool_bytes);
