@@ -44,6 +44,7 @@ typedef unsigned int u32;
 #define LCAP 24
 #define QSLOT 256
 #define SMEM_BLOCK 256     // 4 waves = 64 quads per workgroup
+#define SMEM_FETCH 16      // reads a wave takes from the work counter at a time (>= the 16 quads of a wave)
 
 template <int CTRL>
 __device__ __forceinline__ u32 dpp(u32 v)
@@ -175,7 +176,8 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 	u64 ik0 = 0, ik1 = 0, ik2 = 0, ik_end = 0, lastc_x2 = 0;
 	u64 p0 = 0, p1 = 0, p2 = 0, p_end = 0;   // backward: the list entry being extended
 	u64 *myout = out;
-	u32 nblk = 0;
+	u32 nblk = 0;                 // occ blocks of all the reads of the quad: added to the launch's counter once, at the end
+	int w_next = 0, w_end = 0;    // the wave's stock of reads (wave-uniform)
 	bool overflow = false;
 
 	// start the forward sweep of bwt_smem1a at position x
@@ -232,12 +234,32 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 				}
 			}
 		}
+		// ---- the quads that need a read are served from the wave's own small stock: one atomic on the work counter per
+		// SMEM_FETCH reads of the wave instead of one per read (an atomic on one address costs ~10 ns of a queue the whole chip
+		// shares; the stock is the wave's, so no quad idles while another one hoards reads) ----
+		int r_new = -1;
+		{
+			const bool want = st == ST_PICK && pass == 0;
+			const unsigned long long wantm = __ballot(want && c == 0);
+			if (wantm) {
+				const int n_want = __popcll(wantm), avail = w_end - w_next;
+				int base2 = 0;
+				if (n_want > avail) {   // SMEM_FETCH >= 16 quads: one refill always covers the rest
+					if (lane == __ffsll((long long)wantm) - 1) base2 = (int)atomicAdd(&counters[0], (u64)SMEM_FETCH);
+					base2 = __shfl(base2, __ffsll((long long)wantm) - 1);
+				}
+				const int k = __popcll(wantm & ((1ull << qlead) - 1));   // this quad's rank among the wanting ones
+				if (want) r_new = k < avail ? w_next + k : base2 + (k - avail);
+				if (n_want > avail) { w_next = base2 + (n_want - avail); w_end = base2 + SMEM_FETCH; }
+				else w_next += n_want;
+			}
+		}
 		// ---- between calls: next call of this pass, next pass, next read ----
 		while (st == ST_PICK) {
 			if (pass == 0) {
-				int r = 0;
-				if (c == 0) r = (int)atomicAdd(&counters[0], 1ull);
-				r = __shfl(r, qlead);
+				if (r_new < 0) break;   // (a quad that has just finished a read gets its next one at the top of the next iteration)
+				const int r = r_new;
+				r_new = -1;
 				if (r >= n_reads) { st = ST_DONE; break; }
 				rd = r; gq = seq + off[r]; len = lens[r];
 				q_lds = QLDS || len <= QS;
@@ -249,7 +271,7 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 				nout = p3_first = nout_arr[r];          // the third pass (smem_p3_kernel, launched before) has written its intervals
 				overflow = nout > cap;
 				if (overflow) nout = p3_first = cap;
-				x = 0; nblk = 0;
+				x = 0;
 				pass = len < sp.min_seed_len ? 4 : 1;   // src/bwamem.c:260: shorter than a seed => no intervals
 			}
 			if (pass == 1) {
@@ -271,7 +293,6 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 			} else if (pass == 4) {   // read finished
 				if (c == 0) {
 					nout_arr[rd] = nout;
-					atomicAdd(&counters[1], (u64)nblk);
 					if (overflow) atomicAdd(&counters[2], 1ull);
 				}
 				pass = 0;
@@ -310,6 +331,7 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 			}
 		}
 	}
+	if (c == 0 && nblk) atomicAdd(&counters[1], (u64)nblk);
 }
 
 // One quad per (k+1)-mer: the forward extensions of bwt_seed_strategy1 (src/bwt.c:358-379) with the very function the

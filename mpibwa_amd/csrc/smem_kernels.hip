@@ -146,7 +146,7 @@ smem_p3_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__
 	u64 ik0 = 0, ik1 = 0, ik2 = 0;
 	u64 *myout = out;
 	const uint8_t *rbase = seq;
-	u32 nblk = 0, nblk_tab = 0;   // occ blocks of this read's extensions; the part of them that the jump table stood in for
+	u32 nblk = 0, nblk_tab = 0;   // occ blocks of the extensions of all the lane's reads (added to the launch's counters once, at the end); the part of them that the jump table stood in for
 	bool overflow = false, need = false;
 	ReadWin W;
 	W.reset();
@@ -203,7 +203,7 @@ smem_p3_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__
 			else {
 				rd = r_next; len = nx_len; rbase = seq + nx_off;
 				myout = out + (size_t)rd * cap * 4;
-				nout = 0; x = 0; nblk = 0; nblk_tab = 0; overflow = false;
+				nout = 0; x = 0; overflow = false;
 				W.reset();
 				if (len < sp.min_seed_len || sp.max_mem_intv <= 0) x = len;   // src/bwamem.c:260, :148
 				st = P_SKIP;
@@ -220,8 +220,6 @@ smem_p3_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__
 			if (!blocked) {
 				if (x >= len) {   // the read is finished
 					nout_arr[rd] = nout;
-					if (nblk) atomicAdd(&counters[1], (u64)nblk);
-					if (nblk_tab) atomicAdd(&counters[4], (u64)nblk_tab);
 					if (overflow) atomicAdd(&counters[2], 1ull);
 					st = P_PICK;
 				} else if (use_tab && x + fm.p3_k < len) { st = P_KMER; t = 0; idx = 0; }
@@ -257,6 +255,8 @@ smem_p3_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__
 			if (ahead < len && !W.have(ahead)) { wq = ahead & ~7; wkeep = i; }
 		}
 	}
+	if (nblk) atomicAdd(&counters[1], (u64)nblk);
+	if (nblk_tab) atomicAdd(&counters[4], (u64)nblk_tab);
 }
 
 // ---- launch ----------------------------------------------------------------------------------------------------------
