@@ -34,8 +34,10 @@ namespace {
 typedef long long i64;
 
 #define CK_MAXCH 9
-#define CK_MAXSEEDS 64         // first launch: every read, up to this many seeds
-#define CK_MAXSEEDS_BIG 255    // second and third launch: the reads the first one declined (seed numbers are bytes)
+#define CK_MAXCH_SMALL 4
+#define CK_MAXSEEDS_SMALL 16   // first launch: every read, up to this many seeds and CK_MAXCH_SMALL chains
+#define CK_MAXSEEDS 64         // second launch: what the first declined, up to this many seeds
+#define CK_MAXSEEDS_BIG 255    // third launch (and the B-tree kernel): reads with more seeds than that (seed numbers are bytes)
 #define CK_MAXCH_GEN 255       // third launch: chains per read (chain numbers are bytes, 255 = none)
 #define CK_MAXNODES 128        // ... and B-tree nodes per read (255 keys in nodes of >= 4 need 64 leaves + their parents)
 enum { F_POS_LO = 0, F_POS_HI, F_FIRST_Q, F_LAST_R_LO, F_LAST_R_HI, F_LAST_Q, F_LAST_LEN, F_RID, F_N, F_W, F_KEPT, F_FIRSTOV, F_NFIELDS,
@@ -46,15 +48,16 @@ enum { F_POS_LO = 0, F_POS_HI, F_FIRST_Q, F_LAST_R_LO, F_LAST_R_HI, F_LAST_Q, F_
 // StoreGen: up to 255 chains: the same fields in a per-read slice of an HBM scratch buffer, plus the seeds of a chain as a
 //           linked list in arrival order (the weight and emission loops of a read with 150 seeds and 50 chains would otherwise
 //           scan all seeds once per chain) and the nodes of the B-tree.
+template <int MAXCH_>
 struct StoreLds {
-	static constexpr int MAXCH = CK_MAXCH;
+	static constexpr int MAXCH = MAXCH_;
 	static constexpr bool GENERAL = false;
-	uint32_t *tab;    // [F_NFIELDS * CK_MAXCH][64]
+	uint32_t *tab;    // [F_NFIELDS * MAXCH][64]
 	uint8_t *cid_;    // [MAXS + 1][64]     chain id of every seed (255 = in no chain)
 	uint8_t *ord_;    // [16][64]           chain ids in tree order, later in filter order
 	uint8_t *tmp_;    // [MAXS + 1][64]     scratch: members of one chain
 	int lane;
-	__device__ __forceinline__ uint32_t &f(int field, int id) const { return tab[(field * CK_MAXCH + id) * 64 + lane]; }
+	__device__ __forceinline__ uint32_t &f(int field, int id) const { return tab[(field * MAXCH + id) * 64 + lane]; }
 	__device__ __forceinline__ uint8_t &cid(int k) const { return cid_[k * 64 + lane]; }
 	__device__ __forceinline__ uint8_t &ord(int k) const { return ord_[k * 64 + lane]; }
 	__device__ __forceinline__ uint8_t &tmp(int k) const { return tmp_[k * 64 + lane]; }
@@ -516,40 +519,48 @@ __device__ __forceinline__ int chain_read(const S &L, const ChainParams &P, int 
 	return n_out;
 }
 
-// MAXS: seeds per read the instantiation has LDS for.  RETRY: second launch — only the reads the first launch declined
-// because they have more than CK_MAXSEEDS seeds (a few per cent of 2x150 bp reads, with ~150 seeds each).
-template <int MAXS, bool RETRY>
+// Three launches with growing LDS footprints, because a lane's working set decides how many waves a CU holds and the kernel
+// lives on latency hiding: <16 seeds, 4 chains> takes every read first (15.5 KB per wave: 10 waves per CU; nine reads in ten stay
+// here), <64, 9> (37 KB: 4 waves) retries what that declined, <255, 9> (62 KB) the reads with 65-255 seeds.
+// MAXS / MAXCH: seeds / chains per read the instantiation has LDS for.  LO >= 0: a retry — only reads an earlier launch declined
+// (n_chains = -1) with more than LO seeds.
+template <int MAXS, int MAXCH, int LO>
 __global__ void __launch_bounds__(64)
 chain_kernel(ChainParams P, int n_reads, const int *__restrict__ lens, const int *__restrict__ n_seeds, const int *__restrict__ l_rep,
              const i64 *__restrict__ seed_off, const unsigned long long *__restrict__ sa, const int32_t *__restrict__ qbl,
              const i64 *__restrict__ ann_off, const uint8_t *__restrict__ ann_alt, int n_seqs, const int *__restrict__ tab, int tab_stride,
-             DevChain *__restrict__ chains, DevSeed *__restrict__ seeds, unsigned int *__restrict__ srt, int *__restrict__ n_chains)
+             DevChain *__restrict__ chains, DevSeed *__restrict__ seeds, unsigned int *__restrict__ srt, int *__restrict__ n_chains,
+             const int *__restrict__ list, const unsigned int *__restrict__ list_n)
 {
 	extern __shared__ uint32_t lds_raw[];
-	StoreLds L;
+	StoreLds<MAXCH> L;
 	L.lane = threadIdx.x;
 	L.tab = lds_raw;
-	L.cid_ = (uint8_t *)(lds_raw + F_NFIELDS * CK_MAXCH * 64);
+	L.cid_ = (uint8_t *)(lds_raw + F_NFIELDS * MAXCH * 64);
 	L.ord_ = L.cid_ + (MAXS + 1) * 64;
 	L.tmp_ = L.ord_ + 16 * 64;
-	const int rd = blockIdx.x * 64 + threadIdx.x;
+	// a retry walks the list of the reads it is for (chain_pick_kernel), so that its waves are full: handed the whole batch, nearly
+	// every wave would hold one or two such reads and run the whole serial path for them
+	int rd = blockIdx.x * 64 + threadIdx.x;
+	if (list) { if (rd >= (int)*list_n) return; rd = list[rd]; }
 	if (rd >= n_reads) return;
 	const int ns = n_seeds[rd], lq = lens[rd];
 	const int *gap = tab, *noflt = tab + 5 * tab_stride;
-	if (RETRY) { if (n_chains[rd] != -1 || ns <= CK_MAXSEEDS) return; }
+	if (LO >= 0) { if (n_chains[rd] != -1 || ns <= LO) return; }
 	else if (ns == 0) { n_chains[rd] = 0; return; }
 	if (ns > MAXS || !noflt[lq]) { n_chains[rd] = -1; return; }
-	n_chains[rd] = chain_read<StoreLds, MapArray>(L, P, rd, ns, lq, seed_off[rd], l_rep, sa, qbl, ann_off, ann_alt, n_seqs, gap, chains, seeds, srt);
+	n_chains[rd] = chain_read<StoreLds<MAXCH>, MapArray>(L, P, rd, ns, lq, seed_off[rd], l_rep, sa, qbl, ann_off, ann_alt, n_seqs, gap, chains, seeds, srt);
 }
 
-// Third launch, two kernels: list the reads both single-node launches declined (more than 9 chains) and that the general
-// kernel has room for, then chain them with the reference's B-tree, a lane per read, the working set in an HBM slice.
+// chain_pick_kernel lists the reads a later launch is for: declined so far (n_chains = -1), lo < seeds <= hi, at most cap of them.
+// Last launch: the reads all single-node launches declined (more than 9 chains) are chained with the reference's B-tree, a lane per
+// read, the working set in an HBM slice.
 __global__ void __launch_bounds__(256)
 chain_pick_kernel(int n_reads, const int *__restrict__ lens, const int *__restrict__ n_seeds, const int *__restrict__ n_chains,
-                  const int *__restrict__ noflt, int cap, int *__restrict__ list, unsigned int *__restrict__ count)
+                  const int *__restrict__ noflt, int lo, int hi, int cap, int *__restrict__ list, unsigned int *__restrict__ count)
 {
 	const int rd = blockIdx.x * 256 + threadIdx.x;
-	const bool mine = rd < n_reads && n_chains[rd] == -1 && n_seeds[rd] <= CK_MAXSEEDS_BIG && noflt[lens[rd]] != 0;
+	const bool mine = rd < n_reads && n_chains[rd] == -1 && n_seeds[rd] > lo && n_seeds[rd] <= hi && noflt[lens[rd]] != 0;
 	const unsigned long long m = __ballot(mine);
 	if (!m) return;
 	const int lane = threadIdx.x & 63, lead = __ffsll((long long)m) - 1;
@@ -614,9 +625,9 @@ void launch_reg_pack(void *stream, int n_reads, const int *d_reg_beg, const int 
 	HIP_OK(hipGetLastError());
 }
 
-static size_t chain_lds_bytes(int maxs) { return (size_t)F_NFIELDS * CK_MAXCH * 64 * 4 + (size_t)(2 * (maxs + 1) + 16) * 64; }
+static size_t chain_lds_bytes(int maxs, int maxch) { return (size_t)F_NFIELDS * maxch * 64 * 4 + (size_t)(2 * (maxs + 1) + 16) * 64; }
 
-size_t chain_general_bytes(int cap) { return (size_t)cap * CK_GEN_BYTES + (size_t)cap * 4 + 256; }
+size_t chain_general_bytes(int cap, int n_reads) { return (size_t)cap * CK_GEN_BYTES + (size_t)cap * 4 + (size_t)n_reads * 8 + 512; }
 
 // d_gen / gen_cap: scratch of chain_general_bytes(gen_cap) for the third launch (reads with more than 9 chains, up to 255
 // seeds and chains, at most gen_cap of them per call); null / 0: those reads keep n_chains = -1 (host path).
@@ -626,33 +637,45 @@ void launch_chain(void *stream, const ChainParams &P, int n_reads, const int *d_
                   void *d_gen, int gen_cap)
 {
 	if (n_reads <= 0) return;
-	const size_t lds = chain_lds_bytes(CK_MAXSEEDS), lds_big = chain_lds_bytes(CK_MAXSEEDS_BIG);
+	const size_t lds_s = chain_lds_bytes(CK_MAXSEEDS_SMALL, CK_MAXCH_SMALL), lds = chain_lds_bytes(CK_MAXSEEDS, CK_MAXCH), lds_big = chain_lds_bytes(CK_MAXSEEDS_BIG, CK_MAXCH);
 	static bool s_attr = false;
 	if (!s_attr) {
-		if (lds > 64 * 1024) HIP_OK(hipFuncSetAttribute((const void *)chain_kernel<CK_MAXSEEDS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-		if (lds_big > 64 * 1024) HIP_OK(hipFuncSetAttribute((const void *)chain_kernel<CK_MAXSEEDS_BIG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
+		if (lds > 64 * 1024) HIP_OK(hipFuncSetAttribute((const void *)chain_kernel<CK_MAXSEEDS, CK_MAXCH, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		if (lds_big > 64 * 1024) HIP_OK(hipFuncSetAttribute((const void *)chain_kernel<CK_MAXSEEDS_BIG, CK_MAXCH, CK_MAXSEEDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
 		s_attr = true;
 	}
 	hipStream_t st = (hipStream_t)stream;
-	hipLaunchKernelGGL((chain_kernel<CK_MAXSEEDS, false>), dim3((n_reads + 63) / 64), dim3(64), lds, st, P, n_reads, d_len, d_nseeds, d_lrep,
-	                   (const i64 *)d_seed_off, (const unsigned long long *)d_sa, d_qbl, (const i64 *)d_ann_off, d_ann_alt, n_seqs, d_tab, tab_stride,
-	                   d_chains, d_seeds, d_srt, d_nchains);
-	static const int big = getenv("MPIBWA_CHAIN_BIG") ? atoi(getenv("MPIBWA_CHAIN_BIG")) : 2;   // 0: first launch only, 1: + 255 seeds, 2: + the B-tree kernel
-	if (big >= 1)
-		hipLaunchKernelGGL((chain_kernel<CK_MAXSEEDS_BIG, true>), dim3((n_reads + 63) / 64), dim3(64), lds_big, st, P, n_reads, d_len, d_nseeds,
-		                   d_lrep, (const i64 *)d_seed_off, (const unsigned long long *)d_sa, d_qbl, (const i64 *)d_ann_off, d_ann_alt, n_seqs, d_tab,
-		                   tab_stride, d_chains, d_seeds, d_srt, d_nchains);
-	if (big >= 2 && d_gen && gen_cap > 0) {
+	const dim3 grid((n_reads + 63) / 64), block(64);
+#define CHAIN_ARGS P, n_reads, d_len, d_nseeds, d_lrep, (const i64 *)d_seed_off, (const unsigned long long *)d_sa, d_qbl, (const i64 *)d_ann_off, d_ann_alt, n_seqs, d_tab, \
+	               tab_stride, d_chains, d_seeds, d_srt, d_nchains
+	static const int big = getenv("MPIBWA_CHAIN_BIG") ? atoi(getenv("MPIBWA_CHAIN_BIG")) : 2;   // 0: up to 64 seeds only, 1: + 255 seeds, 2: + the B-tree kernel
+	const int *noflt = d_tab + 5 * tab_stride;
+	hipLaunchKernelGGL((chain_kernel<CK_MAXSEEDS_SMALL, CK_MAXCH_SMALL, -1>), grid, block, lds_s, st, CHAIN_ARGS, (const int *)nullptr, (const unsigned int *)nullptr);
+	if (!d_gen || gen_cap <= 0) {   // no scratch for the lists: the retries look at every read
+		hipLaunchKernelGGL((chain_kernel<CK_MAXSEEDS, CK_MAXCH, 0>), grid, block, lds, st, CHAIN_ARGS, (const int *)nullptr, (const unsigned int *)nullptr);
+		if (big >= 1) hipLaunchKernelGGL((chain_kernel<CK_MAXSEEDS_BIG, CK_MAXCH, CK_MAXSEEDS>), grid, block, lds_big, st, CHAIN_ARGS, (const int *)nullptr, (const unsigned int *)nullptr);
+	} else {
 		uint8_t *scratch = (uint8_t *)d_gen;
-		int *list = (int *)(scratch + (size_t)gen_cap * CK_GEN_BYTES);
-		unsigned int *count = (unsigned int *)(list + gen_cap);
-		HIP_OK(hipMemsetAsync(count, 0, 4, st));
-		hipLaunchKernelGGL(chain_pick_kernel, dim3((n_reads + 255) / 256), dim3(256), 0, st, n_reads, d_len, d_nseeds, (const int *)d_nchains,
-		                   d_tab + 5 * tab_stride, gen_cap, list, count);
-		hipLaunchKernelGGL(chain_general_kernel, dim3((gen_cap + 63) / 64), dim3(64), 0, st, P, (const int *)list, (const unsigned int *)count, gen_cap, d_len,
-		                   d_nseeds, d_lrep, (const i64 *)d_seed_off, (const unsigned long long *)d_sa, d_qbl, (const i64 *)d_ann_off, d_ann_alt, n_seqs,
-		                   d_tab, scratch, d_chains, d_seeds, d_srt, d_nchains);
+		int *list_g = (int *)(scratch + (size_t)gen_cap * CK_GEN_BYTES);
+		int *list_a = list_g + gen_cap, *list_b = list_a + n_reads;
+		unsigned int *count = (unsigned int *)(list_b + n_reads);   // [0] general, [1] 64-seed retry, [2] 255-seed retry
+		HIP_OK(hipMemsetAsync(count, 0, 16, st));
+		const dim3 pgrid((n_reads + 255) / 256), pblock(256);
+		hipLaunchKernelGGL(chain_pick_kernel, pgrid, pblock, 0, st, n_reads, d_len, d_nseeds, (const int *)d_nchains, noflt, 0, CK_MAXSEEDS, n_reads, list_a, count + 1);
+		hipLaunchKernelGGL((chain_kernel<CK_MAXSEEDS, CK_MAXCH, 0>), grid, block, lds, st, CHAIN_ARGS, (const int *)list_a, (const unsigned int *)(count + 1));
+		if (big >= 1) {
+			hipLaunchKernelGGL(chain_pick_kernel, pgrid, pblock, 0, st, n_reads, d_len, d_nseeds, (const int *)d_nchains, noflt, CK_MAXSEEDS, CK_MAXSEEDS_BIG, n_reads, list_b,
+			                   count + 2);
+			hipLaunchKernelGGL((chain_kernel<CK_MAXSEEDS_BIG, CK_MAXCH, CK_MAXSEEDS>), grid, block, lds_big, st, CHAIN_ARGS, (const int *)list_b, (const unsigned int *)(count + 2));
+		}
+		if (big >= 2) {
+			hipLaunchKernelGGL(chain_pick_kernel, pgrid, pblock, 0, st, n_reads, d_len, d_nseeds, (const int *)d_nchains, noflt, 0, CK_MAXSEEDS_BIG, gen_cap, list_g, count);
+			hipLaunchKernelGGL(chain_general_kernel, dim3((gen_cap + 63) / 64), dim3(64), 0, st, P, (const int *)list_g, (const unsigned int *)count, gen_cap, d_len,
+			                   d_nseeds, d_lrep, (const i64 *)d_seed_off, (const unsigned long long *)d_sa, d_qbl, (const i64 *)d_ann_off, d_ann_alt, n_seqs,
+			                   d_tab, scratch, d_chains, d_seeds, d_srt, d_nchains);
+		}
 	}
+#undef CHAIN_ARGS
 	HIP_OK(hipGetLastError());
 }
 

@@ -125,7 +125,7 @@ void launch_chain(void *stream, const ChainParams &P, int n_reads, const int *d_
                   const int64_t *d_seed_off, const uint64_t *d_sa, const int32_t *d_qbl, const int64_t *d_ann_off, const uint8_t *d_ann_alt,
                   int n_seqs, const int *d_tab, int tab_stride, DevChain *d_chains, DevSeed *d_seeds, unsigned int *d_srt, int *d_nchains,
                   void *d_gen = nullptr, int gen_cap = 0);
-size_t chain_general_bytes(int cap);   // scratch of the third launch (reads with more than 9 chains) for `cap` reads
+size_t chain_general_bytes(int cap, int n_reads);   // scratch of launch_chain: the B-tree kernel's slices for `cap` reads + the retry lists
 
 size_t reg_pack_tmp_bytes(int n_reads);
 void launch_reg_pack(void *stream, int n_reads, const int *d_reg_beg, const int *d_nregs, int *d_reg_pos, const DevReg *d_regs, DevReg *d_packed,

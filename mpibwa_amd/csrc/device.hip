@@ -538,7 +538,7 @@ extern "C" int64_t mi355x_chain_batch(const mem_opt_t *opt, const bntseq_t *bns,
 		kp.min_seed_len = opt->min_seed_len; kp.max_chain_extend = opt->max_chain_extend; kp.mask_level = opt->mask_level; kp.drop_ratio = opt->drop_ratio;
 		void *d_gen = nullptr;
 		const int gen_cap = std::min(n_reads, 4096);
-		HIP_OK(hipMalloc(&d_gen, chain_general_bytes(gen_cap)));
+		HIP_OK(hipMalloc(&d_gen, chain_general_bytes(gen_cap, n_reads)));
 		launch_chain(0, kp, n_reads, d_len, d_ns, d_lrep, d_so, d_sa, d_qbl, d_ao, d_aa, bns->n_seqs, d_tab, TS, d_ch, d_sd, d_srt, d_nch, d_gen, gen_cap);
 		HIP_OK(hipDeviceSynchronize());
 		(void)hipFree(d_gen);
