@@ -648,7 +648,7 @@ void launch_chain(void *stream, const ChainParams &P, int n_reads, const int *d_
 	const dim3 grid((n_reads + 63) / 64), block(64);
 #define CHAIN_ARGS P, n_reads, d_len, d_nseeds, d_lrep, (const i64 *)d_seed_off, (const unsigned long long *)d_sa, d_qbl, (const i64 *)d_ann_off, d_ann_alt, n_seqs, d_tab, \
 	               tab_stride, d_chains, d_seeds, d_srt, d_nchains
-	static const int big = getenv("MPIBWA_CHAIN_BIG") ? atoi(getenv("MPIBWA_CHAIN_BIG")) : 2;   // 0: up to 64 seeds only, 1: + 255 seeds, 2: + the B-tree kernel
+	const int big = getenv("MPIBWA_CHAIN_BIG") ? atoi(getenv("MPIBWA_CHAIN_BIG")) : 2;   // 0: up to 64 seeds only, 1: + 255 seeds, 2: + the B-tree kernel
 	const int *noflt = d_tab + 5 * tab_stride;
 	hipLaunchKernelGGL((chain_kernel<CK_MAXSEEDS_SMALL, CK_MAXCH_SMALL, -1>), grid, block, lds_s, st, CHAIN_ARGS, (const int *)nullptr, (const unsigned int *)nullptr);
 	if (!d_gen || gen_cap <= 0) {   // no scratch for the lists: the retries look at every read

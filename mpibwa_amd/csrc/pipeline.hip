@@ -145,7 +145,7 @@ static void parallel_blocks(int n_threads, int n, int chunk, F f)
 }
 
 // MPIBWA_C2A_EARLY: 1 (default) the extension row loops stop early, 0 they run the reference's rows, 2 both with a fatal error on any difference
-static int c2a_early_mode() { static const int m = getenv("MPIBWA_C2A_EARLY") ? atoi(getenv("MPIBWA_C2A_EARLY")) : 1; return m; }
+static int c2a_early_mode() { const char *e = getenv("MPIBWA_C2A_EARLY"); return e ? atoi(e) : 1; }
 static std::mutex g_smem_turn, g_c2a_turn, g_pes_lock;
 
 static double now_ms()

@@ -170,9 +170,14 @@ def test_overlapped_sub_batches_and_host_cigar_paths(both, reads_pe, monkeypatch
     monkeypatch.setenv("MPIBWA_HOST_CHAIN", "1")    # chaining of every read on the host instead of chain_kernel
     assert eng.process(eng.opt(flag=abi.MEM_F_PE), ra) == want
     monkeypatch.delenv("MPIBWA_HOST_CHAIN")
-    monkeypatch.setenv("MPIBWA_CHAIN_BIG", "0")     # without the second chain_kernel launch (reads with 65..255 seeds go to the host)
+    monkeypatch.setenv("MPIBWA_CHAIN_BIG", "0")     # chain_kernel for reads up to 64 seeds / 9 chains only (the rest goes to the host)
     assert eng.process(eng.opt(flag=abi.MEM_F_PE), ra) == want
     monkeypatch.delenv("MPIBWA_CHAIN_BIG")
+    monkeypatch.setenv("MPIBWA_C2A_EARLY", "2")     # every extension also computed row by row like the reference: aborts on a difference
+    assert eng.process(eng.opt(flag=abi.MEM_F_PE), ra) == want
+    monkeypatch.setenv("MPIBWA_C2A_EARLY", "0")     # no closed form, no early stop
+    assert eng.process(eng.opt(flag=abi.MEM_F_PE), ra) == want
+    monkeypatch.delenv("MPIBWA_C2A_EARLY")
     monkeypatch.setenv("MPIBWA_HOST_MATESW", "1")   # mate rescue computed by the host's striped SW instead of msw_kernel
     assert eng.process(eng.opt(flag=abi.MEM_F_PE), ra) == want
     assert eng.stats()["n_msw"] == 0
