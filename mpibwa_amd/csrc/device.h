@@ -142,6 +142,7 @@ struct AlnHdr {                  // result header; cigar (n_cigar x u32) and MD 
 	int32_t flags;               // 1 = not done on the device (band matrix too large / caps): the host recomputes it
 };
 struct AlnParams { int64_t l_pac; int a, w; };
+size_t aln_lds_per_block(int max_len, int tcap);   // LDS of the full-size CIGAR kernel for reads of up to max_len bases
 void launch_aln(void *stream, const AlnParams &P, const ExtParams &ep, int n_req, const AlnReq *d_req, const uint8_t *d_seq,
                 const int64_t *d_off, const uint8_t *d_pac, const int *d_gaptab, AlnHdr *d_hdr, uint8_t *d_pool,
                 unsigned long long *d_counters, size_t pool_bytes, int max_len, int tcap, int *d_lists /* 3 * n_req ints of scratch */,

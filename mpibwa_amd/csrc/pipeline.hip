@@ -831,7 +831,8 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	// plugged in.  Two parts are software-pipelined so that B of one part runs while the host does A / C of the other.
 	const int n_units = pe ? n >> 1 : n;
 	std::vector<PairPlan> plans(pe ? n_units : 0);
-	const bool gpu_aln = getenv("MPIBWA_HOST_CIGAR") == nullptr;
+	// (reads so long that one request's arrays do not fit the LDS of a CU — beyond ~1 700 bp — get their CIGARs from the library's host code)
+	const bool gpu_aln = getenv("MPIBWA_HOST_CIGAR") == nullptr && aln_lds_per_block(max_len, max_len + 256) <= (size_t)160 * 1024;
 	int n_parts = (gpu_aln && n_units >= 20000 && n_sub > 1) ? 2 : 1;
 	if (const char *e = getenv("MPIBWA_SAM_PARTS")) n_parts = std::max(1, std::min(2, atoi(e)));
 	struct Part {

@@ -102,6 +102,16 @@ def test_se_variable_length(both, reads_var):
 
 
 @needs_ref
+@pytest.mark.parametrize("lens", [(700, 900), (2500, 3500), (5000, 7000)])
+def test_long_single_end_reads(both, genome, lens):
+    """Reads far beyond the lengths the kernels are sized for: long enough for mem_flt_chained_seeds to act (host chaining), for
+    the extension kernel's LDS to need the opt-in above 64 KB, and (beyond ~1 700 bp) for the CIGAR stage to go to the host."""
+    eng, ref = both
+    reads = simulate.simulate_reads(genome["seqs"], 60, 150, paired=False, seed=5, var_len=lens)
+    _cmp(eng, ref, simulate.reads_to_ascii(reads), dict(flag=0))
+
+
+@needs_ref
 def test_scoring_matrix_and_misc_inputs(both, reads_pe):
     eng, ref = both
     ra = simulate.reads_to_ascii(reads_pe[:200])
