@@ -28,6 +28,7 @@
 #include <mutex>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -103,44 +104,144 @@ static int host_threads(const mem_opt_t *opt)
 	return thr;
 }
 
+// ---- the library's helper threads ----
+// One persistent pool for all calls in flight (created on first use, as many threads as the process may use).  A parallel region
+// queues one ticket per helper it would like; a pool thread that takes a ticket runs the region's work loop until the region's
+// items are gone; the caller runs the same loop, then withdraws the tickets nobody has taken and waits for the helpers that
+// did start.  (Regions used to create and join their own threads: ~450 thread creations per call, six calls in flight — stack
+// mappings, page faults and exits that all serialise on the process's address-space lock — and up to 96 runnable threads on 16 cores.)
+// MPIBWA_THREAD_POOL=0: threads per region as before.
+class HelperPool {
+public:
+	struct Job {
+		void (*run)(void *, int);   // (region, helper number 1..)
+		void *region;
+		std::atomic<int> started{0}, finished{0};
+	};
+	static HelperPool &get() { static HelperPool *p = new HelperPool;   // never destroyed: its threads wait on it until the process ends
+		return *p; }
+	bool enabled() const { return !th_.empty(); }
+	void run(int helpers, Job &job, void (*self)(void *), void *region)
+	{
+		if (helpers > 0) {
+			{
+				std::lock_guard<std::mutex> lk(m_);
+				for (int t = 0; t < helpers; ++t) q_.push_back(&job);
+			}
+			if (helpers == 1) cv_.notify_one(); else cv_.notify_all();
+		}
+		self(region);
+		if (helpers > 0) {
+			int mine = 0;
+			{
+				std::lock_guard<std::mutex> lk(m_);
+				for (auto it = q_.begin(); it != q_.end();)
+					if (*it == &job) { it = q_.erase(it); ++mine; } else ++it;
+			}
+			const int took = helpers - mine;   // tickets a pool thread has taken (it bumps `finished` when it is done with the region)
+			for (int spin = 0; job.finished.load(std::memory_order_acquire) < took; ++spin)
+				if (spin < 200) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(20));
+		}
+	}
+private:
+	HelperPool()
+	{
+		const char *e = getenv("MPIBWA_THREAD_POOL");
+		if (e && atoi(e) == 0) return;
+		int n = usable_cpus();
+		if (n > 128) n = 128;
+		for (int t = 0; t < n; ++t) th_.emplace_back([this]() { loop(); });
+		for (auto &t : th_) t.detach();   // they live as long as the process
+	}
+	void loop()
+	{
+		for (;;) {
+			Job *j;
+			{
+				std::unique_lock<std::mutex> lk(m_);
+				cv_.wait(lk, [this]() { return !q_.empty(); });
+				j = q_.front();
+				q_.pop_front();
+			}
+			const int tid = j->started.fetch_add(1) + 1;
+			j->run(j->region, tid);
+			j->finished.fetch_add(1, std::memory_order_release);
+		}
+	}
+	std::mutex m_;
+	std::condition_variable cv_;
+	std::deque<Job *> q_;
+	std::vector<std::thread> th_;
+};
+
 template <class F>
 static void parallel_for(int n_threads, int n, int chunk, F f)
 {
 	if (n <= 0) return;
 	if (n_threads <= 1 || n <= chunk) { for (int i = 0; i < n; ++i) f(i); return; }
-	std::atomic<int> next(0);
-	auto work = [&]() {
-		for (;;) {
-			int b = next.fetch_add(chunk);
-			if (b >= n) break;
-			int e = std::min(n, b + chunk);
-			for (int i = b; i < e; ++i) f(i);
+	struct Region {
+		std::atomic<int> next{0};
+		int n, chunk;
+		F *f;
+		void work()
+		{
+			for (;;) {
+				int b = next.fetch_add(chunk);
+				if (b >= n) break;
+				int e = std::min(n, b + chunk);
+				for (int i = b; i < e; ++i) (*f)(i);
+			}
 		}
-	};
+	} R;
+	R.n = n; R.chunk = chunk; R.f = &f;
+	const int helpers = std::min(n_threads - 1, (n + chunk - 1) / chunk - 1);
+	HelperPool &P = HelperPool::get();
+	if (P.enabled()) {
+		HelperPool::Job job;
+		job.run = [](void *r, int) { ((Region *)r)->work(); };
+		job.region = &R;
+		P.run(helpers, job, [](void *r) { ((Region *)r)->work(); }, &R);
+		return;
+	}
 	std::vector<std::thread> th;
-	for (int t = 1; t < n_threads; ++t) th.emplace_back(work);
-	work();
+	for (int t = 0; t < helpers; ++t) th.emplace_back([&R]() { R.work(); });
+	R.work();
 	for (auto &t : th) t.join();
 }
 
 // same, handing whole blocks to f(thread, block, lo, hi) so that a stage can keep per-thread scratch and per-block output
+// (thread numbers are 0 .. n_threads - 1 and unique among the threads working on the region at the same time)
 template <class F>
 static void parallel_blocks(int n_threads, int n, int chunk, F f)
 {
 	if (n <= 0) return;
 	const int nb = (n + chunk - 1) / chunk;
 	if (n_threads > nb) n_threads = nb;
-	std::atomic<int> next(0);
-	auto work = [&](int tid) {
-		for (;;) {
-			int b = next.fetch_add(1);
-			if (b >= nb) break;
-			f(tid, b, b * chunk, std::min(n, (b + 1) * chunk));
+	struct Region {
+		std::atomic<int> next{0};
+		int n, nb, chunk;
+		F *f;
+		void work(int tid)
+		{
+			for (;;) {
+				int b = next.fetch_add(1);
+				if (b >= nb) break;
+				(*f)(tid, b, b * chunk, std::min(n, (b + 1) * chunk));
+			}
 		}
-	};
+	} R;
+	R.n = n; R.nb = nb; R.chunk = chunk; R.f = &f;
+	HelperPool &P = HelperPool::get();
+	if (P.enabled() && n_threads > 1) {
+		HelperPool::Job job;
+		job.run = [](void *r, int tid) { ((Region *)r)->work(tid); };
+		job.region = &R;
+		P.run(n_threads - 1, job, [](void *r) { ((Region *)r)->work(0); }, &R);
+		return;
+	}
 	std::vector<std::thread> th;
-	for (int t = 1; t < n_threads; ++t) th.emplace_back(work, t);
-	work(0);
+	for (int t = 1; t < n_threads; ++t) th.emplace_back([&R, t]() { R.work(t); });
+	R.work(0);
 	for (auto &t : th) t.join();
 }
 
