@@ -1,18 +1,15 @@
 // c2a_kernel.hip — chain -> alignment regions on the device, one wavefront per read.
 //
-// Device counterpart of mem_chain2aln (src/bwamem.c:632-786) including its
-// calls to bns_fetch_seq (the reference window is never materialised: target
-// bases are read straight from the 2-bit pac in HBM, src/bntseq.c:398-446)
-// and ksw_extend2 (wave_ext.cuh).  The seed loop of one read is sequentially
-// dependent (a seed is skipped when an earlier extension of ANY chain of the
-// read already covers it, src/bwamem.c:671-706), so one wavefront owns one
-// read: the scalar control flow is wave-uniform and every inner loop (the
-// containment tests over earlier regions, the overlap test over the other
-// seeds, seed coverage, and the DP rows) runs across the 64 lanes.
+// Device counterpart of mem_chain2aln (src/bwamem.c:632-786) including its calls to bns_fetch_seq (src/bntseq.c:398-446: the
+// chain's reference window is decoded from the 2-bit pac into LDS once per chain) and ksw_extend2 (wave_ext.cuh; not run at all
+// for a flank with at most one mismatch, see `ungapped` below).  The seed loop of one read is sequentially dependent (a seed is
+// skipped when an earlier extension of ANY chain of the read already covers it, src/bwamem.c:671-706), so one wavefront owns one
+// read: the scalar control flow is wave-uniform and every inner loop (the containment tests over earlier regions, the overlap
+// test over the other seeds, seed coverage, and the DP rows) runs across the 64 lanes.  What the wave works on — the read,
+// its chains and seeds, the regions found so far — is staged in LDS at the start (C2A_CAP_*).
 //
-// Floating-point decisions of the reference are resolved on the host into
-// integer tables indexed by length (gap[], bound5[], bound3[], ceil95[],
-// thr10[]), so the device does integer work only.
+// Floating-point decisions of the reference are resolved on the host into integer tables indexed by length (gap[], bound5[],
+// bound3[], ceil95[], thr10[]), so the device does integer work only.
 #include <hip/hip_runtime.h>
 #include "device.h"
 #include "wave_ext.cuh"

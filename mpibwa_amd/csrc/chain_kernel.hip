@@ -1,22 +1,24 @@
 // chain_kernel.hip — seeds -> chains -> filtered chains on the device, one lane per read.
 //
 // Device counterpart of mem_chain (src/bwamem.c:251-315), test_and_merge (:190-211), mem_chain_weight (:213-237) and
-// mem_chain_flt (:327-385) for the reads the reference's own data structure keeps trivial: its ordered map is a B-tree
-// whose root holds up to 9 keys (src/kbtree.h, node size 512 B), so a read that never has more than 9 chains lives in one
-// sorted array — which is what this kernel keeps, with the B-tree's rules for equal keys (a new key goes right behind the
-// FIRST equal one; a lookup that hits equal keys returns the first).  Reads with more chains, more than CK_MAXSEEDS seeds,
-// or long enough for mem_flt_chained_seeds to act (l_query >= ~700 bp) are flagged (n_chains = -1) and take the host
-// path (host_chain.cpp); on 2x150 bp data that is ~2 % of the reads.
+// mem_chain_flt (:327-385).  One body (chain_read) over two kinds of storage and two statements of the reference's ordered map:
+//  * the reads the reference's own data structure keeps trivial: its map is a B-tree whose root holds up to 9 keys
+//    (src/kbtree.h, node size 512 B), so a read that never has more than 9 chains lives in one sorted array — MapArray, with the
+//    B-tree's rules for equal keys (a new key goes right behind the FIRST equal one; a lookup that hits equal keys returns the
+//    first), state in LDS (StoreLds).  Three launches with growing LDS footprints (chain_kernel<seeds, chains, ...>);
+//  * the reads with more chains: the B-tree itself (MapBtree: kb_intervalp / kb_putp with t = 5), state in an HBM slice per read
+//    (StoreGen), up to 255 seeds and chains (chain_general_kernel).
+// Reads with more than 255 seeds, or long enough for mem_flt_chained_seeds to act (l_query >= ~700 bp), are flagged
+// (n_chains = -1) and take the host path (host_chain.cpp).
 //
-// The unstable sort of mem_chain_flt (ks_introsort, src/ksort.h:176-226) is reproduced for what n <= 9 exercises of
-// it: n == 2 is a compare-and-swap, 3 <= n <= 17 is ONE median-of-three partition pass followed by an insertion sort.
+// The unstable sort of mem_chain_flt is ks_introsort (src/ksort.h:176-226) statement by statement (ck_introsort).
 // Floating-point compares (mask_level, drop_ratio, frac_rep) are IEEE single precision in the same expression shapes as
 // the reference (no contraction, no fast-math).
 //
 // Output per read, in the slots the read's seeds already own (seed_off[r] .. seed_off[r] + n_seeds[r]): the kept chains
 // (DevChain, in mem_chain_flt's order, with the reference window of mem_chain2aln), their seeds in the order
 // mem_chain2aln visits them (ascending (score, index) — src/bwamem.c:662-667), and the identity visiting order.
-// Latency-bound integer work: ~1.5 k instructions per read, a few hundred bytes of HBM per read.
+// Latency-bound integer work: ~1.5 k instructions per ordinary read, a few hundred bytes of HBM per read.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include "device.h"
