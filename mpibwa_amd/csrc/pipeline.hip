@@ -128,7 +128,7 @@ public:
 				std::lock_guard<std::mutex> lk(m_);
 				for (int t = 0; t < helpers; ++t) q_.push_back(&job);
 			}
-			if (helpers == 1) cv_.notify_one(); else cv_.notify_all();
+			for (int t = 0; t < helpers; ++t) cv_.notify_one();   // (not notify_all: the pool may hold many more threads than this region asks for)
 		}
 		self(region);
 		if (helpers > 0) {
