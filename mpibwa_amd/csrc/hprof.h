@@ -1,7 +1,7 @@
 // hprof.h — optional host-stage profiler (MPIBWA_PROF=1): cumulative thread time per section.
 // Sections are entered millions of times per chunk from 16+ threads, so a section costs two rdtsc and two adds on a
-// thread-local record; a thread's record is folded into the global counters when the thread ends (the helper threads of
-// a parallel region) or when the report is printed (the reporting thread).
+// thread-local record; a thread's record is folded into the global counters when a pool thread leaves a parallel region
+// (pipeline.hip: HelperPool), when a thread ends, or when the report is printed (the reporting thread).
 #ifndef MBW_HPROF_H
 #define MBW_HPROF_H
 #include <atomic>

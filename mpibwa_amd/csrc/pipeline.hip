@@ -165,6 +165,7 @@ private:
 			}
 			const int tid = j->started.fetch_add(1) + 1;
 			j->run(j->region, tid);
+			if (g_hprof_on) t_hprof.flush();   // (hprof.h: a helper's record is folded in when it leaves a region)
 			j->finished.fetch_add(1, std::memory_order_release);
 		}
 	}
