@@ -105,7 +105,7 @@ static int host_threads(const mem_opt_t *opt)
 }
 
 // ---- the library's helper threads ----
-// One persistent pool for all calls in flight (created on first use, as many threads as the process may use).  A parallel region
+// One persistent pool for all calls in flight (created on first use, as many threads as the rank's share of the node's CPUs).  A parallel region
 // queues one ticket per helper it would like; a pool thread that takes a ticket runs the region's work loop until the region's
 // items are gone; the caller runs the same loop, then withdraws the tickets nobody has taken and waits for the helpers that
 // did start.  (Regions used to create and join their own threads: ~450 thread creations per call, six calls in flight — stack
@@ -148,8 +148,7 @@ private:
 	{
 		const char *e = getenv("MPIBWA_THREAD_POOL");
 		if (e && atoi(e) == 0) return;
-		int n = usable_cpus();
-		if (n > 128) n = 128;
+		const int n = host_threads(nullptr);   // this rank's share of the node's CPUs (MPIBWA_HOST_THREADS overrides)
 		for (int t = 0; t < n; ++t) th_.emplace_back([this]() { loop(); });
 		for (auto &t : th_) t.detach();   // they live as long as the process
 	}
