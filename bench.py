@@ -59,8 +59,8 @@ def main():
     ap.add_argument("--repeat-frac", type=float, default=float(os.environ.get("MPIBWA_BENCH_REPEAT_FRAC", "0.05")),
                     help="share of the synthetic genome covered by planted repeat families (real GRCh38 is ~0.5: see README)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("MPIBWA_BENCH_IN_FLIGHT", "6")),
-                    help="caller threads inside mem_process_seqs at once (the library runs up to six calls side by side: "
+    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("MPIBWA_BENCH_IN_FLIGHT", "8")),
+                    help="caller threads inside mem_process_seqs at once (the library runs up to eight calls side by side: "
                          "the GPU-bound half of one chunk overlaps the host-bound half of the previous one)")
     ap.add_argument("--workdir", default=os.environ.get("MPIBWA_BENCH_DIR", "/tmp/mpibwa_bench"))
     args = ap.parse_args()
@@ -108,7 +108,7 @@ def main():
                    for c in range(n_chunks)]
     import hashlib
     import threading
-    n_fly = max(1, min(args.in_flight, 6))
+    n_fly = max(1, min(args.in_flight, 8))
     # every caller thread owns a bseq1_t[] (and its .sam) per chunk
     batches = [[abi.SeqBatch(api.libc, chunk_reads[c]) for c in range(n_chunks)] for _ in range(n_fly)]
     cores = int(lib.mi355x_host_cpus())

@@ -146,7 +146,7 @@ typedef struct {
 /* is no CPU fallback.                                                 */
 /*                                                                     */
 /* Threads: the function may be called from several threads at once    */
-/* (same index, disjoint seqs[]).  Up to six calls run side by side    */
+/* (same index, disjoint seqs[]).  Up to eight calls run side by side  */
 /* — the first half of a call is bound by the GPU, the second by the   */
 /* host, so chunk i+1 overlaps chunk i — and further callers wait for  */
 /* a free slot (calls in flight on overlapping seqs[] abort).          */

@@ -17,7 +17,7 @@
 //   GPU    CIGAR / MD / NM              aln_kernel             (bwamem.c:1106-1122, bwa.c:121-207)
 //   host   SAM text                                            (bwamem.c:824-1010)
 //
-// Up to six calls run side by side (CallCtx below): the GPU-bound first half of one chunk overlaps the host-bound
+// Up to eight calls run side by side (CallCtx below): the GPU-bound first half of one chunk overlaps the host-bound
 // second half of another.
 //
 // There is no CPU fallback for the GPU stages: without a gfx950 device the call aborts.
@@ -334,9 +334,9 @@ struct Workspace {
 	PinBuf h_sdesc, h_names, h_noff, h_qual, h_sarena[2], h_sooff[2], h_solen[2], h_sbase[2];
 };
 static const int MAX_LANES = 4;
-// Everything one mem_process_seqs() call owns between its first and last line.  Six of them: six caller threads may be inside
+// Everything one mem_process_seqs() call owns between its first and last line.  Eight of them: eight caller threads may be inside
 // the function at once (chunk i+1 seeding and extending on the GPU while the host pairs and prints chunk i — the stage that
-// keeps the GPU busy and the stage that keeps the host busy belong to different halves of a call).  A seventh caller waits.
+// keeps the GPU busy and the stage that keeps the host busy belong to different halves of a call).  A ninth caller waits.
 struct CallCtx {
 	Workspace ws[MAX_LANES];   // one per concurrent sub-batch
 	HostBuf reg_arena[16];     // one per sub-batch: the regions live until the SAM stage
@@ -345,7 +345,7 @@ struct CallCtx {
 	bool busy = false;
 	const bseq1_t *seq_lo = nullptr, *seq_hi = nullptr;   // the caller's array while the call runs
 };
-static const int MAX_CALLS = 6;
+static const int MAX_CALLS = 8;
 static CallCtx g_ctx[MAX_CALLS];
 static std::mutex g_ctx_mu, g_init_mu;
 static std::condition_variable g_ctx_cv;

@@ -131,7 +131,7 @@ def align_files(engine, opt, r1, r2=None, out=None, K=10_000_000, copy_comment=F
     r, r + world, ... — the reference hands chunks out with a fetch-and-add counter (src/mainParallel.c:1112-1119), which
     balances better on uneven data but yields the same set of records.  With world > 1 the trimmed branch's running
     n_processed (reads this rank has already done, :2355-2357) is counted over this rank's chunks, as in the reference.
-    in_flight: caller threads inside mem_process_seqs at once (the library takes up to six: the GPU half of chunk i+1 overlaps the
+    in_flight: caller threads inside mem_process_seqs at once (the library takes up to eight: the GPU half of chunk i+1 overlaps the
     host half of chunk i); the records are written in chunk order whatever the completion order.
     out: a binary file object (the SAM body is written to it) or None (the body is returned as bytes).
     Returns (bytes or None, per-chunk read counts of this rank)."""

@@ -199,7 +199,7 @@ def test_overlapped_sub_batches_and_host_cigar_paths(both, reads_pe, monkeypatch
 
 @needs_ref
 def test_calls_in_flight_from_several_threads(both, reads_pe, monkeypatch):
-    """Several caller threads may be inside mem_process_seqs at once (six run, further ones wait): different chunks,
+    """Several caller threads may be inside mem_process_seqs at once (eight run, further ones wait): different chunks,
     different options, many rounds — every call returns the bytes the reference gives for its chunk."""
     import threading
     eng, ref = both
@@ -219,7 +219,7 @@ def test_calls_in_flight_from_several_threads(both, reads_pe, monkeypatch):
             if got != want[j] or st["n_reads"] != len(got):
                 bad.append((t, rnd, j))
 
-    th = [threading.Thread(target=caller, args=(t,)) for t in range(8)]
+    th = [threading.Thread(target=caller, args=(t,)) for t in range(10)]
     for x in th:
         x.start()
     for x in th:
