@@ -149,6 +149,30 @@ def test_map_image_round_trip_with_the_reference(built, genome, tmp_path):
     assert batch.take_sam() == want
 
 
+@needs_ref
+def test_alt_file_is_read_like_the_reference_and_travels_in_the_map_image(built, genome_alt):
+    """`.alt` next to the index (src/bntseq.c:179-204): same is_alt flags from our loader and the reference's, and the
+    flags survive bwa_idx2mem / bwa_mem2idx (src/bwa.c:310-386) in both directions."""
+    from mpibwa_amd import abi, api
+    ours, ref = api.load_library(), po.ref_lib()
+    prefix = genome_alt["prefix"].encode()
+    ref.bwa_idx2mem.argtypes = [C.POINTER(abi.bwaidx_t)]
+    ref.bwa_mem2idx.argtypes = [C.c_int64, C.c_void_p, C.POINTER(abi.bwaidx_t)]
+    want = [1 if n in genome_alt["alt"] else 0 for n in genome_alt["names"]]
+    imgs = []
+    for lib in (ours, ref):
+        idx = lib.bwa_idx_load_from_disk(prefix, 7)
+        n = int(idx.contents.bns.contents.n_seqs)
+        assert [int(idx.contents.bns.contents.anns[i].is_alt) for i in range(n)] == want
+        assert lib.bwa_idx2mem(idx) == 0
+        imgs.append(np.ctypeslib.as_array(idx.contents.mem, shape=(int(idx.contents.l_mem),)).copy())
+    for lib, img in ((ours, imgs[1]), (ref, imgs[0])):
+        back = abi.bwaidx_t()
+        img = img.copy()
+        assert lib.bwa_mem2idx(len(img), img.ctypes.data, C.byref(back)) == 0
+        assert [int(back.bns.contents.anns[i].is_alt) for i in range(len(want))] == want
+
+
 @pytest.mark.skipif(not have_ref_src, reason="the reference's driver sources only exist in the build container")
 def test_reference_driver_objects_link_against_the_product(built, tmp_path):
     """mpiBWA's own main (mainParallel.c) with parallel_aux.c, fixmate.c, tokenizer.c and the I/O helpers it keeps
