@@ -121,7 +121,7 @@ def main():
 
     step_no = [0]   # steps handed out so far (all phases): step s aligns chunk s mod n_chunks
 
-    def run_steps(k_steps, acc, fly=None):
+    def run_steps(k_steps, acc, fly=None, by_chunk=None):
         """Exactly k_steps calls of mem_process_seqs, at most `fly` (default n_fly) of them in flight."""
         fly = n_fly if fly is None else fly
         first = step_no[0]
@@ -143,6 +143,8 @@ def main():
                     pending.append((t, c, b._rec["sam"].copy()))          # hand the output over, one pointer per read
                     for k, v in st.items():
                         acc[k] = acc.get(k, 0) + v
+                    if by_chunk is not None:
+                        by_chunk[c] = st
 
         th = [threading.Thread(target=worker, args=(t,)) for t in range(1, fly)]
         for x in th:
@@ -200,6 +202,18 @@ def main():
     torch.cuda.synchronize()
     alone_s = time.perf_counter() - ta
     drain()
+    # the algorithmic bytes of the seeding kernel are a property of the reads (64 B per occ block the reference
+    # touches + read + output): counted on the device by the counting variant of the kernel, every chunk once, outside the
+    # timed region (the production variant leaves the per-extension block arithmetic out); a timed step on chunk c moved
+    # exactly those bytes
+    os.environ["MPIBWA_SMEM_COUNT"] = "1"
+    counted = {}
+    run_steps(n_chunks, {}, fly=1, by_chunk=counted)
+    os.environ["MPIBWA_SMEM_COUNT"] = "0"
+    drain()
+    first_timed = step_no[0] - 2 * n_chunks - args.steps
+    acc["smem_bytes"] = sum(counted[s_ % n_chunks]["smem_bytes"] for s_ in range(first_timed, first_timed + args.steps))
+    alone["smem_bytes"] = sum(counted[c]["smem_bytes"] for c in range(n_chunks))
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -81,7 +81,8 @@ static void alloc_index(const bwt_t *bwt, const bntseq_t *bns)
 	HIP_OK(hipMemset(g_idx.d_pac, 0, g_idx.pac_bytes));
 	FmDev &fm = g_idx.fm;
 	fm.blk = g_idx.d_blk; fm.sa = (const uint64_t *)g_idx.d_sa; fm.sa_full = nullptr;
-	fm.p3tab = nullptr; fm.p3_k = 0;
+	fm.p3tab = nullptr; fm.p3_k = 0; fm.occ64 = nullptr;
+	if (g_idx.d_occ64) { (void)hipFree(g_idx.d_occ64); g_idx.d_occ64 = nullptr; }
 	if (g_idx.d_p3tab) { (void)hipFree(g_idx.d_p3tab); g_idx.d_p3tab = nullptr; }
 	if (g_idx.d_sa_full) { (void)hipFree(g_idx.d_sa_full); g_idx.d_sa_full = nullptr; g_idx.sa_full_bytes = 0; }
 	fm.primary = bwt->primary; fm.seq_len = bwt->seq_len;
@@ -119,6 +120,18 @@ static void maybe_build_p3()
 	HIP_OK(hipGetLastError());
 	g_idx.fm.p3tab = g_idx.d_p3tab;
 	g_idx.fm.p3_k = k;
+}
+
+// The seeding kernel's own occ table (fm_kernels.hip: occ64_build_kernel), derived on the device from the bwa-format blocks.
+static void build_occ64()
+{
+	if (g_idx.d_occ64) { (void)hipFree(g_idx.d_occ64); g_idx.d_occ64 = nullptr; }
+	g_idx.occ64_bytes = occ64_bytes(g_idx.fm.seq_len);
+	HIP_OK(hipMalloc(&g_idx.d_occ64, g_idx.occ64_bytes));
+	launch_occ64_build(0, g_idx.fm, g_idx.d_occ64);
+	HIP_OK(hipDeviceSynchronize());
+	HIP_OK(hipGetLastError());
+	g_idx.fm.occ64 = g_idx.d_occ64;
 }
 
 static void maybe_expand_sa()
@@ -167,6 +180,7 @@ extern "C" int mi355x_index_upload(int local_rank, const bwt_t *bwt, const bntse
 	HIP_OK(hipMemcpy(g_idx.d_blk, bwt->bwt, (size_t)bwt->bwt_size * 4, hipMemcpyHostToDevice));
 	HIP_OK(hipMemcpy(g_idx.d_sa, bwt->sa, g_idx.sa_bytes, hipMemcpyHostToDevice));
 	HIP_OK(hipMemcpy(g_idx.d_pac, pac, (size_t)bns->l_pac / 4 + 1, hipMemcpyHostToDevice));
+	build_occ64();
 	maybe_expand_sa();
 	maybe_build_p3();
 	g_idx.ready = true;
@@ -199,6 +213,7 @@ extern "C" int mi355x_index_d2d(int which, void *ext, size_t bytes, int to_index
 extern "C" int mi355x_index_commit(void)
 {
 	if (!g_idx.d_blk) return -1;
+	build_occ64();
 	maybe_expand_sa();
 	maybe_build_p3();
 	g_idx.ready = true;
@@ -211,6 +226,7 @@ extern "C" void mi355x_finalize(void)
 	if (g_idx.d_blk) { (void)hipFree(g_idx.d_blk); (void)hipFree(g_idx.d_sa); (void)hipFree(g_idx.d_pac); }
 	if (g_idx.d_sa_full) (void)hipFree(g_idx.d_sa_full);
 	if (g_idx.d_p3tab) (void)hipFree(g_idx.d_p3tab);
+	if (g_idx.d_occ64) (void)hipFree(g_idx.d_occ64);
 	g_idx = DevIndex();
 }
 
@@ -296,7 +312,9 @@ extern "C" int mi355x_smem_batch(const mem_opt_t *opt, int n, const uint8_t *seq
 	HIP_OK(hipMemset(d_nout, 0, (size_t)n * 4));
 	Timer tm;
 	tm.start(st);
-	launch_smem(st, g_idx.fm, smem_params(opt), n, d_seq, d_off, d_len, cap, d_out, d_nout, max_len, d_cnt, d_scr, per_quad, n_quads);
+	const char *ce = getenv("MPIBWA_SMEM_COUNT");   // "0": the production variant of passes 1-2 (no block counting; *algo_bytes = 0)
+	const bool count_blocks = !(ce && atoi(ce) == 0);
+	launch_smem(st, g_idx.fm, smem_params(opt), n, d_seq, d_off, d_len, cap, d_out, d_nout, max_len, d_cnt, d_scr, per_quad, n_quads, count_blocks);
 	double ms = tm.stop(st);
 	HIP_OK(hipGetLastError());
 	unsigned long long cnt[32];
@@ -315,7 +333,7 @@ extern "C" int mi355x_smem_batch(const mem_opt_t *opt, int n, const uint8_t *seq
 		n_intv += m;
 	}
 	if (kernel_ms) *kernel_ms = ms;
-	if (algo_bytes) *algo_bytes = cnt[1] * 64 + total + n_intv * 32;   // 64 B per occ block + read + output
+	if (algo_bytes) *algo_bytes = count_blocks ? cnt[1] * 64 + total + n_intv * 32 : 0;   // 64 B per occ block + read + output
 	return cnt[2] ? -1 : 0;
 }
 

@@ -16,8 +16,12 @@
 //    four child intervals of bwt_extend come out one per lane with no
 //    reduction, and the data exchange inside the quad is DPP quad_perm
 //    (register-to-register, no LDS).
-//  * Popcount on the packed 2-bit words instead of the reference's byte
-//    lookup table: no table traffic at all.
+//  * SMEM seeding reads a device-only occ table (round 3): 64 rows of the BWT
+//    with the sentinel in place per 64-byte block, per base a running count
+//    and a one-hot bit plane, so Occ(c, k) is one masked 64-bit popcount in
+//    lane c (the bwa-format blocks cost ~30 vector instructions per Occ for
+//    bit-plane arithmetic on 2-bit words, and a shift of k around the
+//    sentinel); the bwa-format blocks stay for the SA walk and the third pass.
 //  * Every quad runs a small state machine whose loop body contains exactly
 //    one bwt_extend, so quads that are in different phases (forward sweep,
 //    backward sweep, re-seeding) or on reads of different
@@ -59,63 +63,51 @@ __device__ __forceinline__ u64 dpp64(u64 v)
 // quad_perm selectors
 #define QP(a, b, c, d) ((a) | (b) << 2 | (c) << 4 | (d) << 6)
 
-// A quad's view of one occ block: lane j holds the running count of base j (8 B) and packed words 2j, 2j+1 (8 B);
-// the four lanes together touch exactly the 64 bytes of the block.
-struct BlkPart { u64 cnt; uint2 w; };
+// A quad's view of one block of the device-only occ table (FmDev::occ64, built at upload by occ64_build_kernel): the
+// table covers the rows of the BWT *with the sentinel in place* (row fm.primary has no base), 64 rows per 64-byte block,
+// and lane c of the quad owns bytes [16c, 16c+16) of a block: the number of c in all earlier rows (8 B) and the one-hot
+// plane of c over the block's 64 rows (8 B).  Occ(c, k) is then cnt + popcount(plane & mask(k)) in lane c: no bit-plane
+// arithmetic on 2-bit words, no cross-lane add, and no shift of k around the sentinel row (src/bwt.c:173, 193-194).
+struct OccPart { u64 cnt, plane; };
 
-__device__ __forceinline__ BlkPart load_part(const FmDev &fm, u64 k, int c)
+__device__ __forceinline__ OccPart load_part(const char *lane_base, u64 k)
 {
-	const char *base = (const char *)fm.blk + (k >> 7) * 64;
-	BlkPart p;
-	p.cnt = *(const u64 *)(base + 8 * c);
-	p.w = *(const uint2 *)(base + 32 + 8 * c);
+	const ulonglong2 v = *(const ulonglong2 *)(lane_base + (k & ~63ull));
+	OccPart p;
+	p.cnt = v.x; p.plane = v.y;
 	return p;
 }
-
-// Occ(c, k) for the lane's own base c; k is already shifted for the '$' row.  Every lane counts all four bases in
-// its two words (bit planes + popcount), the per-base partial counts travel packed in one dword (<= 128 per byte),
-// two DPP adds give every lane the block totals, and lane c keeps byte c.
-__device__ __forceinline__ u64 quad_occ(BlkPart p, u64 k, int c)
+// number of the lane's base in rows 0..k (k = row of the BWT with sentinel)
+__device__ __forceinline__ u64 lane_occ(OccPart p, u64 k)
 {
-	const int kk = (int)(k & 127) + 1 - 32 * c;   // symbols of this lane's two words that are counted
-	u32 a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-#pragma unroll
-	for (int t = 0; t < 2; ++t) {
-		int m = kk - 16 * t;
-		m = m < 0 ? 0 : (m > 16 ? 16 : m);
-		const u32 msk = (u32)(0xFFFFFFFF00000000ull >> (2 * m)) & 0x55555555u;
-		const u32 w = t ? p.w.y : p.w.x;
-		const u32 lo = w & msk, hi = (w >> 1) & msk, nlo = lo ^ msk, nhi = hi ^ msk;
-		a0 += __popc(nhi & nlo); a1 += __popc(nhi & lo); a2 += __popc(hi & nlo); a3 += __popc(hi & lo);
-	}
-	u32 pk = a0 | a1 << 8 | a2 << 16 | a3 << 24;
-	pk += dpp<QP(1, 0, 3, 2)>(pk);
-	pk += dpp<QP(2, 3, 0, 1)>(pk);
-	return p.cnt + ((pk >> (8 * c)) & 0xffu);
+	const u64 m = ~0ull >> (~(u32)k & 63);
+	return p.cnt + (u32)__popcll(p.plane & m);
 }
 
-// bwt_extend for one quad: lane c receives child interval c.
-// Returns the number of distinct occ blocks touched (1 or 2).
-__device__ __forceinline__ int quad_extend(const FmDev &fm, u64 x0, u64 x1, u64 x2, bool back, int c,
-                                           u64 &o0, u64 &o1, u64 &o2)
+// bwt_extend for one quad: lane c receives child interval c as (searched side, mirrored side, size).
+// p = the side searched in the BWT (x[0] going backward, x[1] going forward; always >= 1), q = the other side.
+// COUNT: also return the number of distinct 128-symbol occ blocks the REFERENCE touches for this extension (1 or 2,
+// src/bwt.c:193-194) — the algorithmic-work counter of SURVEY §8d; 0 otherwise.
+template <bool COUNT>
+__device__ __forceinline__ int quad_extend(const FmDev &fm, const char *lane_base, u64 l2c1, u64 p, u64 q, u64 x2, int c,
+                                           u64 &oa, u64 &omir, u64 &os)
 {
-	u64 p = back ? x0 : x1;                  // the side searched in the BWT (always >= 1)
-	u64 k = p - 1, l = k + x2;
-	u64 ka = k - (k >= fm.primary), la = l - (l >= fm.primary);
-	BlkPart vk = load_part(fm, ka, c), vl = load_part(fm, la, c);
-	u64 tk = quad_occ(vk, ka, c), tl = quad_occ(vl, la, c);
-	u64 a = fm.L2[c] + 1 + tk, s = tl - tk;
+	const u64 k = p - 1, l = k + x2;
+	const OccPart vk = load_part(lane_base, k), vl = load_part(lane_base, l);
+	const u64 tk = lane_occ(vk, k), tl = lane_occ(vl, l);
+	const u64 s = tl - tk;
 	// mirrored side: children are laid out T,G,C,A behind the (possible) sentinel
-	u64 base = (back ? x1 : x0) + ((p <= fm.primary && p + x2 - 1 >= fm.primary) ? 1 : 0);
+	const u64 base = q + ((p <= fm.primary && l >= fm.primary) ? 1 : 0);
 	// (DPP reads must stay outside any lane-divergent branch: a disabled source lane reads as garbage)
-	u64 n1 = dpp64<QP(1, 2, 3, 3)>(s);
-	u64 s1 = s + (c < 3 ? n1 : 0);
-	u64 n2 = dpp64<QP(2, 3, 2, 3)>(s1);
-	u64 s2 = s1 + (c < 2 ? n2 : 0);
-	u64 mir = base + (s2 - s);
-	o0 = back ? a : mir;
-	o1 = back ? mir : a;
-	o2 = s;
+	const u64 n1 = dpp64<QP(1, 2, 3, 3)>(s);
+	const u64 s1 = s + (c < 3 ? n1 : 0);
+	const u64 n2 = dpp64<QP(2, 3, 2, 3)>(s1);
+	const u64 s2 = s1 + (c < 2 ? n2 : 0);
+	oa = l2c1 + tk;
+	omir = base + (s2 - s);
+	os = s;
+	if (!COUNT) return 0;
+	const u64 ka = k - (k >= fm.primary), la = l - (l >= fm.primary);
 	return (ka >> 7) == (la >> 7) ? 1 : 2;
 }
 
@@ -130,14 +122,18 @@ struct QuadList {
 
 __device__ __forceinline__ void list_store(const QuadList &L, int e, int c, u64 x0, u64 x1, u64 x2, u64 end)
 {
-	u32 hi = (u32)(x0 >> 32) | (u32)(x1 >> 32) << 2 | (u32)(x2 >> 32) << 4 | (u32)end << 16;
-	u32 v = c == 0 ? (u32)x0 : c == 1 ? (u32)x1 : c == 2 ? (u32)x2 : hi;
-	u32 *p = (u32 *)(e < L.cap ? L.lds + e : L.spill + (e - L.cap));
-	p[c] = v;
+	const u32 hi = (u32)(x0 >> 32) | (u32)(x1 >> 32) << 2 | (u32)(x2 >> 32) << 4 | (u32)end << 16;
+	// the lane's dword by two selects on lane constants (not a chain of compares on c: the compiler turns that into branches)
+	const u32 a = (c & 1) ? (u32)x1 : (u32)x0, b = (c & 1) ? hi : (u32)x2;
+	const u32 v = (c & 2) ? b : a;
+	if (e < L.cap) ((u32 *)(L.lds + e))[c] = v;
+	else ((u32 *)(L.spill + (e - L.cap)))[c] = v;
 }
 __device__ __forceinline__ void list_load(const QuadList &L, int e, u64 &x0, u64 &x1, u64 &x2, u64 &end)
 {
-	uint4 v = e < L.cap ? L.lds[e] : L.spill[e - L.cap];
+	uint4 v;
+	if (e < L.cap) v = L.lds[e];
+	else v = L.spill[e - L.cap];
 	x0 = (u64)(v.w & 3) << 32 | v.x;
 	x1 = (u64)(v.w >> 2 & 3) << 32 | v.y;
 	x2 = (u64)(v.w >> 4 & 3) << 32 | v.z;
@@ -147,8 +143,14 @@ __device__ __forceinline__ void list_load(const QuadList &L, int e, u64 &x0, u64
 enum { ST_PICK = 0, ST_FWD = 1, ST_BWD = 2, ST_DONE = 4 };
 
 // QLDS: every read of the launch fits its quad's LDS slot, so a base is always a plain LDS byte (otherwise the
-// accessor needs a generic pointer and every base costs a flat load)
-template <bool QLDS, int LC, int QS>
+// accessor needs a generic pointer and every base costs a flat load).  COUNT: count the reference's occ blocks
+// (counters[1]) — tests and the bench's counting pass; the production launch leaves it out (13 of ~150 vector
+// instructions per extension).
+//
+// State of a quad between two extensions: (cp, cq, cs, c_end) = the bi-interval to extend next as (searched side,
+// mirrored side, size, end position) — going forward that is bwt_smem1a's `ik` with x[1] searched, going backward the
+// list entry with x[0] searched — so the extension needs no select between two register sets.
+template <bool QLDS, int LC, int QS, bool COUNT>
 __global__ void __launch_bounds__(SMEM_BLOCK)
 smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ seq, const int64_t *__restrict__ off,
             const int *__restrict__ lens, int cap, u64 *__restrict__ out, int *__restrict__ nout_arr, u64 *counters, uint4 *scratch,
@@ -165,16 +167,18 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 	L.spill = scratch + quad_gid * scratch_ent_per_quad;
 	uint4 *myread = lds_read + quad_in_blk * (QS / 16);
 	const uint8_t *lq = (const uint8_t *)myread;
+	const char *lane_base = (const char *)fm.occ64 + 16 * c;   // the lane's 16 bytes of block 0
+	const u64 l2c1 = fm.L2[c] + 1;
 
 	int st = ST_PICK, pass = 0;
 	int rd = 0, len = 0, x = 0, i = 0, j = 0, np = 0, nc = 0, top = 0, min_intv = 1, ret = 0, last_start = -1;
-	int nout = 0, k2 = 0, old_n = 0, cb = -1, last_push_end = 0, p3_first = 0;
+	int nout = 0, k2 = 0, old_n = 0, last_push_end = 0, p3_first = 0;
+	int csel = 0;                 // the child the sweep follows: 3 - base going forward, the base going backward; < 0: no base (backward only)
 	const uint8_t *gq = seq;
 	bool q_lds = false;
 	// read base i: from the quad's LDS copy when the read fits, else from HBM
 	auto Q = [&](int i_) -> int { return (QLDS || q_lds) ? lq[i_] : gq[i_]; };
-	u64 ik0 = 0, ik1 = 0, ik2 = 0, ik_end = 0, lastc_x2 = 0;
-	u64 p0 = 0, p1 = 0, p2 = 0, p_end = 0;   // backward: the list entry being extended
+	u64 cp = 0, cq = 0, cs = 0, c_end = 0, lastc_x2 = 0;
 	u64 *myout = out;
 	u32 nblk = 0;                 // occ blocks of all the reads of the quad: added to the launch's counter once, at the end
 	int w_next = 0, w_end = 0;    // the wave's stock of reads (wave-uniform)
@@ -184,15 +188,15 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 	auto begin_smem = [&](int xs, int mi) {
 		x = xs; min_intv = mi < 1 ? 1 : mi;
 		int b = Q(xs);
-		ik0 = fm.L2[b] + 1; ik2 = fm.L2[b + 1] - fm.L2[b]; ik1 = fm.L2[3 - b] + 1; ik_end = xs + 1;
+		cq = fm.L2[b] + 1; cs = fm.L2[b + 1] - fm.L2[b]; cp = fm.L2[3 - b] + 1; c_end = xs + 1;
 		i = xs + 1; top = 0; st = ST_FWD;
 	};
 	auto push_fwd = [&]() {
-		list_store(L, top, c, ik0, ik1, ik2, ik_end);
-		last_push_end = (int)ik_end;
+		list_store(L, top, c, cq, cp, cs, c_end);
+		last_push_end = (int)c_end;
 		++top;
 	};
-	auto set_cb = [&]() { cb = (i < 0 || Q(i) > 3) ? -1 : (int)Q(i); };
+	auto set_cb = [&]() { csel = (i < 0 || Q(i) > 3) ? -1 : (int)Q(i); };
 	auto fwd_done = [&]() {   // the list holds `top` entries, longest match last pushed
 		ret = last_push_end; np = top; i = x - 1; j = 0; nc = 0; last_start = -1; st = ST_BWD;
 		set_cb();
@@ -212,25 +216,24 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 
 	// One pass per iteration, no inner re-dispatch: [backward bookkeeping] -> [pick the next call / read] ->
 	// [forward bookkeeping] -> one bwt_extend for every quad that has a request -> [consume its result].
-	bool need = false, back = false;
-	u64 o0 = 0, o1 = 0, o2 = 0;
-	int qi = 0;    // base at position i (forward / LAST-like sweeps)
+	bool need = false;
+	u64 oa = 0, omir = 0, os = 0;
 	for (;;) {
 		need = false;
 		// ---- backward sweep: end of a row, end of the call, or the next list entry ----
 		if (st == ST_BWD) {
-			if (cb >= 0 && j == np) {
+			if (csel >= 0 && j == np) {
 				if (nc == 0) call_done();
 				else { np = nc; --i; j = 0; nc = 0; set_cb(); }
 			}
 			if (st == ST_BWD) {
-				if (cb < 0) {   // start of the read or an ambiguous base: only the longest live match can be maximal
-					list_load(L, top - 1, p0, p1, p2, p_end);
-					if (last_start < 0 || i + 1 < last_start) emit(p0, p1, p2, i + 1, (int)p_end);
+				if (csel < 0) {   // start of the read or an ambiguous base: only the longest live match can be maximal
+					list_load(L, top - 1, cp, cq, cs, c_end);
+					if (last_start < 0 || i + 1 < last_start) emit(cp, cq, cs, i + 1, (int)c_end);
 					call_done();
 				} else {
-					list_load(L, top - 1 - j, p0, p1, p2, p_end);
-					need = true; back = true;
+					list_load(L, top - 1 - j, cp, cq, cs, c_end);
+					need = true;
 				}
 			}
 		}
@@ -300,38 +303,83 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 		}
 		// ---- forward sweeps ----
 		if (st == ST_FWD) {
+			int qi = 4;
 			if (i < len) qi = Q(i);
-			if (i == len || qi > 3) { push_fwd(); fwd_done(); }   // the backward sweep starts in the next iteration
-			else { need = true; back = false; }
+			if (qi > 3) { push_fwd(); fwd_done(); }   // end of the read or an ambiguous base: the backward sweep starts in the next iteration
+			else { need = true; csel = 3 - qi; }
 		}
 		if (__ballot(st != ST_DONE) == 0) break;
-		if (need) nblk += quad_extend(fm, back ? p0 : ik0, back ? p1 : ik1, back ? p2 : ik2, back, c, o0, o1, o2);
+		if (need) nblk += quad_extend<COUNT>(fm, lane_base, l2c1, cp, cq, cs, c, oa, omir, os);
 		// ---- consume ----
 		if (need) {
-			const int csel = back ? cb : 3 - qi;
-			const u64 s0 = __shfl(o0, qlead | csel), s1 = __shfl(o1, qlead | csel), s2 = __shfl(o2, qlead | csel);
+			const int src = qlead | csel;
+			const u64 s0 = __shfl(oa, src), s1 = __shfl(omir, src), s2 = __shfl(os, src);
 			if (st == ST_FWD) {
 				bool stop = false;
-				if (s2 != ik2) {
+				if (s2 != cs) {
 					push_fwd();
 					if (s2 < (u64)min_intv) { fwd_done(); stop = true; }
 				}
-				if (!stop) { ik0 = s0; ik1 = s1; ik2 = s2; ik_end = i + 1; ++i; }
+				if (!stop) { cp = s0; cq = s1; cs = s2; c_end = i + 1; ++i; }
 			} else {   // ST_BWD
 				if (s2 < (u64)min_intv) {
 					if (nc == 0 && (last_start < 0 || i + 1 < last_start)) {
-						emit(p0, p1, p2, i + 1, (int)p_end);
+						emit(cp, cq, cs, i + 1, (int)c_end);
 						last_start = i + 1;
 					}
 				} else if (nc == 0 || s2 != lastc_x2) {
-					list_store(L, top - 1 - nc, c, s0, s1, s2, p_end);
+					list_store(L, top - 1 - nc, c, s0, s1, s2, c_end);
 					++nc; lastc_x2 = s2;
 				}
 				++j;
 			}
 		}
 	}
-	if (c == 0 && nblk) atomicAdd(&counters[1], (u64)nblk);
+	if (COUNT && c == 0 && nblk) atomicAdd(&counters[1], (u64)nblk);
+}
+
+// The device-only occ table: one thread per block of 64 rows of the BWT with the sentinel in place (row `primary` has no
+// base), from the bwa-format blocks (src/bwt.h:72-73: per 128 symbols 4 x u64 running counts + 8 x u32 packed symbols,
+// first symbol in the top bits, the sentinel left out).  Output per block: for c = 0..3 {count of c in all earlier rows,
+// one-hot plane of c over the block's rows}.
+__global__ void __launch_bounds__(256) occ64_build_kernel(const u32 *__restrict__ blk, u64 primary, u64 seq_len, u64 n_new, ulonglong2 *__restrict__ out)
+{
+	const u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (b >= n_new) return;
+	const u64 R0 = b << 6;
+	u64 cnt[4] = {0, 0, 0, 0}, plane[4] = {0, 0, 0, 0};
+	auto sym = [&](u64 jdx) -> int {   // symbol jdx of the sentinel-less BWT
+		const u32 w = blk[(jdx >> 7) * 16 + 8 + ((jdx & 127) >> 4)];
+		return (int)(w >> ((~(u32)jdx & 15) << 1)) & 3;
+	};
+	if (R0 > 0 && R0 <= seq_len + 1) {
+		const u64 k = R0 - 1, kk = k - (k >= primary);   // rows 0..k hold the symbols 0..kk (src/bwt.c:173)
+		if (!(k == 0 && primary == 0)) {
+			const u64 *cb = (const u64 *)(blk + (kk >> 7) * 16);
+			for (int t = 0; t < 4; ++t) cnt[t] = cb[t];
+			for (u64 jdx = kk & ~127ull; jdx <= kk; ++jdx) ++cnt[sym(jdx)];
+		}
+	} else if (R0 > seq_len + 1) {   // pad blocks past the last row: every base's total
+		const u64 kk = seq_len - 1;
+		const u64 *cb = (const u64 *)(blk + (kk >> 7) * 16);
+		for (int t = 0; t < 4; ++t) cnt[t] = cb[t];
+		for (u64 jdx = kk & ~127ull; jdx <= kk; ++jdx) ++cnt[sym(jdx)];
+	}
+	for (int r = 0; r < 64; ++r) {
+		const u64 R = R0 + r;
+		if (R > seq_len) break;
+		if (R == primary) continue;
+		plane[sym(R - (R > primary))] |= 1ull << r;
+	}
+	for (int t = 0; t < 4; ++t) out[b * 4 + t] = make_ulonglong2(cnt[t], plane[t]);
+}
+
+size_t occ64_bytes(uint64_t seq_len) { return ((seq_len + 1 + 63) / 64 + 2) * 64; }
+void launch_occ64_build(void *stream, const FmDev &fm, void *d_occ64)
+{
+	const u64 n_new = occ64_bytes(fm.seq_len) / 64;
+	hipLaunchKernelGGL(occ64_build_kernel, dim3((unsigned)((n_new + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const u32 *)fm.blk, fm.primary,
+	                   fm.seq_len, n_new, (ulonglong2 *)d_occ64);
 }
 
 // One quad per (k+1)-mer: the forward extensions of bwt_seed_strategy1 (src/bwt.c:358-379) with the very function the
@@ -342,15 +390,17 @@ __global__ void __launch_bounds__(256) p3_build_kernel(FmDev fm, int k, u64 n_km
 	const u64 q = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
 	const bool live = q < n_kmers;
 	const u64 kmer = live ? q : 0;
+	const char *lane_base = (const char *)fm.occ64 + 16 * c;
+	const u64 l2c1 = fm.L2[c] + 1;
 	int b = (int)(kmer >> (2 * k)) & 3;
 	u64 ik0 = fm.L2[b] + 1, ik2 = fm.L2[b + 1] - fm.L2[b], ik1 = fm.L2[3 - b] + 1;
 	u32 nblk = 0;
 	for (int t = 1; t <= k; ++t) {   // uniform trip count: DPP inside quad_extend needs all lanes of the quad
 		const int qi = (int)(kmer >> (2 * (k - t))) & 3;
-		u64 o0, o1, o2;
-		nblk += quad_extend(fm, ik0, ik1, ik2, false, c, o0, o1, o2);
+		u64 oa, omir, os;
+		nblk += quad_extend<true>(fm, lane_base, l2c1, ik1, ik0, ik2, c, oa, omir, os);
 		const int csel = 3 - qi;
-		ik0 = __shfl(o0, qlead | csel); ik1 = __shfl(o1, qlead | csel); ik2 = __shfl(o2, qlead | csel);
+		ik1 = __shfl(oa, qlead | csel); ik0 = __shfl(omir, qlead | csel); ik2 = __shfl(os, qlead | csel);
 	}
 	if (live) tab[q * 4 + c] = c == 0 ? ik0 : c == 1 ? ik1 : c == 2 ? ik2 : (u64)nblk;
 }
@@ -379,7 +429,7 @@ int smem_grid_quads(int max_len, size_t *scratch_per_quad)
 
 void launch_smem(void *stream, const FmDev &fm, const SmemParams &sp, int n_reads, const uint8_t *d_seq,
                  const int64_t *d_off, const int *d_len, int cap, uint64_t *d_out, int *d_nout, int max_len,
-                 unsigned long long *d_counters, void *d_scratch, size_t scratch_bytes_per_quad, int n_quads)
+                 unsigned long long *d_counters, void *d_scratch, size_t scratch_bytes_per_quad, int n_quads, bool count_blocks)
 {
 	// the third pass depends on the read only: its own launch, first (it writes the interval counts the kernel below appends to)
 	launch_smem_p3(stream, fm, sp, n_reads, d_seq, d_off, d_len, cap, d_out, d_nout, d_counters);
@@ -390,9 +440,15 @@ void launch_smem(void *stream, const FmDev &fm, const SmemParams &sp, int n_read
 #define SMEM_LAUNCH(...) hipLaunchKernelGGL((smem_kernel<__VA_ARGS__>), dim3(n_blocks), dim3(SMEM_BLOCK), 0, (hipStream_t)stream, fm, sp, n_reads, d_seq, \
 	                                    d_off, d_len, cap, (u64 *)d_out, d_nout, (u64 *)d_counters, (uint4 *)d_scratch,                          \
 	                                    scratch_bytes_per_quad / sizeof(uint4))
-	if (max_len <= QSLOT_S) SMEM_LAUNCH(true, LCAP_S, QSLOT_S);
-	else if (max_len <= QSLOT) SMEM_LAUNCH(true, LCAP, QSLOT);
-	else SMEM_LAUNCH(false, LCAP, QSLOT);
+	if (count_blocks) {
+		if (max_len <= QSLOT_S) SMEM_LAUNCH(true, LCAP_S, QSLOT_S, true);
+		else if (max_len <= QSLOT) SMEM_LAUNCH(true, LCAP, QSLOT, true);
+		else SMEM_LAUNCH(false, LCAP, QSLOT, true);
+	} else {
+		if (max_len <= QSLOT_S) SMEM_LAUNCH(true, LCAP_S, QSLOT_S, false);
+		else if (max_len <= QSLOT) SMEM_LAUNCH(true, LCAP, QSLOT, false);
+		else SMEM_LAUNCH(false, LCAP, QSLOT, false);
+	}
 #undef SMEM_LAUNCH
 }
 

@@ -560,6 +560,10 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		int *d_nseeds = (int *)W.nseeds.ensure((size_t)n * 4), *d_lrep = (int *)W.lrep.ensure((size_t)n * 4);
 		int *nseeds = (int *)W.h_nseeds.ensure((size_t)n * 4 + 8), *lrep = (int *)W.h_lrep.ensure((size_t)n * 4 + 8);
 		int *nintv = (int *)W.h_nintv.ensure((size_t)n * 4 + 8);
+		// MPIBWA_SMEM_COUNT=1: the seeding kernel also counts the occ blocks the reference would touch (the algorithmic bytes of
+		// SURVEY §8d; a property of the reads, so the bench counts every chunk once, outside its timed region)
+		const char *ce = getenv("MPIBWA_SMEM_COUNT");
+		const bool count_blocks = ce && atoi(ce) != 0;
 		for (;;) {
 			d_intv = (uint64_t *)W.intv.ensure((size_t)n * cap * 32);
 			d_nintv = (int *)W.nintv.ensure((size_t)n * 4);
@@ -568,7 +572,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			// after the other staggers the sub-batches so that the host stages of one fall under the kernels of the other
 			std::unique_lock<std::mutex> turn(g_smem_turn);
 			ev_smem.start(st);
-			launch_smem(st, ix.fm, smem_params(opt), n, d_seq, d_off_r, d_len_r, cap, d_intv, d_nintv, max_len, d_cnt, d_scr, per_quad, n_quads);
+			launch_smem(st, ix.fm, smem_params(opt), n, d_seq, d_off_r, d_len_r, cap, d_intv, d_nintv, max_len, d_cnt, d_scr, per_quad, n_quads, count_blocks);
 			ev_smem.stop(st);
 			// seed bookkeeping queued right behind it (src/bwamem.c:265-283): one host round trip for both
 			launch_seed_prep(st, n, cap, d_intv, d_nintv, opt->max_occ, d_nseeds, d_lrep);
@@ -583,7 +587,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			if (cnt[2] == 0) break;
 			cap *= 4;
 		}
-		ps.smem_bytes = cnt[1] * 64 + range_bases;
+		ps.smem_bytes = count_blocks ? cnt[1] * 64 + range_bases : 0;
 		ps.smem_tab_bytes = cnt[4] * 64;
 		double t2 = now_ms();
 
@@ -593,7 +597,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		uint64_t n_intv = 0;
 		for (int i = 0; i < n; ++i) { seed_off[i + 1] = seed_off[i] + nseeds[i]; n_intv += nintv[i]; }
 		const int64_t S = seed_off[n];
-		ps.smem_bytes += n_intv * 32;
+		if (count_blocks) ps.smem_bytes += n_intv * 32;
 		ps.n_intv = n_intv; ps.n_seeds = S;
 		uint64_t *sa = (uint64_t *)W.h_sa.ensure((size_t)S * 8 + 8);
 		int32_t *qbl = (int32_t *)W.h_qbl.ensure((size_t)S * 8 + 8);
