@@ -12,7 +12,8 @@ namespace mbw {
 // coalesced 64-B request.
 struct FmDev {
 	const void *blk;        // n_blk x 64 B
-	const void *occ64;      // device-only occ table of the seeding kernel (fm_kernels.hip): per 64 rows of the BWT with sentinel, 4 x {u64 count, u64 one-hot plane}
+	const void *occ32;      // device-only occ table of the seeding kernel (fm_kernels.hip): per 32 rows of the BWT with sentinel and per base 16 B {count, count of greater symbols, plane, plane of greater symbols}
+	const void *occ_sb;     // its superblock records: absolute counts before every 2^31 rows
 	const uint64_t *sa;     // sampled SA, sa[0] = -1
 	const uint64_t *sa_full; // optional: SA value of EVERY row (seq_len+1 entries), expanded in HBM at upload; null if absent
 	uint64_t primary, seq_len;
@@ -29,7 +30,7 @@ struct DevIndex {
 	bool ready = false;
 	FmDev fm{};
 	void *d_blk = nullptr; size_t blk_bytes = 0;
-	void *d_occ64 = nullptr; size_t occ64_bytes = 0;
+	void *d_occ32 = nullptr; size_t occ32_bytes = 0;
 	void *d_sa = nullptr;  size_t sa_bytes = 0;
 	void *d_pac = nullptr; size_t pac_bytes = 0;
 	void *d_sa_full = nullptr; size_t sa_full_bytes = 0; double sa_expand_ms = 0;
@@ -66,8 +67,8 @@ void launch_smem(void *stream, const FmDev &fm, const SmemParams &sp, int n_read
                  unsigned long long *d_counters /* zeroed; [1]=blocks, [2]=overflow on return */,
                  void *d_scratch, size_t scratch_bytes_per_quad, int n_quads,
                  bool count_blocks /* counters[1] += the reference's occ blocks of passes 1-2 (the third pass always counts) */);
-size_t occ64_bytes(uint64_t seq_len);
-void launch_occ64_build(void *stream, const FmDev &fm, void *d_occ64);   // from fm.blk (bwa format), after upload / broadcast
+size_t occ32_bytes(uint64_t seq_len);
+void launch_occ32_build(void *stream, FmDev &fm, void *d_buf);   // from fm.blk (bwa format), after upload / broadcast; sets fm.occ32 / fm.occ_sb
 int  smem_grid_quads(int max_len, size_t *scratch_per_quad);
 void launch_smem_p3(void *stream, const FmDev &fm, const SmemParams &sp, int n_reads, const uint8_t *d_seq, const int64_t *d_off,
                     const int *d_len, int cap, uint64_t *d_out, int *d_nout, unsigned long long *d_counters);

@@ -81,8 +81,8 @@ static void alloc_index(const bwt_t *bwt, const bntseq_t *bns)
 	HIP_OK(hipMemset(g_idx.d_pac, 0, g_idx.pac_bytes));
 	FmDev &fm = g_idx.fm;
 	fm.blk = g_idx.d_blk; fm.sa = (const uint64_t *)g_idx.d_sa; fm.sa_full = nullptr;
-	fm.p3tab = nullptr; fm.p3_k = 0; fm.occ64 = nullptr;
-	if (g_idx.d_occ64) { (void)hipFree(g_idx.d_occ64); g_idx.d_occ64 = nullptr; }
+	fm.p3tab = nullptr; fm.p3_k = 0; fm.occ32 = nullptr; fm.occ_sb = nullptr;
+	if (g_idx.d_occ32) { (void)hipFree(g_idx.d_occ32); g_idx.d_occ32 = nullptr; }
 	if (g_idx.d_p3tab) { (void)hipFree(g_idx.d_p3tab); g_idx.d_p3tab = nullptr; }
 	if (g_idx.d_sa_full) { (void)hipFree(g_idx.d_sa_full); g_idx.d_sa_full = nullptr; g_idx.sa_full_bytes = 0; }
 	fm.primary = bwt->primary; fm.seq_len = bwt->seq_len;
@@ -122,16 +122,15 @@ static void maybe_build_p3()
 	g_idx.fm.p3_k = k;
 }
 
-// The seeding kernel's own occ table (fm_kernels.hip: occ64_build_kernel), derived on the device from the bwa-format blocks.
-static void build_occ64()
+// The seeding kernel's own occ table (fm_kernels.hip: occ32_build_kernel), derived on the device from the bwa-format blocks.
+static void build_occ32()
 {
-	if (g_idx.d_occ64) { (void)hipFree(g_idx.d_occ64); g_idx.d_occ64 = nullptr; }
-	g_idx.occ64_bytes = occ64_bytes(g_idx.fm.seq_len);
-	HIP_OK(hipMalloc(&g_idx.d_occ64, g_idx.occ64_bytes));
-	launch_occ64_build(0, g_idx.fm, g_idx.d_occ64);
+	if (g_idx.d_occ32) { (void)hipFree(g_idx.d_occ32); g_idx.d_occ32 = nullptr; }
+	g_idx.occ32_bytes = occ32_bytes(g_idx.fm.seq_len);
+	HIP_OK(hipMalloc(&g_idx.d_occ32, g_idx.occ32_bytes));
+	launch_occ32_build(0, g_idx.fm, g_idx.d_occ32);
 	HIP_OK(hipDeviceSynchronize());
 	HIP_OK(hipGetLastError());
-	g_idx.fm.occ64 = g_idx.d_occ64;
 }
 
 static void maybe_expand_sa()
@@ -180,9 +179,14 @@ extern "C" int mi355x_index_upload(int local_rank, const bwt_t *bwt, const bntse
 	HIP_OK(hipMemcpy(g_idx.d_blk, bwt->bwt, (size_t)bwt->bwt_size * 4, hipMemcpyHostToDevice));
 	HIP_OK(hipMemcpy(g_idx.d_sa, bwt->sa, g_idx.sa_bytes, hipMemcpyHostToDevice));
 	HIP_OK(hipMemcpy(g_idx.d_pac, pac, (size_t)bns->l_pac / 4 + 1, hipMemcpyHostToDevice));
-	build_occ64();
+	const bool dbg = getenv("MPIBWA_DEBUG") != nullptr;
+	if (dbg) fprintf(stderr, "[upload] copied\n");
+	build_occ32();
+	if (dbg) fprintf(stderr, "[upload] occ32 built\n");
 	maybe_expand_sa();
+	if (dbg) fprintf(stderr, "[upload] SA expanded\n");
 	maybe_build_p3();
+	if (dbg) fprintf(stderr, "[upload] jump table built\n");
 	g_idx.ready = true;
 	return 0;
 }
@@ -213,7 +217,7 @@ extern "C" int mi355x_index_d2d(int which, void *ext, size_t bytes, int to_index
 extern "C" int mi355x_index_commit(void)
 {
 	if (!g_idx.d_blk) return -1;
-	build_occ64();
+	build_occ32();
 	maybe_expand_sa();
 	maybe_build_p3();
 	g_idx.ready = true;
@@ -226,7 +230,7 @@ extern "C" void mi355x_finalize(void)
 	if (g_idx.d_blk) { (void)hipFree(g_idx.d_blk); (void)hipFree(g_idx.d_sa); (void)hipFree(g_idx.d_pac); }
 	if (g_idx.d_sa_full) (void)hipFree(g_idx.d_sa_full);
 	if (g_idx.d_p3tab) (void)hipFree(g_idx.d_p3tab);
-	if (g_idx.d_occ64) (void)hipFree(g_idx.d_occ64);
+	if (g_idx.d_occ32) (void)hipFree(g_idx.d_occ32);
 	g_idx = DevIndex();
 }
 

@@ -41,11 +41,11 @@ typedef unsigned int u32;
 
 // Two LDS footprints per quad: {interval-list entries of 16 B kept in LDS, bytes for the read itself}.
 //   short reads (<= 160 bp): 20 entries + 160 B = 480 B per quad -> 30 KB per workgroup, 5 workgroups per CU (the VGPR limit)
-//   otherwise:               24 entries + 256 B = 640 B per quad -> 40 KB per workgroup, 4 workgroups per CU
+//   otherwise:               23 entries + 256 B = 624 B per quad -> 39.5 KB per workgroup (with the superblock records), 4 workgroups per CU
 // (measured on 2x150 bp: 24.9 ms -> 22.7-23.5 ms for the whole chunk; 16 entries spill too often, 32 cost a workgroup)
 #define LCAP_S 20
 #define QSLOT_S 160
-#define LCAP 24
+#define LCAP 23
 #define QSLOT 256
 #define SMEM_BLOCK 256     // 4 waves = 64 quads per workgroup
 #define SMEM_FETCH 16      // reads a wave takes from the work counter at a time (>= the 16 quads of a wave)
@@ -63,71 +63,59 @@ __device__ __forceinline__ u64 dpp64(u64 v)
 // quad_perm selectors
 #define QP(a, b, c, d) ((a) | (b) << 2 | (c) << 4 | (d) << 6)
 
-// A quad's view of one block of the device-only occ table (FmDev::occ64, built at upload by occ64_build_kernel): the
-// table covers the rows of the BWT *with the sentinel in place* (row fm.primary has no base), 64 rows per 64-byte block,
-// and lane c of the quad owns bytes [16c, 16c+16) of a block: the number of c in all earlier rows (8 B) and the one-hot
-// plane of c over the block's 64 rows (8 B).  Occ(c, k) is then cnt + popcount(plane & mask(k)) in lane c: no bit-plane
-// arithmetic on 2-bit words, no cross-lane add, and no shift of k around the sentinel row (src/bwt.c:173, 193-194).
-struct OccPart { u64 cnt, plane; };
+// ---------------------------------------------------------------------------------------------------------------
+// The device-only occ table of the seeding kernel (FmDev::occ32, built at upload by occ32_build_kernel).
+//
+// bwt_extend (src/bwt.c:262-275) computes four child intervals, but a sweep of bwt_smem1a only ever follows ONE of
+// them, base c: it needs  Occ(c, k), Occ(c, l)  for the searched side and the size, and for the mirrored side the
+// number of symbols GREATER than c in rows (k, l]  (the children lie T,G,C,A behind the sentinel: src/bwt.c:270-273).
+// So the table stores, per block of 32 rows of the BWT *with the sentinel in place* (row fm.primary has no base: no
+// shift of k around it, src/bwt.c:173, 193-194) and per base c, one 16-byte record
+//        { count of c before the block, count of symbols > c before the block, plane of c, plane of symbols > c }
+// with the counts relative to the block's superblock of 2^31 rows (absolute superblock counts: FmDev::occ_sb, 32 records
+// staged in LDS with L2[c] + 1 folded in).  One extension = two 16-byte loads and four masked popcounts IN ONE LANE:
+// no cross-lane traffic, and the four lanes of a quad can extend four different list entries of a backward row.
+// 64 B per 32 rows = 12.4 GB for GRCh38 (of 288 GB); the bwa-format blocks stay for the SA walk and the third pass.
+// ---------------------------------------------------------------------------------------------------------------
+#define SB_SHIFT 31
+#define SB_MAX 8          // 2^34 rows (the 34-bit interval bounds) / 2^31
 
-__device__ __forceinline__ OccPart load_part(const char *lane_base, u64 k)
-{
-	const ulonglong2 v = *(const ulonglong2 *)(lane_base + (k & ~63ull));
-	OccPart p;
-	p.cnt = v.x; p.plane = v.y;
-	return p;
-}
-// number of the lane's base in rows 0..k (k = row of the BWT with sentinel)
-__device__ __forceinline__ u64 lane_occ(OccPart p, u64 k)
-{
-	const u64 m = ~0ull >> (~(u32)k & 63);
-	return p.cnt + (u32)__popcll(p.plane & m);
-}
-
-// bwt_extend for one quad: lane c receives child interval c as (searched side, mirrored side, size).
-// p = the side searched in the BWT (x[0] going backward, x[1] going forward; always >= 1), q = the other side.
-// COUNT: also return the number of distinct 128-symbol occ blocks the REFERENCE touches for this extension (1 or 2,
-// src/bwt.c:193-194) — the algorithmic-work counter of SURVEY §8d; 0 otherwise.
+// One bwt_extend for child `c` only: (p, q, s) = searched side, mirrored side, size of the parent; cbase = table + 16 c,
+// sbc = &lds_sb[c] (records of superblock s at sbc[4 s]).  COUNT: returns the number of distinct 128-symbol occ blocks
+// the REFERENCE touches for this extension (1 or 2, src/bwt.c:193-194), the algorithmic-work counter of SURVEY §8d.
 template <bool COUNT>
-__device__ __forceinline__ int quad_extend(const FmDev &fm, const char *lane_base, u64 l2c1, u64 p, u64 q, u64 x2, int c,
-                                           u64 &oa, u64 &omir, u64 &os)
+__device__ __forceinline__ int lane_extend(const FmDev &fm, const char *cbase, const ulonglong2 *sbc, u64 p, u64 q, u64 s, u64 &oa, u64 &omir, u64 &os)
 {
-	const u64 k = p - 1, l = k + x2;
-	const OccPart vk = load_part(lane_base, k), vl = load_part(lane_base, l);
-	const u64 tk = lane_occ(vk, k), tl = lane_occ(vl, l);
-	const u64 s = tl - tk;
-	// mirrored side: children are laid out T,G,C,A behind the (possible) sentinel
-	const u64 base = q + ((p <= fm.primary && l >= fm.primary) ? 1 : 0);
-	// (DPP reads must stay outside any lane-divergent branch: a disabled source lane reads as garbage)
-	const u64 n1 = dpp64<QP(1, 2, 3, 3)>(s);
-	const u64 s1 = s + (c < 3 ? n1 : 0);
-	const u64 n2 = dpp64<QP(2, 3, 2, 3)>(s1);
-	const u64 s2 = s1 + (c < 2 ? n2 : 0);
-	oa = l2c1 + tk;
-	omir = base + (s2 - s);
-	os = s;
+	const u64 k = p - 1, l = k + s;
+	const uint4 vk = *(const uint4 *)(cbase + ((k & ~31ull) << 1));
+	const uint4 vl = *(const uint4 *)(cbase + ((l & ~31ull) << 1));
+	const ulonglong2 bk = sbc[(u32)(k >> SB_SHIFT) * 4], bl = sbc[(u32)(l >> SB_SHIFT) * 4];
+	const u32 mk = 0xFFFFFFFFu >> (~(u32)k & 31), ml = 0xFFFFFFFFu >> (~(u32)l & 31);
+	const u64 ck = bk.x + (u32)(__popc(vk.z & mk) + vk.x), gk = bk.y + (u32)(__popc(vk.w & mk) + vk.y);
+	const u64 cl = bl.x + (u32)(__popc(vl.z & ml) + vl.x), gl = bl.y + (u32)(__popc(vl.w & ml) + vl.y);
+	oa = ck;                                                              // L2[c] + 1 + Occ(c, k): the superblock record carries L2[c] + 1
+	os = cl - ck;
+	omir = q + ((p <= fm.primary && l >= fm.primary) ? 1 : 0) + (gl - gk);  // behind the sentinel and the children of the greater bases
 	if (!COUNT) return 0;
 	const u64 ka = k - (k >= fm.primary), la = l - (l >= fm.primary);
 	return (ka >> 7) == (la >> 7) ? 1 : 2;
 }
 
-// One interval-list entry = 16 bytes: x0,x1,x2 (34 bits each: references up to 2^34 symbols = 8.5 Gbp) and the
-// end coordinate (16 bits).  Lane c of the quad stores dword c; every lane reads the whole entry back (one
-// ds_read_b128, broadcast inside the quad).
+// One interval-list entry = 16 bytes: x0,x1,x2 (34 bits each: references up to 2^34 symbols = 8.5 Gbp) and the end
+// coordinate (16 bits); a lane reads or writes a whole entry (ds_read_b128 / ds_write_b128).
 struct QuadList {
 	uint4 *lds;      // `cap` entries of this quad
 	uint4 *spill;    // per-quad HBM scratch for entries >= cap
 	int cap;
 };
 
-__device__ __forceinline__ void list_store(const QuadList &L, int e, int c, u64 x0, u64 x1, u64 x2, u64 end)
+__device__ __forceinline__ void list_store(const QuadList &L, int e, u64 x0, u64 x1, u64 x2, u64 end)
 {
-	const u32 hi = (u32)(x0 >> 32) | (u32)(x1 >> 32) << 2 | (u32)(x2 >> 32) << 4 | (u32)end << 16;
-	// the lane's dword by two selects on lane constants (not a chain of compares on c: the compiler turns that into branches)
-	const u32 a = (c & 1) ? (u32)x1 : (u32)x0, b = (c & 1) ? hi : (u32)x2;
-	const u32 v = (c & 2) ? b : a;
-	if (e < L.cap) ((u32 *)(L.lds + e))[c] = v;
-	else ((u32 *)(L.spill + (e - L.cap)))[c] = v;
+	uint4 v;
+	v.x = (u32)x0; v.y = (u32)x1; v.z = (u32)x2;
+	v.w = (u32)(x0 >> 32) | (u32)(x1 >> 32) << 2 | (u32)(x2 >> 32) << 4 | (u32)end << 16;
+	if (e < L.cap) L.lds[e] = v;
+	else L.spill[e - L.cap] = v;
 }
 __device__ __forceinline__ void list_load(const QuadList &L, int e, u64 &x0, u64 &x1, u64 &x2, u64 &end)
 {
@@ -142,14 +130,19 @@ __device__ __forceinline__ void list_load(const QuadList &L, int e, u64 &x0, u64
 
 enum { ST_PICK = 0, ST_FWD = 1, ST_BWD = 2, ST_DONE = 4 };
 
-// QLDS: every read of the launch fits its quad's LDS slot, so a base is always a plain LDS byte (otherwise the
-// accessor needs a generic pointer and every base costs a flat load).  COUNT: count the reference's occ blocks
-// (counters[1]) — tests and the bench's counting pass; the production launch leaves it out (13 of ~150 vector
-// instructions per extension).
+// smem_kernel: passes 1 and 2 of mem_collect_intv (src/bwamem.c:114-147), one read per quad of lanes.
 //
-// State of a quad between two extensions: (cp, cq, cs, c_end) = the bi-interval to extend next as (searched side,
-// mirrored side, size, end position) — going forward that is bwt_smem1a's `ik` with x[1] searched, going backward the
-// list entry with x[0] searched — so the extension needs no select between two register sets.
+// A quad runs the state machine of its read (which call, which sweep, which row) in quad-uniform registers.  Going
+// forward (src/bwt.c:299-311) the chain of extensions is serial: the four lanes compute the same extension (their loads
+// coalesce into one request).  Going backward (src/bwt.c:315-343) the entries of a row are independent: lane t extends
+// entry j + t, four entries per iteration, and the row's bookkeeping — which entries die, which survivors are kept
+// (a survivor whose size equals the previous survivor's is dropped, :337), where the kept ones go in the compacted list —
+// is a few quad-wide bit operations on two ballots.  Dead entries are a prefix of a row (a longer match cannot occur more
+// often than its prefix), so at most the first entry of a row is reported (:330-334).
+//
+// QLDS: every read of the launch fits its quad's LDS slot, so a base is always a plain LDS byte (otherwise the accessor
+// needs a generic pointer and every base costs a flat load).  COUNT: count the reference's occ blocks (counters[1]) —
+// tests and the bench's counting pass; the production launch leaves that arithmetic out.
 template <bool QLDS, int LC, int QS, bool COUNT>
 __global__ void __launch_bounds__(SMEM_BLOCK)
 smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ seq, const int64_t *__restrict__ off,
@@ -158,7 +151,14 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 {
 	__shared__ uint4 lds_list[(SMEM_BLOCK / 4) * LC];
 	__shared__ uint4 lds_read[(SMEM_BLOCK / 4) * (QS / 16)];
-	const int lane = threadIdx.x & 63, c = lane & 3, qlead = lane & ~3;
+	__shared__ ulonglong2 lds_sb[SB_MAX * 4];
+	if (threadIdx.x < SB_MAX * 4) {
+		ulonglong2 v = ((const ulonglong2 *)fm.occ_sb)[threadIdx.x];
+		v.x += fm.L2[threadIdx.x & 3] + 1;
+		lds_sb[threadIdx.x] = v;
+	}
+	__syncthreads();
+	const int lane = threadIdx.x & 63, t = lane & 3, qlead = lane & ~3;
 	const int quad_in_blk = threadIdx.x >> 2;
 	const size_t quad_gid = (size_t)blockIdx.x * (SMEM_BLOCK / 4) + quad_in_blk;
 	QuadList L;
@@ -167,8 +167,7 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 	L.spill = scratch + quad_gid * scratch_ent_per_quad;
 	uint4 *myread = lds_read + quad_in_blk * (QS / 16);
 	const uint8_t *lq = (const uint8_t *)myread;
-	const char *lane_base = (const char *)fm.occ64 + 16 * c;   // the lane's 16 bytes of block 0
-	const u64 l2c1 = fm.L2[c] + 1;
+	const u32 below = (1u << t) - 1;      // the lower lanes of the quad, as a mask
 
 	int st = ST_PICK, pass = 0;
 	int rd = 0, len = 0, x = 0, i = 0, j = 0, np = 0, nc = 0, top = 0, min_intv = 1, ret = 0, last_start = -1;
@@ -178,9 +177,13 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 	bool q_lds = false;
 	// read base i: from the quad's LDS copy when the read fits, else from HBM
 	auto Q = [&](int i_) -> int { return (QLDS || q_lds) ? lq[i_] : gq[i_]; };
-	u64 cp = 0, cq = 0, cs = 0, c_end = 0, lastc_x2 = 0;
+	// the bi-interval to extend next as (searched side, mirrored side, size, end): going forward bwt_smem1a's `ik` with
+	// x[1] searched (the same in all four lanes), going backward the lane's list entry with x[0] searched
+	u64 cp = 1, cq = 0, cs = 0, c_end = 0;
+	u64 carry_s = 0;              // backward: size of the child of the previous entry of the row, if it survived
+	bool carry_surv = false;
 	u64 *myout = out;
-	u32 nblk = 0;                 // occ blocks of all the reads of the quad: added to the launch's counter once, at the end
+	u32 nblk = 0;                 // occ blocks of the lane's extensions: added to the launch's counter once, at the end
 	int w_next = 0, w_end = 0;    // the wave's stock of reads (wave-uniform)
 	bool overflow = false;
 
@@ -190,49 +193,60 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 		int b = Q(xs);
 		cq = fm.L2[b] + 1; cs = fm.L2[b + 1] - fm.L2[b]; cp = fm.L2[3 - b] + 1; c_end = xs + 1;
 		i = xs + 1; top = 0; st = ST_FWD;
+#ifdef SMEM_DEBUG
+		printf("begin t=%d xs=%d mi=%d pass=%d k2=%d\n", t, xs, mi, pass, k2);
+#endif
 	};
 	auto push_fwd = [&]() {
-		list_store(L, top, c, cq, cp, cs, c_end);
+		if (t == 0) list_store(L, top, cq, cp, cs, c_end);
 		last_push_end = (int)c_end;
 		++top;
 	};
 	auto set_cb = [&]() { csel = (i < 0 || Q(i) > 3) ? -1 : (int)Q(i); };
 	auto fwd_done = [&]() {   // the list holds `top` entries, longest match last pushed
-		ret = last_push_end; np = top; i = x - 1; j = 0; nc = 0; last_start = -1; st = ST_BWD;
+		ret = last_push_end; np = top; i = x - 1; j = 0; nc = 0; last_start = -1; st = ST_BWD; carry_surv = false;
 		set_cb();
+#ifdef SMEM_DEBUG
+		printf("fwd_done t=%d np=%d x=%d ret=%d\n", t, np, x, ret);
+#endif
 	};
 	auto call_done = [&]() {
 		if (pass == 1) x = ret;
 		st = ST_PICK;
 	};
-	auto emit = [&](u64 e0, u64 e1, u64 e2, int start, int end) {
+	// report entry (e0, e1, e2) as the match [start, end) (one lane writes the 32-byte record)
+	auto emit = [&](bool writer, u64 e0, u64 e1, u64 e2, int start, int end) {
 		if (end - start < sp.min_seed_len) return;
 		if (nout < cap) {
-			u64 v = c == 0 ? e0 : c == 1 ? e1 : c == 2 ? e2 : ((u64)start << 32 | (u32)end);
-			myout[(size_t)nout * 4 + c] = v;
+			if (writer) {
+				ulonglong2 *o = (ulonglong2 *)(myout + (size_t)nout * 4);
+				o[0] = make_ulonglong2(e0, e1);
+				o[1] = make_ulonglong2(e2, (u64)start << 32 | (u32)end);
+			}
 		} else overflow = true;
 		++nout;
 	};
 
 	// One pass per iteration, no inner re-dispatch: [backward bookkeeping] -> [pick the next call / read] ->
-	// [forward bookkeeping] -> one bwt_extend for every quad that has a request -> [consume its result].
-	bool need = false;
+	// [forward bookkeeping] -> one extension per lane that has a request -> [consume the results].
 	u64 oa = 0, omir = 0, os = 0;
 	for (;;) {
-		need = false;
-		// ---- backward sweep: end of a row, end of the call, or the next list entry ----
+		bool need = false, valid = false;
+		// ---- backward sweep: end of a row, end of the call, or the next four list entries ----
 		if (st == ST_BWD) {
-			if (csel >= 0 && j == np) {
+			if (csel >= 0 && j >= np) {
 				if (nc == 0) call_done();
-				else { np = nc; --i; j = 0; nc = 0; set_cb(); }
+				else { np = nc; --i; j = 0; nc = 0; carry_surv = false; set_cb(); }
 			}
 			if (st == ST_BWD) {
 				if (csel < 0) {   // start of the read or an ambiguous base: only the longest live match can be maximal
 					list_load(L, top - 1, cp, cq, cs, c_end);
-					if (last_start < 0 || i + 1 < last_start) emit(cp, cq, cs, i + 1, (int)c_end);
+					if (last_start < 0 || i + 1 < last_start) emit(t == 0, cp, cq, cs, i + 1, (int)c_end);
 					call_done();
 				} else {
-					list_load(L, top - 1 - j, cp, cq, cs, c_end);
+					valid = j + t < np;
+					cp = 1; cs = 0;                 // a lane without an entry extends a harmless dummy (rows 0..0)
+					if (valid) list_load(L, top - 1 - j - t, cp, cq, cs, c_end);
 					need = true;
 				}
 			}
@@ -243,7 +257,7 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 		int r_new = -1;
 		{
 			const bool want = st == ST_PICK && pass == 0;
-			const unsigned long long wantm = __ballot(want && c == 0);
+			const unsigned long long wantm = __ballot(want && t == 0);
 			if (wantm) {
 				const int n_want = __popcll(wantm), avail = w_end - w_next;
 				int base2 = 0;
@@ -268,7 +282,7 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 				q_lds = QLDS || len <= QS;
 				if (q_lds) {   // off[] is 16-byte aligned: the quad copies the read with 16-B loads
 					const uint4 *src = (const uint4 *)gq;
-					for (int k = c; k * 16 < len; k += 4) myread[k] = src[k];
+					for (int k = t; k * 16 < len; k += 4) myread[k] = src[k];
 				}
 				myout = out + (size_t)r * cap * 4;
 				nout = p3_first = nout_arr[r];          // the third pass (smem_p3_kernel, launched before) has written its intervals
@@ -286,6 +300,9 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 				while (k2 < old_n) {
 					u64 info = myout[(size_t)k2 * 4 + 3], xx2 = myout[(size_t)k2 * 4 + 2];
 					++k2;
+#ifdef SMEM_DEBUG
+					printf("scan t=%d k2=%d old_n=%d nout=%d info=%llx xx2=%llu p3_first=%d\n", t, k2 - 1, old_n, nout, info, xx2, p3_first);
+#endif
 					int s = (int)(info >> 32), e = (int)(u32)info;
 					if (e - s < sp.split_len || xx2 > (u64)sp.split_width) continue;
 					begin_smem((s + e) >> 1, (int)xx2 + 1);
@@ -294,7 +311,7 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 				}
 				if (!found) pass = 4;
 			} else if (pass == 4) {   // read finished
-				if (c == 0) {
+				if (t == 0) {
 					nout_arr[rd] = nout;
 					if (overflow) atomicAdd(&counters[2], 1ull);
 				}
@@ -309,106 +326,150 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 			else { need = true; csel = 3 - qi; }
 		}
 		if (__ballot(st != ST_DONE) == 0) break;
-		if (need) nblk += quad_extend<COUNT>(fm, lane_base, l2c1, cp, cq, cs, c, oa, omir, os);
-		// ---- consume ----
 		if (need) {
-			const int src = qlead | csel;
-			const u64 s0 = __shfl(oa, src), s1 = __shfl(omir, src), s2 = __shfl(os, src);
-			if (st == ST_FWD) {
+			const int cnt = lane_extend<COUNT>(fm, (const char *)fm.occ32 + 16 * csel, lds_sb + csel, cp, cq, cs, oa, omir, os);
+			if (COUNT && (st == ST_FWD ? t == 0 : valid)) nblk += cnt;
+		}
+		// ---- consume ----
+		const bool bwd = need && st == ST_BWD;   // (before the forward branch below may turn the quad around)
+		if (need) {
+			if (st == ST_FWD) {   // (the four lanes hold the same child)
 				bool stop = false;
-				if (s2 != cs) {
+				if (os != cs) {
 					push_fwd();
-					if (s2 < (u64)min_intv) { fwd_done(); stop = true; }
+					if (os < (u64)min_intv) { fwd_done(); stop = true; }
 				}
-				if (!stop) { cp = s0; cq = s1; cs = s2; c_end = i + 1; ++i; }
-			} else {   // ST_BWD
-				if (s2 < (u64)min_intv) {
-					if (nc == 0 && (last_start < 0 || i + 1 < last_start)) {
-						emit(cp, cq, cs, i + 1, (int)c_end);
-						last_start = i + 1;
-					}
-				} else if (nc == 0 || s2 != lastc_x2) {
-					list_store(L, top - 1 - nc, c, s0, s1, s2, c_end);
-					++nc; lastc_x2 = s2;
+				if (!stop) { cp = oa; cq = omir; cs = os; c_end = i + 1; ++i; }
+			}
+		}
+		// (the ballots and the DPP reads of the backward bookkeeping stay outside lane-divergent branches)
+		{
+			const bool dead = bwd && valid && os < (u64)min_intv, surv = bwd && valid && !dead;
+			const u64 prev_s = dpp64<QP(0, 0, 1, 2)>(os);                 // the child size of the entry before the lane's
+			const u32 survq = (u32)(__ballot(surv) >> qlead) & 15u;
+			const bool prev_surv = t == 0 ? carry_surv : ((survq << 1) >> t) & 1;
+			const bool keep = surv && !(prev_surv && os == (t == 0 ? carry_s : prev_s));
+			const u32 keepq = (u32)(__ballot(keep) >> qlead) & 15u;
+			const u32 deadq = (u32)(__ballot(dead) >> qlead) & 15u;
+			const u64 last_s = dpp64<QP(3, 3, 3, 3)>(os);
+			const int end0 = (int)dpp<QP(0, 0, 0, 0)>((u32)c_end);          // the end of entry j (lane 0's): what the row's report is decided on
+#ifdef SMEM_DEBUG
+			if (bwd && t == 0) printf("row i=%d j=%d np=%d nc=%d min=%d last_start=%d surv=%x dead=%x keep=%x os=%llu cs=%llu end=%d\n", i, j, np, nc, min_intv, last_start, survq, deadq, keepq, os, cs, (int)c_end);
+#endif
+			if (bwd) {
+				// the first entry of a row is reported when it dies and no longer match is alive (src/bwt.c:330-334)
+				if (j == 0 && (deadq & 1) && (last_start < 0 || i + 1 < last_start)) {
+					emit(t == 0, cp, cq, cs, i + 1, end0);           // (lane 0 holds entry 0 of the row; the other lanes only keep count)
+					last_start = i + 1;
 				}
-				++j;
+				if (keep) list_store(L, top - 1 - nc - __popc(keepq & below), oa, omir, os, c_end);
+				nc += __popc(keepq);
+				carry_surv = (survq >> 3) & 1; carry_s = last_s;
+				j += 4;
 			}
 		}
 	}
-	if (COUNT && c == 0 && nblk) atomicAdd(&counters[1], (u64)nblk);
+	if (COUNT) {
+		for (int o = 32; o; o >>= 1) nblk += __shfl_xor(nblk, o);
+		if (lane == 0 && nblk) atomicAdd(&counters[1], (u64)nblk);
+	}
 }
 
-// The device-only occ table: one thread per block of 64 rows of the BWT with the sentinel in place (row `primary` has no
-// base), from the bwa-format blocks (src/bwt.h:72-73: per 128 symbols 4 x u64 running counts + 8 x u32 packed symbols,
-// first symbol in the top bits, the sentinel left out).  Output per block: for c = 0..3 {count of c in all earlier rows,
-// one-hot plane of c over the block's rows}.
-__global__ void __launch_bounds__(256) occ64_build_kernel(const u32 *__restrict__ blk, u64 primary, u64 seq_len, u64 n_new, ulonglong2 *__restrict__ out)
+// The device-only occ table (layout above): one thread per block of 32 rows, from the bwa-format blocks (src/bwt.h:72-73:
+// per 128 symbols 4 x u64 running counts + 8 x u32 packed symbols, first symbol in the top bits, the sentinel left out).
+__device__ __forceinline__ void occ_before_row(const u32 *__restrict__ blk, u64 primary, u64 seq_len, u64 R0, u64 cnt[4])
+{
+	// number of each base in rows 0 .. R0-1 of the BWT with sentinel
+	cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0;
+	if (R0 == 0) return;
+	u64 k = R0 - 1;
+	if (k > seq_len) k = seq_len;
+	if (k == 0 && primary == 0) return;
+	const u64 kk = k - (k >= primary);                  // rows 0..k hold the symbols 0..kk (src/bwt.c:173)
+	const u64 *cb = (const u64 *)(blk + (kk >> 7) * 16);
+	for (int c = 0; c < 4; ++c) cnt[c] = cb[c];
+	for (u64 jdx = kk & ~127ull; jdx <= kk; ++jdx) {
+		const u32 w = blk[(jdx >> 7) * 16 + 8 + ((jdx & 127) >> 4)];
+		++cnt[(w >> ((~(u32)jdx & 15) << 1)) & 3];
+	}
+}
+__global__ void __launch_bounds__(256) occ32_build_kernel(const u32 *__restrict__ blk, u64 primary, u64 seq_len, u64 n_new, uint4 *__restrict__ out,
+                                                          ulonglong2 *__restrict__ sb)
 {
 	const u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-	if (b >= n_new) return;
-	const u64 R0 = b << 6;
-	u64 cnt[4] = {0, 0, 0, 0}, plane[4] = {0, 0, 0, 0};
-	auto sym = [&](u64 jdx) -> int {   // symbol jdx of the sentinel-less BWT
-		const u32 w = blk[(jdx >> 7) * 16 + 8 + ((jdx & 127) >> 4)];
-		return (int)(w >> ((~(u32)jdx & 15) << 1)) & 3;
-	};
-	if (R0 > 0 && R0 <= seq_len + 1) {
-		const u64 k = R0 - 1, kk = k - (k >= primary);   // rows 0..k hold the symbols 0..kk (src/bwt.c:173)
-		if (!(k == 0 && primary == 0)) {
-			const u64 *cb = (const u64 *)(blk + (kk >> 7) * 16);
-			for (int t = 0; t < 4; ++t) cnt[t] = cb[t];
-			for (u64 jdx = kk & ~127ull; jdx <= kk; ++jdx) ++cnt[sym(jdx)];
-		}
-	} else if (R0 > seq_len + 1) {   // pad blocks past the last row: every base's total
-		const u64 kk = seq_len - 1;
-		const u64 *cb = (const u64 *)(blk + (kk >> 7) * 16);
-		for (int t = 0; t < 4; ++t) cnt[t] = cb[t];
-		for (u64 jdx = kk & ~127ull; jdx <= kk; ++jdx) ++cnt[sym(jdx)];
+	if (b < SB_MAX) {   // the superblock records (absolute counts before row b << SB_SHIFT)
+		u64 cnt[4];
+		occ_before_row(blk, primary, seq_len, b << SB_SHIFT, cnt);
+		sb[b * 4 + 0] = make_ulonglong2(cnt[0], cnt[1] + cnt[2] + cnt[3]);
+		sb[b * 4 + 1] = make_ulonglong2(cnt[1], cnt[2] + cnt[3]);
+		sb[b * 4 + 2] = make_ulonglong2(cnt[2], cnt[3]);
+		sb[b * 4 + 3] = make_ulonglong2(cnt[3], 0);
 	}
-	for (int r = 0; r < 64; ++r) {
+	if (b >= n_new) return;
+	const u64 R0 = b << 5;
+	u64 cnt[4], base[4];
+	occ_before_row(blk, primary, seq_len, R0, cnt);
+	occ_before_row(blk, primary, seq_len, R0 >> SB_SHIFT << SB_SHIFT, base);
+	u32 plane[4] = {0, 0, 0, 0};
+	for (int r = 0; r < 32; ++r) {
 		const u64 R = R0 + r;
 		if (R > seq_len) break;
 		if (R == primary) continue;
-		plane[sym(R - (R > primary))] |= 1ull << r;
+		const u64 jdx = R - (R > primary);
+		const u32 w = blk[(jdx >> 7) * 16 + 8 + ((jdx & 127) >> 4)];
+		plane[(w >> ((~(u32)jdx & 15) << 1)) & 3] |= 1u << r;
 	}
-	for (int t = 0; t < 4; ++t) out[b * 4 + t] = make_ulonglong2(cnt[t], plane[t]);
+	u32 rel[4];
+	for (int c = 0; c < 4; ++c) rel[c] = (u32)(cnt[c] - base[c]);
+	out[b * 4 + 0] = make_uint4(rel[0], rel[1] + rel[2] + rel[3], plane[0], plane[1] | plane[2] | plane[3]);
+	out[b * 4 + 1] = make_uint4(rel[1], rel[2] + rel[3], plane[1], plane[2] | plane[3]);
+	out[b * 4 + 2] = make_uint4(rel[2], rel[3], plane[2], plane[3]);
+	out[b * 4 + 3] = make_uint4(rel[3], 0, plane[3], 0);
 }
 
-size_t occ64_bytes(uint64_t seq_len) { return ((seq_len + 1 + 63) / 64 + 2) * 64; }
-void launch_occ64_build(void *stream, const FmDev &fm, void *d_occ64)
+#define OCC_SB_BYTES (SB_MAX * 4 * 16)
+size_t occ32_bytes(uint64_t seq_len) { return OCC_SB_BYTES + ((seq_len + 1 + 31) / 32 + 2) * 64; }
+// d_buf: occ32_bytes(seq_len) bytes; the superblock records come first, the blocks behind them
+void launch_occ32_build(void *stream, FmDev &fm, void *d_buf)
 {
-	const u64 n_new = occ64_bytes(fm.seq_len) / 64;
-	hipLaunchKernelGGL(occ64_build_kernel, dim3((unsigned)((n_new + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const u32 *)fm.blk, fm.primary,
-	                   fm.seq_len, n_new, (ulonglong2 *)d_occ64);
+	const u64 n_new = (occ32_bytes(fm.seq_len) - OCC_SB_BYTES) / 64;
+	fm.occ_sb = d_buf;
+	fm.occ32 = (const char *)d_buf + OCC_SB_BYTES;
+	hipLaunchKernelGGL(occ32_build_kernel, dim3((unsigned)((n_new + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const u32 *)fm.blk, fm.primary,
+	                   fm.seq_len, n_new, (uint4 *)fm.occ32, (ulonglong2 *)d_buf);
 }
 
-// One quad per (k+1)-mer: the forward extensions of bwt_seed_strategy1 (src/bwt.c:358-379) with the very function the
+// One lane per (k+1)-mer: the forward extensions of bwt_seed_strategy1 (src/bwt.c:358-379) with the very function the
 // seeding kernel uses, so a table hit is indistinguishable from doing the steps.
 __global__ void __launch_bounds__(256) p3_build_kernel(FmDev fm, int k, u64 n_kmers, u64 *__restrict__ tab)
 {
-	const int lane = threadIdx.x & 63, c = lane & 3, qlead = lane & ~3;
-	const u64 q = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
-	const bool live = q < n_kmers;
-	const u64 kmer = live ? q : 0;
-	const char *lane_base = (const char *)fm.occ64 + 16 * c;
-	const u64 l2c1 = fm.L2[c] + 1;
+	__shared__ ulonglong2 lds_sb[SB_MAX * 4];
+	if (threadIdx.x < SB_MAX * 4) {
+		ulonglong2 v = ((const ulonglong2 *)fm.occ_sb)[threadIdx.x];
+		v.x += fm.L2[threadIdx.x & 3] + 1;
+		lds_sb[threadIdx.x] = v;
+	}
+	__syncthreads();
+	const u64 kmer = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (kmer >= n_kmers) return;
 	int b = (int)(kmer >> (2 * k)) & 3;
 	u64 ik0 = fm.L2[b] + 1, ik2 = fm.L2[b + 1] - fm.L2[b], ik1 = fm.L2[3 - b] + 1;
 	u32 nblk = 0;
-	for (int t = 1; t <= k; ++t) {   // uniform trip count: DPP inside quad_extend needs all lanes of the quad
-		const int qi = (int)(kmer >> (2 * (k - t))) & 3;
+	for (int s = 1; s <= k; ++s) {
+		const int csel = 3 - ((int)(kmer >> (2 * (k - s))) & 3);
 		u64 oa, omir, os;
-		nblk += quad_extend<true>(fm, lane_base, l2c1, ik1, ik0, ik2, c, oa, omir, os);
-		const int csel = 3 - qi;
-		ik1 = __shfl(oa, qlead | csel); ik0 = __shfl(omir, qlead | csel); ik2 = __shfl(os, qlead | csel);
+		nblk += lane_extend<true>(fm, (const char *)fm.occ32 + 16 * csel, lds_sb + csel, ik1, ik0, ik2, oa, omir, os);
+		ik1 = oa; ik0 = omir; ik2 = os;
 	}
-	if (live) tab[q * 4 + c] = c == 0 ? ik0 : c == 1 ? ik1 : c == 2 ? ik2 : (u64)nblk;
+	ulonglong2 *o = (ulonglong2 *)(tab + kmer * 4);
+	o[0] = make_ulonglong2(ik0, ik1);
+	o[1] = make_ulonglong2(ik2, (u64)nblk);
 }
 
 void launch_p3_build(void *stream, const FmDev &fm, int k, void *d_tab)
 {
 	const u64 n_kmers = 1ull << (2 * (k + 1));
-	const u64 threads = n_kmers * 4;
+	const u64 threads = n_kmers;
 	hipLaunchKernelGGL(p3_build_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fm, k, n_kmers, (u64 *)d_tab);
 }
 
