@@ -232,14 +232,14 @@ def main():
     traffic, traffic_src = None, None
     try:
         here = os.path.dirname(os.path.abspath(__file__))
-        pj = json.load(open(os.path.join(here, "profiles", "r02_pmc_smem.json")))
+        pj = json.load(open(os.path.join(here, "profiles", "r03_pmc_smem.json")))
         now = kernel_sources_sha256(here)
         if pj.get("kernel_sources_sha256") != now:
-            log("WARNING: profiles/r02_pmc_smem.json was measured on other kernel sources (%s..., now %s...): roofline.traffic = null; "
+            log("WARNING: profiles/r03_pmc_smem.json was measured on other kernel sources (%s..., now %s...): roofline.traffic = null; "
                 "re-run tools/pmc_smem.sh" % (str(pj.get("kernel_sources_sha256"))[:12], now[:12]))
         elif args.genome_mbp >= 3000 and args.read_len == 150:
             traffic = int(pj["smem_kernel"]["traffic_bytes_per_read"] * 2 * args.pairs * args.steps / n_launch)
-            traffic_src = "profiles/r02_pmc_smem.json (FETCH_SIZE pass of the same workload, per read) x reads per launch"
+            traffic_src = "profiles/r03_pmc_smem.json (FETCH_SIZE pass of the same workload, per read) x reads per launch"
     except Exception as e:
         log("WARNING: no usable PMC summary for roofline.traffic: %r" % (e,))
     tab = acc.get("smem_tab_bytes", 0)
@@ -311,6 +311,16 @@ def main():
                 out["cpu_baseline"] = {"value": round(n_ref / t_ref / 1e6, 5), "unit": "Mreads/s", "cores": cores, "kind": "reference",
                                        "sample": "the %d chunks of the run (%d reads), one reference mem_process_seqs -t %d call each (%.1f s in all)" %
                                                  (n_chunks, n_ref, cores, t_ref)}
+                # the per-core anchor: the reference at -t 1 on a bounded slice of the first chunk
+                n1 = min(len(chunk_reads[0]), int(os.environ.get("MPIBWA_BENCH_T1_PAIRS", "30000")))
+                rb1 = abi.SeqBatch(po.libc, chunk_reads[0][:n1])
+                ropt1 = ref.opt(flag=abi.MEM_F_PE, n_threads=1)
+                t0 = time.perf_counter()
+                ref.lib.mem_process_seqs(ropt1, ref.bwt, ref.bns, ref.pac, 0, rb1.n, rb1.arr, None)
+                t1 = time.perf_counter() - t0
+                rb1.take_sam()
+                out["cpu_baseline"]["one_thread"] = {"value": round(rb1.n / t1 / 1e6, 6), "unit": "Mreads/s", "cores": 1,
+                                                     "sample": "the first %d reads of chunk 0, reference mem_process_seqs -t 1 (%.1f s)" % (rb1.n, t1)}
                 out["parity_on_sample"] = bool(ok)
                 if same is not None:
                     out["all_steps_identical_to_checked_sam"] = bool(same)
@@ -322,6 +332,11 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    # a throughput figure next to SAM that differs from the reference's is not a result: fail the run
+    if out.get("parity_on_sample") is False or out.get("all_steps_identical_to_checked_sam") is False:
+        log("FAILED: SAM differs from the reference (parity_on_sample=%r, all_steps_identical_to_checked_sam=%r)" %
+            (out.get("parity_on_sample"), out.get("all_steps_identical_to_checked_sam")))
+        sys.exit(3)
 
 
 if __name__ == "__main__":
