@@ -301,6 +301,7 @@ typedef struct {
 	uint64_t n_sub;                              /* sub-batches of the chunk = launches of each phase-1 kernel */
 	uint64_t smem_tab_bytes;                     /* the part of smem_bytes (64 B per occ block) that the third pass took from its jump table instead of fetching */
 	uint64_t n_sam_dev;                          /* SAM records written by sam_kernel (the rest are formatted by the host) */
+	uint64_t n_pair_dev;                         /* pairs whose pairing decisions (mem_sam_pe) were taken on the device (pair_kernel.hip) */
 } mi355x_stats_t;
 void mi355x_last_stats(mi355x_stats_t *st);
 

@@ -87,7 +87,7 @@ class mi355x_stats_t(C.Structure):
                                           "pestat_ms", "sam_ms", "k_smem_ms", "k_sa_ms", "k_ext_ms")] + \
                [(n, C.c_uint64) for n in ("smem_bytes", "sa_bytes", "ext_cells", "n_reads", "n_intv", "n_seeds",
                                           "n_chains", "n_ext")] + \
-               [(n, C.c_double) for n in ("plan_ms", "aln_ms", "k_aln_ms")] + [("n_aln", C.c_uint64), ("phase1_ms", C.c_double), ("msw_ms", C.c_double), ("k_msw_ms", C.c_double), ("n_msw", C.c_uint64), ("emit_ms", C.c_double), ("n_sub", C.c_uint64), ("smem_tab_bytes", C.c_uint64), ("n_sam_dev", C.c_uint64)]
+               [(n, C.c_double) for n in ("plan_ms", "aln_ms", "k_aln_ms")] + [("n_aln", C.c_uint64), ("phase1_ms", C.c_double), ("msw_ms", C.c_double), ("k_msw_ms", C.c_double), ("n_msw", C.c_uint64), ("emit_ms", C.c_double), ("n_sub", C.c_uint64), ("smem_tab_bytes", C.c_uint64), ("n_sam_dev", C.c_uint64), ("n_pair_dev", C.c_uint64)]
 
 
 assert C.sizeof(mem_opt_t) == 168

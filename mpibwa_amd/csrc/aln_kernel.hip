@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(256) aln_classify_kernel(AlnParams P, int n_re
                                                            int *__restrict__ lists, unsigned long long *counters, int dp_kind)
 {
 	const int rq = blockIdx.x * 256 + threadIdx.x;
-	const bool live = rq < n_req;
+	const bool live = rq < n_req && reqs[rq < n_req ? rq : 0].read >= 0;   // (read < 0: an unused slot of the request array, pair_kernel.hip)
 	bool nodp = false;
 	if (live) nodp = aln_same_len(P, reqs[rq], max_len, tcap);
 	const unsigned long long below = (1ull << (threadIdx.x & 63)) - 1;

@@ -173,6 +173,24 @@ void launch_sam_emit(void *stream, const SamParams &P, int n_reads, const SamDes
                      const uint8_t *d_names, const int *d_name_off, const int64_t *d_ann_off, const char *d_ann_names, const int *d_ann_name_off,
                      uint8_t *d_arena, size_t arena_bytes, unsigned long long *d_arena_used, unsigned long long *d_out_off, int *d_out_len);
 
+// ---- pairing decisions of the pairs with one plain hit per end (pair_kernel.hip) ----
+struct PairParams {
+	int64_t l_pac;
+	int a, b, pen_unpaired, min_seed_len, w, o_del, e_del, o_ins, e_ins;
+	int no_rescue;            // MEM_F_NO_RESCUE or max_matesw <= 0: mem_sam_pe's rescue loop does not run
+	int low[4], high[4], failed[4];   // mem_pestat_t per orientation
+	int tab_off[4];           // start of each orientation's run in the pair-score table: entry [dist - low]
+	int ltab_n;               // entries of the per-length table
+};
+// per read of a sub-batch: its first region and its number of regions, into chunk-wide arrays
+void launch_first_reg(void *stream, int n, const int *d_reg_pos, const int *d_nregs, const DevReg *d_packed, DevReg *d_first, int *d_nfirst);
+// status[k] = 1: pair k is decided; reqs[2k .. 2k+1] and desc[2k .. 2k+1] are what the host's COLLECT pass would have listed
+// (desc.req = 0 / 1, relative to the pair's first request); status 0: the host's pair (reqs marked read = -1)
+void launch_pair_simple(void *stream, const PairParams &P, int n_pairs, const DevReg *d_first, const int *d_nfirst, const uint8_t *d_ok,
+                        const int64_t *d_ann_off, const uint8_t *d_ann_alt, const double *d_ptab, const double *d_ltab, uint8_t *d_status,
+                        AlnReq *d_reqs, SamDesc *d_desc);
+void launch_desc_overlay(void *stream, int n_pairs, const uint8_t *d_status, const SamDesc *d_from, SamDesc *d_to);
+
 // ---- mate-rescue local alignment on the device (msw_kernel.hip) ----
 struct MswReq {                  // one ksw_align2() call of mem_matesw (src/bwamem_pair.c:150-177)
 	int64_t rb, re;              // target window in the doubled coordinate, already clipped to the contig

@@ -332,6 +332,9 @@ struct Workspace {
 	// SAM text on the device (sam_kernel.hip): line descriptors, names / qualities of the chunk, contig names, output arena per part
 	DevBuf sdesc, sbase[2], squal, snames, snoff, sann_names, sann_noff, sarena[2], sused[2], sooff[2], solen[2];
 	PinBuf h_sdesc, h_names, h_noff, h_qual, h_sarena[2], h_sooff[2], h_solen[2], h_sbase[2];
+	// pairs decided on the device (pair_kernel.hip): first region / region count per read, flags, tables, requests, descriptors
+	DevBuf pr_first, pr_nfirst, pr_ok, pr_status, pr_ptab, pr_ltab, pr_req, pr_desc;
+	PinBuf h_pr_ok, h_pr_status, h_pr_tab;
 };
 static const int MAX_LANES = 4;
 // Everything one mem_process_seqs() call owns between its first and last line.  Eight of them: eight caller threads may be inside
@@ -509,6 +512,12 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	std::vector<uint64_t> pes_hist_v;
 	if (pe && !pes0 && pestat_can_count(opt)) pes_hist_v.assign(4 * ((size_t)opt->max_ins + 1), 0);
 	uint64_t *pes_hist = pes_hist_v.empty() ? nullptr : pes_hist_v.data();
+	// Pairs with one plain hit per end are decided on the device after the insert-size statistics (pair_kernel.hip): every
+	// sub-batch leaves the first region and the region count of its reads in chunk-wide arrays.
+	const bool dev_pair = pe && getenv("MPIBWA_HOST_PAIR") == nullptr && !(opt->flag & (MEM_F_NOPAIRING | MEM_F_ALL | MEM_F_REF_HDR)) &&
+	                      opt->mapQ_coef_len > 0;
+	DevReg *d_pr_first = dev_pair ? (DevReg *)W.pr_first.ensure((size_t)n * sizeof(DevReg)) : nullptr;
+	int *d_pr_nfirst = dev_pair ? (int *)W.pr_nfirst.ensure((size_t)n * 4) : nullptr;
 	struct P1 { double k_smem = 0, k_sa = 0, k_ext = 0, smem = 0, sa = 0, chain = 0, ext = 0, regs = 0; uint64_t smem_bytes = 0, smem_tab_bytes = 0, sa_bytes = 0, cells = 0, n_ext = 0, n_intv = 0, n_seeds = 0, n_chains = 0; };
 	const int n_all = n;
 	auto phase1 = [&](int lo, int hi, Workspace &W, HostBuf &reg_arena, hipStream_t st, int n_thr, P1 &ps) {
@@ -810,6 +819,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			const size_t tmp_bytes = reg_pack_tmp_bytes(n);
 			void *d_tmp = W.pack_tmp.ensure(tmp_bytes);
 			launch_reg_pack(st, n, d_reg_beg, d_nregs, d_reg_pos, d_regs, d_packed, d_tmp, tmp_bytes);
+			if (d_pr_first) launch_first_reg(st, n, d_reg_pos, d_nregs, d_packed, d_pr_first + lo, d_pr_nfirst + lo);
 			hregs = (DevReg *)W.h_regs.ensure((size_t)guess * sizeof(DevReg) + 8);
 			unsigned long long *stat_h = (unsigned long long *)W.h_c2a_stat.ensure(C2A_STAT_SLOTS * 64);
 			HIP_OK(hipMemcpyAsync(stat_h, d_c2a_stat, C2A_STAT_SLOTS * 64, hipMemcpyDeviceToHost, st));
@@ -947,6 +957,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		AlnHdrH *hdr = nullptr;           // results, in page-locked staging buffers
 		uint8_t *pool = nullptr;
 		int slot = 0;
+		size_t off2 = 0;                  // request slots of the pairs decided on the device, in front of `req`
 		unsigned long long cnt[8] = {0};
 		// mate-rescue alignments of the part: requests of unit k are mreq[mbase[k] .. mbase[k+1])
 		MswReqH *mreq = nullptr; MswResH *mres = nullptr;
@@ -1036,6 +1047,66 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		d_names = dn; d_noff = dno; d_ann_names = dcn; d_ann_noff = dcno;
 	}
 
+	// ---- pairs with one plain hit per end: decided on the device (pair_kernel.hip) ----
+	// status[k] = 1: the pair's two CIGAR requests and line descriptors exist on the device; the host neither lists rescue
+	// alignments nor plans nor formats it (it only copies the two finished records out, or takes the pair back if the device
+	// hands a record back).
+	const uint8_t *pstat = nullptr;
+	const uint8_t *d_pstat = nullptr;
+	const AlnReq *d_pr_req = nullptr;
+	const SamDesc *d_pr_desc = nullptr;
+	double pair_dev_ms = 0;
+	if (dev_pair && gpu_sam && gpu_aln) {
+		const double tp0 = now_ms();
+		PairParams pp;
+		memset(&pp, 0, sizeof pp);
+		pp.l_pac = bns->l_pac; pp.a = opt->a; pp.b = opt->b; pp.pen_unpaired = opt->pen_unpaired; pp.min_seed_len = opt->min_seed_len; pp.w = opt->w;
+		pp.o_del = opt->o_del; pp.e_del = opt->e_del; pp.o_ins = opt->o_ins; pp.e_ins = opt->e_ins;
+		pp.no_rescue = ((opt->flag & MEM_F_NO_RESCUE) || opt->max_matesw <= 0) ? 1 : 0;
+		bool usable = true;
+		size_t n_tab = 0;
+		for (int d = 0; d < 4; ++d) {
+			pp.low[d] = pes[d].low; pp.high[d] = pes[d].high; pp.failed[d] = pes[d].failed ? 1 : 0;
+			pp.tab_off[d] = (int)n_tab;
+			if (!pes[d].failed) {
+				if (pes[d].high < pes[d].low || (int64_t)pes[d].high - pes[d].low > (1 << 20)) usable = false;
+				else n_tab += (size_t)(pes[d].high - pes[d].low + 1);
+			}
+		}
+		if (usable) {
+			pp.ltab_n = 4 * max_len + 256;
+			double *tab = (double *)W.h_pr_tab.ensure((n_tab + (size_t)pp.ltab_n) * 8 + 64);
+			for (int d = 0; d < 4; ++d)
+				if (!pes[d].failed)
+					for (int64_t dist = pes[d].low; dist <= pes[d].high; ++dist) {   // src/bwamem_pair.c:218-219, the double part of q
+						const double ns = (dist - pes[d].avg) / pes[d].std;
+						tab[pp.tab_off[d] + (dist - pes[d].low)] = .721 * log(2. * erfc(fabs(ns) * M_SQRT1_2)) * opt->a;
+					}
+			double *ltab = tab + n_tab;
+			ltab[0] = 1.;
+			for (int l = 1; l < pp.ltab_n; ++l) ltab[l] = l < opt->mapQ_coef_len ? 1. : opt->mapQ_coef_fac / log(l);   // src/bwamem.c:964
+			uint8_t *ok = (uint8_t *)W.h_pr_ok.ensure((size_t)n_units + 64);
+			parallel_for(n_thr, n_units, 8192, [&](int k) {
+				ok[k] = !seqs[2 * k].comment && !seqs[2 * k + 1].comment && strcmp(seqs[2 * k].name, seqs[2 * k + 1].name) == 0;
+			});
+			double *d_tab = (double *)W.pr_ptab.ensure((n_tab + (size_t)pp.ltab_n) * 8 + 64);
+			uint8_t *d_ok = (uint8_t *)W.pr_ok.ensure((size_t)n_units + 64);
+			uint8_t *d_status = (uint8_t *)W.pr_status.ensure((size_t)n_units + 64);
+			AlnReq *d_rq = (AlnReq *)W.pr_req.ensure((size_t)n * sizeof(AlnReq));
+			SamDesc *d_ds = (SamDesc *)W.pr_desc.ensure((size_t)n * sizeof(SamDesc));
+			uint8_t *hs = (uint8_t *)W.h_pr_status.ensure((size_t)n_units + 64);
+			HIP_OK(hipMemcpyAsync(d_tab, tab, (n_tab + (size_t)pp.ltab_n) * 8, hipMemcpyHostToDevice, st));
+			HIP_OK(hipMemcpyAsync(d_ok, ok, (size_t)n_units, hipMemcpyHostToDevice, st));
+			launch_pair_simple(st, pp, n_units, d_pr_first, d_pr_nfirst, d_ok, d_ann_off, d_ann_alt, d_tab, d_tab + n_tab, d_status, d_rq, d_ds);
+			HIP_OK(hipMemcpyAsync(hs, d_status, (size_t)n_units, hipMemcpyDeviceToHost, st));
+			stream_wait(st);
+			HIP_OK(hipGetLastError());
+			pstat = hs; d_pstat = d_status; d_pr_req = d_rq; d_pr_desc = d_ds;
+		}
+		pair_dev_ms = now_ms() - tp0;
+	}
+	const size_t dev_slots = pstat ? 2 : 0;   // request slots per unit in front of the host's requests of a part
+
 	// mate rescue on the device: list the local alignments the pairs of a part will ask for, run them in one launch
 	static_assert(sizeof(MswReq) == sizeof(MswReqH) && sizeof(MswRes) == sizeof(MswResH), "host/device record layouts differ");
 	const int MSW_MAX_T = 4096;
@@ -1059,7 +1130,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			const int lo = P.lo + blk * 256, hi = std::min(P.hi, lo + 256);
 			for (int i = lo; i < hi; ++i) {
 				const size_t before = rq.size();
-				sam_pe_msw_collect(opt, bns, pes, &seqs[i << 1], &regs[i << 1], i << 1, MSW_MAX_T, rq);
+				if (!(pstat && pstat[i])) sam_pe_msw_collect(opt, bns, pes, &seqs[i << 1], &regs[i << 1], i << 1, MSW_MAX_T, rq);
 				u_first[i - P.lo] = (uint32_t)before; u_cnt[i - P.lo] = (uint32_t)(rq.size() - before);
 			}
 		});
@@ -1122,6 +1193,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			unsigned long long tsc_plan_blk = 0, tsc_emitc_blk = 0;
 			for (int i = lo; i < hi; ++i) {
 				const int k = i - P.lo;
+				if (pstat && pstat[i]) continue;   // decided on the device
 				const bool waits = P.m_launched && P.mbase[k + 1] != P.mbase[k];   // needs results of the mate-rescue kernel
 				if (waits != (round == 1)) continue;
 				const size_t before = rq.size();
@@ -1156,8 +1228,10 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		cpu_collect += cpu_sec() - ca;
 	};
 	auto launch = [&](Part &P, int slot) {   // B (asynchronous)
-		const size_t n_req = P.req.size();
-		P.slot = slot;
+		const size_t n_host_req = P.req.size();
+		const size_t off2 = dev_slots * (size_t)(P.hi - P.lo);   // the slots of the pairs decided on the device come first
+		const size_t n_req = off2 + n_host_req;
+		P.slot = slot; P.off2 = off2;
 		if (!gpu_aln || n_req == 0) return;
 		static_assert(sizeof(AlnReq) == sizeof(AlnReqH) && sizeof(AlnHdr) == sizeof(AlnHdrH), "host/device record layouts differ");
 		P.st = a_streams[slot];
@@ -1166,7 +1240,8 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		P.d_hdr = (AlnHdr *)(slot ? W.ahdr2 : W.ahdr).ensure(n_req * sizeof(AlnHdr));
 		P.d_pool = (uint8_t *)(slot ? W.apool2 : W.apool).ensure(P.pool_bytes);
 		P.d_cnt = (unsigned long long *)(slot ? W.acnt2 : W.acnt).ensure(256);
-		HIP_OK(hipMemcpyAsync(d_req, P.req.data(), n_req * sizeof(AlnReq), hipMemcpyHostToDevice, P.st));
+		if (off2) HIP_OK(hipMemcpyAsync(d_req, d_pr_req + 2 * (size_t)P.lo, off2 * sizeof(AlnReq), hipMemcpyDeviceToDevice, P.st));
+		if (n_host_req) HIP_OK(hipMemcpyAsync(d_req + off2, P.req.data(), n_host_req * sizeof(AlnReq), hipMemcpyHostToDevice, P.st));
 		HIP_OK(hipMemsetAsync(P.d_cnt, 0, 256, P.st));
 		AlnParams ap;
 		ap.l_pac = bns->l_pac; ap.a = opt->a; ap.w = opt->w;
@@ -1182,7 +1257,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			const int r0 = P.lo << 1, nr = (P.hi - P.lo) << 1, nu = P.hi - P.lo;
 			SamDesc *d_desc = (SamDesc *)W.sdesc.ensure((size_t)n * sizeof(SamDesc));
 			int *hb = (int *)W.h_sbase[slot].ensure((size_t)(nu + 1) * 4 + 64);
-			for (int k = 0; k <= nu; ++k) hb[k] = (int)P.base[k];
+			for (int k = 0; k <= nu; ++k) hb[k] = (k < nu && pstat && pstat[P.lo + k]) ? 2 * k : (int)(off2 + P.base[k]);
 			int *d_base = (int *)W.sbase[slot].ensure((size_t)(nu + 1) * 4);
 			P.arena_bytes = (size_t)nr * (size_t)(2 * max_len + 320) + (1 << 20);
 			uint8_t *d_arena = (uint8_t *)W.sarena[slot].ensure(P.arena_bytes);
@@ -1190,6 +1265,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			unsigned long long *d_ooff = (unsigned long long *)W.sooff[slot].ensure((size_t)nr * 8);
 			int *d_olen = (int *)W.solen[slot].ensure((size_t)nr * 4);
 			HIP_OK(hipMemcpyAsync(d_desc + r0, sdesc + r0, (size_t)nr * sizeof(SamDesc), hipMemcpyHostToDevice, P.st));
+			if (pstat) launch_desc_overlay(P.st, nu, d_pstat + P.lo, d_pr_desc + r0, d_desc + r0);
 			HIP_OK(hipMemcpyAsync(d_base, hb, (size_t)(nu + 1) * 4, hipMemcpyHostToDevice, P.st));
 			HIP_OK(hipMemsetAsync(d_used, 0, 64, P.st));
 			launch_sam_emit(P.st, sam_par, nr, d_desc + r0, d_base, P.d_hdr, P.d_pool, d_seq, d_off + r0, d_len + r0, d_qual, d_names, d_noff + r0,
@@ -1198,7 +1274,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		}
 	};
 	auto finish = [&](Part &P) {   // wait for B, fetch the pool
-		const size_t n_req = P.req.size();
+		const size_t n_req = P.off2 + P.req.size();
 		if (!gpu_aln || n_req == 0) return;
 		double ta = now_ms();
 		stream_wait(P.st);
@@ -1261,7 +1337,11 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 						continue;
 					}
 					AlnCtx ctx;
-					if (gpu_aln) { ctx.mode = AlnCtx::REPLAY; ctx.hdr = P.hdr; ctx.pool = P.pool; ctx.cursor = P.base[k]; }
+					if (gpu_aln) { ctx.mode = AlnCtx::REPLAY; ctx.hdr = P.hdr; ctx.pool = P.pool; ctx.cursor = P.off2 + P.base[k]; }
+					if (pstat && pstat[i]) {   // the device decided the pair but handed a record back: the host decides it again (same two requests, same order)
+						sam_pe_plan(opt, bns, pac, pes, (uint64_t)((n_processed >> 1) + i), &seqs[i << 1], &regs[i << 1], plans[i], nullptr, i << 1);
+						ctx.cursor = 2 * (size_t)k;
+					}
 					sam_pe_emit(opt, bns, pac, pes, &seqs[i << 1], &regs[i << 1], plans[i], gpu_aln ? &ctx : nullptr, i << 1);
 				}
 				n_sam_dev += n_dev; tsc_devcopy += tsc;
@@ -1296,6 +1376,8 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	}
 	STAT.plan_ms = plan_ms; STAT.aln_ms = aln_wait_ms; STAT.msw_ms = msw_ms; STAT.emit_ms = emit_ms;
 	STAT.n_sam_dev = n_sam_dev.load();
+	if (pstat) { uint64_t c = 0; for (int k = 0; k < n_units; ++k) c += pstat[k]; STAT.n_pair_dev = c; }
+	STAT.plan_ms += pair_dev_ms;
 	double t8 = now_ms();
 	hprof_report("sam stage");
 	if (s_cpusec) fprintf(stderr, "[plan Mcycles] sam_pe_plan %.0f  emit(collect) %.0f  device-record copy %.0f (%llu records)\n", tsc_plan.load() * 1e-6, tsc_emitc.load() * 1e-6, tsc_devcopy.load() * 1e-6, n_sam_dev.load());

@@ -171,6 +171,11 @@ def test_overlapped_sub_batches_and_host_cigar_paths(both, reads_pe, monkeypatch
     monkeypatch.setenv("MPIBWA_SUBBATCH", "1")
     assert eng.process(eng.opt(flag=abi.MEM_F_PE), ra) == want
     assert eng.stats()["n_sam_dev"] > len(want) // 2   # most records of this chunk were written by sam_kernel
+    assert eng.stats()["n_pair_dev"] > len(ra) // 2   # most pairs of this chunk were decided by pair_kernel (one plain hit per end)
+    monkeypatch.setenv("MPIBWA_HOST_PAIR", "1")     # every pair decided by the host's mem_sam_pe instead
+    assert eng.process(eng.opt(flag=abi.MEM_F_PE), ra) == want
+    assert eng.stats()["n_pair_dev"] == 0
+    monkeypatch.delenv("MPIBWA_HOST_PAIR")
     monkeypatch.setenv("MPIBWA_HOST_SAM", "1")      # every record formatted by the host instead
     assert eng.process(eng.opt(flag=abi.MEM_F_PE), ra) == want
     assert eng.stats()["n_sam_dev"] == 0
