@@ -174,15 +174,19 @@ void launch_sam_emit(void *stream, const SamParams &P, int n_reads, const SamDes
                      uint8_t *d_arena, size_t arena_bytes, unsigned long long *d_arena_used, unsigned long long *d_out_off, int *d_out_len);
 
 // ---- pairing decisions of the pairs with one plain hit per end (pair_kernel.hip) ----
+#define PR_MAXREG 4               // regions per read the kernel looks at (a read with more is the host's)
 struct PairParams {
 	int64_t l_pac;
-	int a, b, pen_unpaired, min_seed_len, w, o_del, e_del, o_ins, e_ins;
+	int a, b, pen_unpaired, min_seed_len, w, o_del, e_del, o_ins, e_ins, max_chain_gap, T, max_matesw;
+	float mask_level_redun, mask_level, XA_drop_ratio;
+	uint64_t id0;             // number of the chunk's first pair (n_processed >> 1): the hash tie-breaks of src/bwamem.c:527, src/bwamem_pair.c:222
+	int lnq[40];              // (int)(4.343 * log(n + 1) + .499), src/bwamem.c:972, src/bwamem_pair.c:313
 	int no_rescue;            // MEM_F_NO_RESCUE or max_matesw <= 0: mem_sam_pe's rescue loop does not run
 	int low[4], high[4], failed[4];   // mem_pestat_t per orientation
 	int tab_off[4];           // start of each orientation's run in the pair-score table: entry [dist - low]
 	int ltab_n;               // entries of the per-length table
 };
-// per read of a sub-batch: its first region and its number of regions, into chunk-wide arrays
+// per read of a sub-batch: its first PR_MAXREG regions and its number of regions, into chunk-wide arrays (d_first: PR_MAXREG records per read)
 void launch_first_reg(void *stream, int n, const int *d_reg_pos, const int *d_nregs, const DevReg *d_packed, DevReg *d_first, int *d_nfirst);
 // status[k] = 1: pair k is decided; reqs[2k .. 2k+1] and desc[2k .. 2k+1] are what the host's COLLECT pass would have listed
 // (desc.req = 0 / 1, relative to the pair's first request); status 0: the host's pair (reqs marked read = -1)

@@ -90,6 +90,7 @@ extern "C" int mi355x_init(int local_rank, const bwaidx_t *idx, const mi355x_com
 		HIP_OK(hipMemcpy(d[2], idx->pac, (size_t)idx->bns->l_pac / 4 + 1, hipMemcpyHostToDevice));
 	} else if (mi355x_index_alloc(local_rank, idx->bwt, idx->bns) != 0) return -1;
 
+	(void)hipGetLastError();   // RCCL checks the thread's last HIP error after its own calls: start from a clean slate
 	Rccl &R = rccl();
 	RcclId id;
 	memset(&id, 0, sizeof id);

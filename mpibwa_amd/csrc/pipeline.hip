@@ -283,6 +283,7 @@ static void stream_wait(hipStream_t st)
 			hipError_t e = hipStreamQuery(st);
 			if (e == hipSuccess) break;
 			if (e != hipErrorNotReady) HIP_OK(e);
+			(void)hipGetLastError();   // "not ready" is this thread's last error otherwise: the next library that checks it (RCCL) takes it for a failure
 			usleep(60);
 		}
 	}
@@ -514,9 +515,9 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	uint64_t *pes_hist = pes_hist_v.empty() ? nullptr : pes_hist_v.data();
 	// Pairs with one plain hit per end are decided on the device after the insert-size statistics (pair_kernel.hip): every
 	// sub-batch leaves the first region and the region count of its reads in chunk-wide arrays.
-	const bool dev_pair = pe && getenv("MPIBWA_HOST_PAIR") == nullptr && !(opt->flag & (MEM_F_NOPAIRING | MEM_F_ALL | MEM_F_REF_HDR)) &&
+	const bool dev_pair = pe && getenv("MPIBWA_HOST_PAIR") == nullptr && !(opt->flag & (MEM_F_NOPAIRING | MEM_F_ALL | MEM_F_REF_HDR | MEM_F_PRIMARY5)) &&
 	                      opt->mapQ_coef_len > 0;
-	DevReg *d_pr_first = dev_pair ? (DevReg *)W.pr_first.ensure((size_t)n * sizeof(DevReg)) : nullptr;
+	DevReg *d_pr_first = dev_pair ? (DevReg *)W.pr_first.ensure((size_t)n * PR_MAXREG * sizeof(DevReg)) : nullptr;
 	int *d_pr_nfirst = dev_pair ? (int *)W.pr_nfirst.ensure((size_t)n * 4) : nullptr;
 	struct P1 { double k_smem = 0, k_sa = 0, k_ext = 0, smem = 0, sa = 0, chain = 0, ext = 0, regs = 0; uint64_t smem_bytes = 0, smem_tab_bytes = 0, sa_bytes = 0, cells = 0, n_ext = 0, n_intv = 0, n_seeds = 0, n_chains = 0; };
 	const int n_all = n;
@@ -819,7 +820,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			const size_t tmp_bytes = reg_pack_tmp_bytes(n);
 			void *d_tmp = W.pack_tmp.ensure(tmp_bytes);
 			launch_reg_pack(st, n, d_reg_beg, d_nregs, d_reg_pos, d_regs, d_packed, d_tmp, tmp_bytes);
-			if (d_pr_first) launch_first_reg(st, n, d_reg_pos, d_nregs, d_packed, d_pr_first + lo, d_pr_nfirst + lo);
+			if (d_pr_first) launch_first_reg(st, n, d_reg_pos, d_nregs, d_packed, d_pr_first + (size_t)lo * PR_MAXREG, d_pr_nfirst + lo);
 			hregs = (DevReg *)W.h_regs.ensure((size_t)guess * sizeof(DevReg) + 8);
 			unsigned long long *stat_h = (unsigned long long *)W.h_c2a_stat.ensure(C2A_STAT_SLOTS * 64);
 			HIP_OK(hipMemcpyAsync(stat_h, d_c2a_stat, C2A_STAT_SLOTS * 64, hipMemcpyDeviceToHost, st));
@@ -1062,6 +1063,9 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		memset(&pp, 0, sizeof pp);
 		pp.l_pac = bns->l_pac; pp.a = opt->a; pp.b = opt->b; pp.pen_unpaired = opt->pen_unpaired; pp.min_seed_len = opt->min_seed_len; pp.w = opt->w;
 		pp.o_del = opt->o_del; pp.e_del = opt->e_del; pp.o_ins = opt->o_ins; pp.e_ins = opt->e_ins;
+		pp.max_chain_gap = opt->max_chain_gap; pp.mask_level_redun = opt->mask_level_redun; pp.mask_level = opt->mask_level;
+		pp.XA_drop_ratio = opt->XA_drop_ratio; pp.T = opt->T; pp.max_matesw = opt->max_matesw; pp.id0 = (uint64_t)(n_processed >> 1);
+		for (int v = 0; v < 40; ++v) pp.lnq[v] = (int)(4.343 * log(v + 1) + .499);
 		pp.no_rescue = ((opt->flag & MEM_F_NO_RESCUE) || opt->max_matesw <= 0) ? 1 : 0;
 		bool usable = true;
 		size_t n_tab = 0;
@@ -1130,7 +1134,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			const int lo = P.lo + blk * 256, hi = std::min(P.hi, lo + 256);
 			for (int i = lo; i < hi; ++i) {
 				const size_t before = rq.size();
-				if (!(pstat && pstat[i])) sam_pe_msw_collect(opt, bns, pes, &seqs[i << 1], &regs[i << 1], i << 1, MSW_MAX_T, rq);
+				if (!(pstat && pstat[i] == 1)) sam_pe_msw_collect(opt, bns, pes, &seqs[i << 1], &regs[i << 1], i << 1, MSW_MAX_T, rq);
 				u_first[i - P.lo] = (uint32_t)before; u_cnt[i - P.lo] = (uint32_t)(rq.size() - before);
 			}
 		});
@@ -1193,7 +1197,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			unsigned long long tsc_plan_blk = 0, tsc_emitc_blk = 0;
 			for (int i = lo; i < hi; ++i) {
 				const int k = i - P.lo;
-				if (pstat && pstat[i]) continue;   // decided on the device
+				if (pstat && pstat[i] == 1) continue;   // decided on the device
 				const bool waits = P.m_launched && P.mbase[k + 1] != P.mbase[k];   // needs results of the mate-rescue kernel
 				if (waits != (round == 1)) continue;
 				const size_t before = rq.size();
@@ -1257,7 +1261,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			const int r0 = P.lo << 1, nr = (P.hi - P.lo) << 1, nu = P.hi - P.lo;
 			SamDesc *d_desc = (SamDesc *)W.sdesc.ensure((size_t)n * sizeof(SamDesc));
 			int *hb = (int *)W.h_sbase[slot].ensure((size_t)(nu + 1) * 4 + 64);
-			for (int k = 0; k <= nu; ++k) hb[k] = (k < nu && pstat && pstat[P.lo + k]) ? 2 * k : (int)(off2 + P.base[k]);
+			for (int k = 0; k <= nu; ++k) hb[k] = (k < nu && pstat && pstat[P.lo + k] == 1) ? 2 * k : (int)(off2 + P.base[k]);
 			int *d_base = (int *)W.sbase[slot].ensure((size_t)(nu + 1) * 4);
 			P.arena_bytes = (size_t)nr * (size_t)(2 * max_len + 320) + (1 << 20);
 			uint8_t *d_arena = (uint8_t *)W.sarena[slot].ensure(P.arena_bytes);
@@ -1338,7 +1342,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 					}
 					AlnCtx ctx;
 					if (gpu_aln) { ctx.mode = AlnCtx::REPLAY; ctx.hdr = P.hdr; ctx.pool = P.pool; ctx.cursor = P.off2 + P.base[k]; }
-					if (pstat && pstat[i]) {   // the device decided the pair but handed a record back: the host decides it again (same two requests, same order)
+					if (pstat && pstat[i] == 1) {   // the device decided the pair but handed a record back: the host decides it again (same two requests, same order)
 						sam_pe_plan(opt, bns, pac, pes, (uint64_t)((n_processed >> 1) + i), &seqs[i << 1], &regs[i << 1], plans[i], nullptr, i << 1);
 						ctx.cursor = 2 * (size_t)k;
 					}
@@ -1376,7 +1380,14 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	}
 	STAT.plan_ms = plan_ms; STAT.aln_ms = aln_wait_ms; STAT.msw_ms = msw_ms; STAT.emit_ms = emit_ms;
 	STAT.n_sam_dev = n_sam_dev.load();
-	if (pstat) { uint64_t c = 0; for (int k = 0; k < n_units; ++k) c += pstat[k]; STAT.n_pair_dev = c; }
+	if (pstat) {
+		uint64_t c[16] = {0};
+		for (int k = 0; k < n_units; ++k) ++c[pstat[k] & 15];
+		STAT.n_pair_dev = c[1];
+		if (s_cpusec) fprintf(stderr, "[pair_kernel] %d pairs: decided %llu; host: no/unnamed hit %llu, > %d hits %llu, patch %llu, ALT/length %llu, rescue %llu, no proper pair %llu, score %llu, second primary hit %llu, XA %llu\n",
+		                      n_units, (unsigned long long)c[1], (unsigned long long)c[2], PR_MAXREG, (unsigned long long)c[3], (unsigned long long)c[4], (unsigned long long)c[6],
+		                      (unsigned long long)c[7], (unsigned long long)c[8], (unsigned long long)c[9], (unsigned long long)c[10], (unsigned long long)c[11]);
+	}
 	STAT.plan_ms += pair_dev_ms;
 	double t8 = now_ms();
 	hprof_report("sam stage");
