@@ -41,20 +41,28 @@ def test_index_attached_from_map_image(gold):
 
 def test_mi355x_init_broadcasts_through_rccl(gold):
     """A communicator of one rank still takes the RCCL path: ncclGetUniqueId -> the caller's bootstrap broadcast ->
-    ncclCommInitRank -> ncclBroadcast of the three index arrays in place -> commit."""
-    from mpibwa_amd import api
-    lib = api.load_library()
-    lib.mi355x_finalize()
-    seen = []
-
-    def bcast(buf, nbytes, root, user):
-        seen.append((int(nbytes), int(root)))
-    cb = api.mi355x_comm_t.BCAST(bcast)
-    comm = api.mi355x_comm_t(0, 1, cb, None)
-    eng = api.Engine(gold, device=0, comm=comm)
-    assert seen == [(128, 0)]
-    assert eng.bcast_seconds is not None and eng.bcast_seconds > 0
-    assert _golden_ok(eng)
+    ncclCommInitRank -> ncclBroadcast of the three index arrays in place -> commit.  In a process of its own, like a rank of
+    mpibwa_gpu: the test runner's process may carry a second HIP runtime (an imported torch brings its own librccl and
+    libamdhip64), and a communicator created by that pair cannot take this library's device buffers."""
+    code = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from mpibwa_amd import api
+from golden_util import load_reads, load_sam, sam_cases
+seen = []
+def bcast(buf, nbytes, root, user):
+    seen.append((int(nbytes), int(root)))
+cb = api.mi355x_comm_t.BCAST(bcast)
+comm = api.mi355x_comm_t(0, 1, cb, None)
+eng = api.Engine(%r, device=0, comm=comm)
+assert seen == [(128, 0)], seen
+assert eng.bcast_seconds is not None and eng.bcast_seconds > 0
+kw = sam_cases()["pe_default"]
+assert b"".join(eng.process(eng.opt(**kw), load_reads("reads_pe150.tsv.gz"))) == load_sam("pe_default")
+print("RCCL_PATH_OK")
+""" % (ROOT, os.path.join(ROOT, "tests"), gold)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_PATH_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
 def test_a_call_with_another_index_than_the_resident_one_aborts(gold, genome):
