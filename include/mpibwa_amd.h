@@ -316,6 +316,8 @@ int   mi355x_host_cpus(void);
  * every seqs[i].sam into one malloc()ed buffer (returned, NUL-terminated, *total_len bytes) and free()s
  * the per-read strings. */
 char *mi355x_collect_sam(bseq1_t *seqs, int n, size_t *total_len);
+/* the same into a buffer the caller keeps from chunk to chunk (*buf / *cap: replaced when a chunk needs more); returns the length */
+size_t mi355x_collect_sam_into(bseq1_t *seqs, int n, char **buf, size_t *cap);
 
 #ifdef __cplusplus
 }

@@ -399,6 +399,32 @@ extern "C" int mi355x_host_cpus(void) { return usable_cpus(); }
 
 // Caller-side helper mirroring mpiBWA's copy_buffer_thr (src/mainParallel.c:103-127): concatenate all
 // seqs[i].sam into one malloc'ed buffer and free the per-read strings.
+// the same into a buffer the caller keeps from chunk to chunk (*buf, *cap: grown with realloc when a chunk needs more)
+extern "C" size_t mi355x_collect_sam_into(bseq1_t *seqs, int n, char **buf, size_t *cap)
+{
+	std::vector<size_t> off(n + 1);
+	const int n_thr = std::min(usable_cpus(), 32);
+	parallel_for(n_thr, n, 8192, [&](int i) { off[i + 1] = seqs[i].sam ? strlen(seqs[i].sam) : 0; });
+	off[0] = 0;
+	for (int i = 0; i < n; ++i) off[i + 1] += off[i];
+	const size_t tot = off[n];
+	if (tot + 1 > *cap) {
+		free(*buf);
+		*cap = tot + tot / 8 + 4096;
+		*buf = (char *)malloc(*cap);
+		if (!*buf) die("out of memory collecting SAM");
+	}
+	char *b = *buf;
+	parallel_for(n_thr, n, 8192, [&](int i) {
+		if (!seqs[i].sam) return;
+		memcpy(b + off[i], seqs[i].sam, off[i + 1] - off[i]);
+		free(seqs[i].sam);
+		seqs[i].sam = 0;
+	});
+	b[tot] = 0;
+	return tot;
+}
+
 extern "C" char *mi355x_collect_sam(bseq1_t *seqs, int n, size_t *total_len)
 {
 	std::vector<size_t> off(n + 1);

@@ -1,6 +1,6 @@
 /* mpibwa_gpu.c — a thin MPI host program around the C ABI of libmpibwa_amd.so: one rank per GPU,
  *
- *     mpiexec -n N mpibwa_gpu mem [-t threads] [-K bases] [-C] [--dry-run] -o OUT PREFIX R1.fastq [R2.fastq]
+ *     mpiexec -n N mpibwa_gpu mem [-t threads] [-K bases] [-P chunks in flight] [-C] [--dry-run] -o OUT PREFIX R1.fastq [R2.fastq]
  *
  * It does, with this repo's own code, what mpiBWA's main does around mem_process_seqs():
  *   - every rank takes a byte slice of each FASTQ file, finds the first record boundary in it and scans its records
@@ -17,7 +17,14 @@
  * The index reaches the GPUs through mi355x_init(): the ranks of a node that have a GPU each get it by RCCL broadcast
  * from the node's first rank; where ranks outnumber GPUs (tests on a one-GPU box) every rank uploads its own copy.
  *
- * Plain C99 + MPI; built by mpibwa_amd/build.py when an MPI installation is found (mpibwa_amd/mpibwa_gpu).
+ * Reading, aligning and writing overlap (the reference's docs/TODO:4, "overlaping reading, aligning and writing"): the
+ * chunk loop runs on -P worker threads per rank (default 6), each of them fetching the next chunk number, reading its bytes
+ * with MPI-IO, building the bseq1_t array, calling mem_process_seqs() — the library runs up to eight calls side by side,
+ * the GPU half of one chunk under the host half of another — and appending the SAM text through the shared file pointer.
+ * With MPI_THREAD_MULTIPLE the workers call MPI concurrently; with MPI_THREAD_SERIALIZED a mutex takes turns; below that
+ * one worker runs (the reference's blocking loop, src/mainParallel.c:1112-1391).
+ *
+ * Plain C99 + MPI + pthreads; built by mpibwa_amd/build.py when an MPI installation is found (mpibwa_amd/mpibwa_gpu).
  */
 #define _GNU_SOURCE
 #include <mpi.h>
@@ -25,6 +32,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdint.h>
+#include <pthread.h>
 #include "mpibwa_amd.h"
 
 #define DIE(...) do { fprintf(stderr, "[mpibwa_gpu] " __VA_ARGS__); fputc('\n', stderr); MPI_Abort(MPI_COMM_WORLD, 1); } while (0)
@@ -152,17 +160,108 @@ typedef struct { int64_t first; long long off1, off2; } chunk_t;   /* first reco
 
 static void bcast_cb(void *buf, size_t bytes, int root, void *user) { MPI_Bcast(buf, (int)bytes, MPI_BYTE, root, *(MPI_Comm *)user); }
 
+/* ---- the chunk loop of one rank, shared by its worker threads ---- */
+typedef struct {
+	const mem_opt_t *opt;
+	bwaidx_t *idx;
+	MPI_Win win;
+	MPI_File out, f1, f2;
+	const long long *tab;        /* per chunk: first record, byte offset in R1, byte offset in R2 (+ one closing row) */
+	long long n_chunks;
+	int paired, lockstep, trimmed, copy_comment;
+	int serialize;               /* MPI_THREAD_SERIALIZED: one thread inside MPI at a time */
+	pthread_mutex_t mpi_mu, fetch_mu;
+	int64_t n_fetched;           /* reads of the chunks this rank has taken so far (trimmed pairs: n_processed) */
+	double t_start;
+} loop_t;
+
+#define MPI_ENTER(L) do { if ((L)->serialize) pthread_mutex_lock(&(L)->mpi_mu); } while (0)
+#define MPI_LEAVE(L) do { if ((L)->serialize) pthread_mutex_unlock(&(L)->mpi_mu); } while (0)
+
+/* a buffer a worker keeps from chunk to chunk (no allocation, no page faults per chunk) */
+static void *grown(void **p, size_t *cap, size_t need)
+{
+	if (need > *cap) { free(*p); *cap = need + need / 8 + 4096; *p = malloc(*cap); if (!*p) DIE("out of memory"); }
+	return *p;
+}
+
+static void *chunk_worker(void *arg)
+{
+	loop_t *L = arg;
+	const long long *tab = L->tab;
+	const int paired = L->paired;
+	void *pb1 = 0, *pb2 = 0, *po1 = 0, *po2 = 0, *pbb = 0, *pseqs = 0;
+	size_t cb1 = 0, cb2 = 0, co1 = 0, co2 = 0, cbb = 0, cseqs = 0, csam = 0;
+	char *sam = 0;
+	const int prof = getenv("MPIBWA_DRV_PROF") != 0;
+	for (;;) {
+		long long one = 1, c = 0;
+		int64_t n_before;
+		/* next chunk by fetch-and-add on rank 0's counter (src/mainParallel.c:1112-1119); the rank's own chunks keep their
+		 * order, so that n_processed of a trimmed-pair chunk is what the reference's sequential loop would pass */
+		pthread_mutex_lock(&L->fetch_mu);
+		MPI_ENTER(L);
+		MPI_OK(MPI_Win_lock(MPI_LOCK_SHARED, 0, 0, L->win));
+		MPI_OK(MPI_Fetch_and_op(&one, &c, MPI_LONG_LONG, 0, 0, MPI_SUM, L->win));
+		MPI_OK(MPI_Win_unlock(0, L->win));
+		MPI_LEAVE(L);
+		if (c >= L->n_chunks) { pthread_mutex_unlock(&L->fetch_mu); break; }
+		const int64_t count = tab[3 * (c + 1)] - tab[3 * c];
+		const int n = (int)(count * (paired ? 2 : 1));
+		n_before = L->n_fetched;
+		L->n_fetched += n;
+		pthread_mutex_unlock(&L->fetch_mu);
+		const double t0 = MPI_Wtime();
+		int64_t len1 = tab[3 * (c + 1) + 1] - tab[3 * c + 1], len2 = paired ? tab[3 * (c + 1) + 2] - tab[3 * c + 2] : 0;
+		char *buf1 = grown(&pb1, &cb1, (size_t)len1 + 1), *buf2 = paired ? grown(&pb2, &cb2, (size_t)len2 + 1) : 0;
+		MPI_ENTER(L);
+		read_at(L->f1, tab[3 * c + 1], buf1, len1);
+		if (paired) read_at(L->f2, tab[3 * c + 2], buf2, len2);
+		MPI_LEAVE(L);
+		buf1[len1] = 0;
+		if (paired) buf2[len2] = 0;
+		const double t1 = MPI_Wtime();
+		int64_t *o1 = grown(&po1, &co1, sizeof(int64_t) * (size_t)(count + 1)), *o2 = paired ? grown(&po2, &co2, sizeof(int64_t) * (size_t)(count + 1)) : 0;
+		int32_t *bb = grown(&pbb, &cbb, sizeof(int32_t) * (size_t)(count + 1));
+		if (mi355x_fastq_scan(buf1, len1, count, o1, bb) != count) DIE("chunk %lld of R1 does not hold %lld records", c, (long long)count);
+		if (paired && mi355x_fastq_scan(buf2, len2, count, o2, bb) != count) DIE("chunk %lld of R2 does not hold %lld records", c, (long long)count);
+		bseq1_t *seqs = grown(&pseqs, &cseqs, sizeof(bseq1_t) * (size_t)n);
+		memset(seqs, 0, sizeof(bseq1_t) * (size_t)n);
+		if (mi355x_fastq_fill(buf1, o1, buf2, o2, 0, count, L->copy_comment, L->lockstep, seqs) < 0) DIE("malformed record in chunk %lld", c);
+		const double t2 = MPI_Wtime();
+		/* n_processed: 0 for single end and equal-size pairs, the reads this rank has done for trimmed pairs (src/mainParallel.c:1314, 2355-2357, 3093) */
+		mem_process_seqs(L->opt, L->idx->bwt, L->idx->bns, L->idx->pac, L->trimmed ? n_before : 0, n, seqs, 0);
+		const double t3 = MPI_Wtime();
+		const size_t sam_len = mi355x_collect_sam_into(seqs, n, &sam, &csam);
+		const double t4 = MPI_Wtime();
+		MPI_ENTER(L);
+		for (size_t w = 0; w < sam_len; ) {
+			int piece = sam_len - w > (1u << 30) ? (1 << 30) : (int)(sam_len - w);
+			MPI_Status st;
+			MPI_OK(MPI_File_write_shared(L->out, sam + w, piece, MPI_BYTE, &st));
+			w += (size_t)piece;
+		}
+		MPI_LEAVE(L);
+		if (prof)
+			fprintf(stderr, "[mpibwa_gpu] chunk %lld done at %.3f: read %.0f  scan+fill %.0f  align %.0f  collect %.0f  write %.0f ms\n", c, MPI_Wtime() - L->t_start,
+			        (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (MPI_Wtime() - t4) * 1e3);
+	}
+	free(sam); free(pseqs); free(po1); free(po2); free(pbb); free(pb1); free(pb2);
+	return 0;
+}
+
 int main(int argc, char **argv)
 {
-	MPI_Init(&argc, &argv);
+	int provided = MPI_THREAD_SINGLE;
+	MPI_Init_thread(&argc, &argv, MPI_THREAD_MULTIPLE, &provided);
 	MPI_Comm_rank(MPI_COMM_WORLD, &g_rank);
 	MPI_Comm_size(MPI_COMM_WORLD, &g_size);
-	int n_threads = 0, copy_comment = 0, dry = 0;
+	int n_threads = 0, copy_comment = 0, dry = 0, n_workers = 6;
 	int64_t K = 0;
 	const char *out_path = 0, *pos[4];
 	int n_pos = 0;
 	if (argc < 2 || strcmp(argv[1], "mem") != 0) {
-		if (g_rank == 0) fprintf(stderr, "usage: mpiexec -n N %s mem [-t threads] [-K bases] [-C] [--dry-run] -o OUT PREFIX R1.fastq [R2.fastq]\n", argv[0]);
+		if (g_rank == 0) fprintf(stderr, "usage: mpiexec -n N %s mem [-t threads] [-K bases] [-P chunks in flight] [-C] [--dry-run] -o OUT PREFIX R1.fastq [R2.fastq]\n", argv[0]);
 		MPI_Finalize();
 		return 1;
 	}
@@ -170,6 +269,7 @@ int main(int argc, char **argv)
 		if (!strcmp(argv[i], "-t") && i + 1 < argc) n_threads = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-K") && i + 1 < argc) K = atoll(argv[++i]);
 		else if (!strcmp(argv[i], "-o") && i + 1 < argc) out_path = argv[++i];
+		else if (!strcmp(argv[i], "-P") && i + 1 < argc) n_workers = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-C")) copy_comment = 1;
 		else if (!strcmp(argv[i], "--dry-run")) dry = 1;
 		else if (argv[i][0] == '-') DIE("unknown option %s", argv[i]);
@@ -277,39 +377,30 @@ int main(int argc, char **argv)
 	MPI_OK(MPI_Win_allocate(g_rank == 0 ? sizeof(long long) : 0, sizeof(long long), MPI_INFO_NULL, MPI_COMM_WORLD, &counter_mem, &win));
 	if (g_rank == 0) *counter_mem = 0;
 	MPI_Barrier(MPI_COMM_WORLD);
-	int64_t n_done = 0;
-	for (;;) {
-		long long one = 1, c = 0;
-		MPI_OK(MPI_Win_lock(MPI_LOCK_SHARED, 0, 0, win));
-		MPI_OK(MPI_Fetch_and_op(&one, &c, MPI_LONG_LONG, 0, 0, MPI_SUM, win));
-		MPI_OK(MPI_Win_unlock(0, win));
-		if (c >= n_chunks) break;
-		const int64_t count = tab_all[3 * (c + 1)] - tab_all[3 * c];
-		int64_t len1 = tab_all[3 * (c + 1) + 1] - tab_all[3 * c + 1], len2 = paired ? tab_all[3 * (c + 1) + 2] - tab_all[3 * c + 2] : 0;
-		char *buf1 = malloc((size_t)len1 + 1), *buf2 = paired ? malloc((size_t)len2 + 1) : 0;
-		read_at(f1.fh, tab_all[3 * c + 1], buf1, len1); buf1[len1] = 0;
-		if (paired) { read_at(f2.fh, tab_all[3 * c + 2], buf2, len2); buf2[len2] = 0; }
-		int64_t *o1 = malloc(sizeof(int64_t) * (size_t)(count + 1)), *o2 = paired ? malloc(sizeof(int64_t) * (size_t)(count + 1)) : 0;
-		int32_t *bb = malloc(sizeof(int32_t) * (size_t)(count + 1));
-		if (mi355x_fastq_scan(buf1, len1, count, o1, bb) != count) DIE("chunk %lld of R1 does not hold %lld records", c, (long long)count);
-		if (paired && mi355x_fastq_scan(buf2, len2, count, o2, bb) != count) DIE("chunk %lld of R2 does not hold %lld records", c, (long long)count);
-		const int n = (int)(count * (paired ? 2 : 1));
-		bseq1_t *seqs = calloc((size_t)n, sizeof(bseq1_t));
-		if (mi355x_fastq_fill(buf1, o1, buf2, o2, 0, count, copy_comment, lockstep, seqs) < 0) DIE("malformed record in chunk %lld", c);
-		/* n_processed: 0 for single end and equal-size pairs, the reads this rank has done for trimmed pairs (src/mainParallel.c:1314, 2355-2357, 3093) */
-		mem_process_seqs(opt, idx->bwt, idx->bns, idx->pac, trimmed ? n_done : 0, n, seqs, 0);
-		size_t sam_len = 0;
-		char *sam = mi355x_collect_sam(seqs, n, &sam_len);
-		for (size_t w = 0; w < sam_len; ) {
-			int piece = sam_len - w > (1u << 30) ? (1 << 30) : (int)(sam_len - w);
-			MPI_Status st;
-			MPI_OK(MPI_File_write_shared(out, sam + w, piece, MPI_BYTE, &st));
-			w += (size_t)piece;
-		}
-		free(sam); free(seqs); free(o1); free(o2); free(bb); free(buf1); free(buf2);
-		n_done += n;
-	}
+	const double t_loop = MPI_Wtime();
+	if (provided < MPI_THREAD_SERIALIZED) n_workers = 1;
+	if (n_workers < 1) n_workers = 1;
+	if (n_workers > 8) n_workers = 8;   /* the library runs eight calls side by side */
+	loop_t L;
+	memset(&L, 0, sizeof L);
+	L.opt = opt; L.idx = idx; L.win = win; L.out = out; L.f1 = f1.fh; L.f2 = paired ? f2.fh : MPI_FILE_NULL;
+	L.tab = tab_all; L.n_chunks = n_chunks; L.paired = paired; L.lockstep = lockstep; L.trimmed = trimmed; L.copy_comment = copy_comment;
+	L.serialize = provided < MPI_THREAD_MULTIPLE;
+	L.t_start = t_loop;
+	pthread_mutex_init(&L.mpi_mu, 0);
+	pthread_mutex_init(&L.fetch_mu, 0);
+	pthread_t th[8];
+	for (int w = 1; w < n_workers; ++w)
+		if (pthread_create(&th[w], 0, chunk_worker, &L) != 0) DIE("cannot start worker thread %d", w);
+	chunk_worker(&L);
+	for (int w = 1; w < n_workers; ++w) pthread_join(th[w], 0);
 	MPI_Barrier(MPI_COMM_WORLD);
+	if (g_rank == 0) {   /* the phase the reference brackets with MPI_Wtime (src/mainParallel.c:1238-1240, 1316-1319), over all ranks */
+		const double dt = MPI_Wtime() - t_loop;
+		const long long n_reads = (long long)f1.n_total * (paired ? 2 : 1);
+		fprintf(stderr, "[mpibwa_gpu] chunk loop: %lld reads in %lld chunks, %d rank(s) x %d chunks in flight, %.3f s = %.3f Mreads/s\n", n_reads, n_chunks, g_size,
+		        n_workers, dt, dt > 0 ? n_reads / dt * 1e-6 : 0.);
+	}
 	MPI_Win_free(&win);
 	MPI_File_close(&out);
 	MPI_File_close(&f1.fh);
