@@ -58,6 +58,9 @@ def main():
                     help="distinct chunks per rank the steps cycle through (config 1: 1 M pairs = 3 chunks of 333 334)")
     ap.add_argument("--repeat-frac", type=float, default=float(os.environ.get("MPIBWA_BENCH_REPEAT_FRAC", "0.05")),
                     help="share of the synthetic genome covered by planted repeat families (real GRCh38 is ~0.5: see README)")
+    ap.add_argument("--genome-model", default=os.environ.get("MPIBWA_BENCH_GENOME_MODEL", "uniform"), choices=["uniform", "grch38like"],
+                    help="uniform: i.i.d. bases + planted repeats of 2-40 copies (the headline workload since round 1); grch38like: SURVEY §8d's "
+                         "generator (order-3 Markov, GC 41 %, repeat families of up to 10^4 copies, 0-5 % divergence), use with --repeat-frac 0.5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--in-flight", type=int, default=int(os.environ.get("MPIBWA_BENCH_IN_FLIGHT", "8")),
                     help="caller threads inside mem_process_seqs at once (the library runs up to eight calls side by side: "
@@ -94,7 +97,7 @@ def main():
     t0 = time.time()
     idx = bigindex.make_or_get(args.workdir, genome_mbp=args.genome_mbp, seed=38, rank=rank, world=world,
                                local_rank=dev, dist=dist if world > 1 else None, log=log if rank == 0 else None,
-                               repeat_frac=args.repeat_frac)
+                               repeat_frac=args.repeat_frac, model=args.genome_model)
     eng = idx.engine
     if rank == 0:
         log("index ready in %.1f s: l_pac=%d, occ blocks %.2f GB, SA %.2f GB" %
@@ -260,7 +263,9 @@ def main():
         "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int32", "data": "synthetic",
         "config": {"workload": "%d x %d pairs of 2x%d bp PE reads per GPU vs seeded synthetic %.0f Mbp reference (GRCh38 absent on the box; "
-                               "uniform base composition, %.0f %% of it in planted repeat families)" % (n_chunks, args.pairs, args.read_len, idx.l_pac / 1e6, 100 * args.repeat_frac),
+                               "%s, %.0f %% of it in planted repeat families%s)" % (n_chunks, args.pairs, args.read_len, idx.l_pac / 1e6,
+                                                                                     "uniform base composition" if args.genome_model == "uniform" else "order-3 Markov base composition with GC 41 %",
+                                                                                     100 * args.repeat_frac, "" if args.genome_model == "uniform" else " of up to 10^4 copies"),
                    "pairs_per_step_per_gpu": args.pairs, "distinct_chunks": n_chunks, "reference_mbp": round(idx.l_pac / 1e6, 1),
                    "chunking": "one mem_process_seqs chunk per step (mpiBWA -K 1e8 semantics)", "parallelism": "reads sharded, 1 rank/GPU",
                    "calls_in_flight": n_fly},
@@ -328,6 +333,14 @@ def main():
                 out["cpu_baseline"] = None
         except Exception as e:  # the baseline must never take the bench line down
             out["cpu_baseline"] = {"error": repr(e)}
+    # the same bench on harder references (more repeats; SURVEY §8d's generator), measured in runs of their own with this very
+    # script and committed under profiles/: attached for the reader, not part of `value`
+    try:
+        alt = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_alt_workloads.json")))
+        if args.genome_model == "uniform" and args.repeat_frac == 0.05:
+            out["alt_workloads"] = alt
+    except Exception:
+        pass
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -13,7 +13,7 @@ import numpy as np
 from . import abi, api
 
 _REV_BYTE = None
-BUILDER_VERSION = 2   # bump whenever index_gpu.hip changes, so a cached index of an older build is never reused
+BUILDER_VERSION = 3   # bump whenever index_gpu.hip changes, so a cached index of an older build is never reused
 
 
 def _revcomp_bytes(a):
@@ -85,6 +85,69 @@ def unpack_windows(pac, starts, width):
     return ((pac[idx >> 2] >> ((~idx & 3) << 1).astype(np.uint8)) & 3).astype(np.uint8)
 
 
+def synth_packed_genome_grch38like(total_bases, seed=38, n_contigs=24, repeat_frac=0.5):
+    """The generator of SURVEY.md §8d: order-3 Markov base composition with GC ~ 41 %, and `repeat_frac` of the bases
+    inside planted repeat families with copy numbers 2 .. 10^4 (log-uniform), units of 100 .. 6000 bp, 0 .. 5 % divergence
+    of every copy from its family's consensus, half of the copies reverse-complemented; no N.  Packed 2 bit/base."""
+    total_bases = int(total_bases) // 4 * 4
+    rng = np.random.default_rng(seed)
+    nbytes = total_bases // 4
+    # order-3 Markov chain over bases, advanced a byte (4 bases) at a time on many interleaved streams: the next byte is
+    # drawn given the last three bases through a 4096-entry quantile table per context
+    base_p = np.array([0.295, 0.205, 0.205, 0.295])                      # A C G T: GC = 41 %
+    trans = rng.dirichlet(base_p * 12.0, size=64)                       # P(next base | 3 previous bases)
+    lut = np.zeros((64, 4096), dtype=np.uint8)
+    for ctx in range(64):
+        pb = np.zeros(256)
+        for b in range(256):
+            c, p = ctx, 1.0
+            for k in range(4):
+                x = (b >> (6 - 2 * k)) & 3
+                p *= trans[c, x]
+                c = ((c << 2) | x) & 63
+            pb[b] = p
+        edges = np.floor(np.cumsum(pb) / pb.sum() * 4096 + 0.5).astype(np.int64)
+        lut[ctx] = np.repeat(np.arange(256, dtype=np.uint8), np.diff(np.concatenate([[0], edges])).clip(min=0))[:4096] if edges[-1] >= 4096 else 0
+    n_streams = 1 << 16 if nbytes < (1 << 26) else 1 << 20
+    ls = (nbytes + n_streams - 1) // n_streams
+    arr = np.empty((ls, n_streams), dtype=np.uint8)
+    ctx = rng.integers(0, 64, size=n_streams)
+    for t in range(ls):
+        b = lut[ctx, rng.integers(0, 4096, size=n_streams)]
+        arr[t] = b
+        ctx = (b & 63).astype(np.int64)
+    pac = np.empty(nbytes + 1, dtype=np.uint8)
+    pac[:nbytes] = arr.T.reshape(-1)[:nbytes]
+    pac[nbytes] = 0
+    del arr
+    target = int(total_bases * repeat_frac)
+    placed = 0
+    while placed < target:
+        unit = int(rng.integers(25, 1500))                                # bytes = 100 .. 6000 bases
+        copies = int(np.exp(rng.uniform(np.log(2.0), np.log(1e4))))
+        copies = max(2, min(copies, (target - placed) // (unit * 4) + 2))
+        div = float(rng.uniform(0.0, 0.05))
+        src = int(rng.integers(0, nbytes - unit))
+        u = pac[src:src + unit].copy()
+        cp = np.tile(u, (copies, 1))
+        rc = rng.random(copies) < 0.5
+        if rc.any():
+            cp[rc] = _revcomp_bytes(u)
+        nmut = int(rng.binomial(copies * unit * 4, div))
+        if nmut:
+            where = rng.integers(0, copies * unit * 4, size=nmut)
+            delta = rng.integers(1, 4, size=nmut).astype(np.uint8)
+            sh = ((3 - (where & 3)) * 2).astype(np.uint8)
+            np.bitwise_xor.at(cp.reshape(-1), where >> 2, (delta << sh).astype(np.uint8))
+        dst = rng.integers(0, nbytes - unit, size=copies)
+        for i in range(copies):
+            pac[dst[i]:dst[i] + unit] = cp[i]
+        placed += copies * unit * 4
+    lens = np.full(n_contigs, total_bases // n_contigs // 4 * 4, dtype=np.int64)
+    lens[-1] += total_bases - lens.sum()
+    return pac, lens
+
+
 class BigIndex:
     def __init__(self, prefix, pac, lens, engine):
         self.prefix, self.pac, self.lens, self.engine = prefix, pac, lens, engine
@@ -149,16 +212,19 @@ def _load_packed_genome(prefix):
     return pac, lens
 
 
-def make_or_get(workdir, genome_mbp=3100.0, seed=38, rank=0, world=1, local_rank=0, dist=None, log=None, repeat_frac=0.05):
+def make_or_get(workdir, genome_mbp=3100.0, seed=38, rank=0, world=1, local_rank=0, dist=None, log=None, repeat_frac=0.05, model="uniform"):
     lib = api.load_library()
     lib.mi355x_index_build_gpu.restype = C.c_int
     lib.mi355x_index_build_gpu.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_char_p, C.POINTER(C.c_double)]
     tag = "" if repeat_frac == 0.05 else "_r%d" % int(round(repeat_frac * 100))
+    if model != "uniform":
+        tag += "_" + model
     prefix = os.path.join(workdir, "synth_%dM_s%d%s_b%d.fa" % (int(genome_mbp), seed, tag, BUILDER_VERSION))
     # the genome is generated ONCE per node: rank 0 writes it (with the index), every rank maps .pac from the node-local file
     if rank == 0 and not os.path.exists(prefix + ".ok"):
         t0 = time.time()
-        pac, lens = synth_packed_genome(genome_mbp * 1e6, seed=seed, repeat_frac=repeat_frac)
+        gen = synth_packed_genome_grch38like if model == "grch38like" else synth_packed_genome
+        pac, lens = gen(genome_mbp * 1e6, seed=seed, repeat_frac=repeat_frac)
         if log:
             log("synthetic genome: %.1f Mbp in %d contigs, generated in %.1f s" % (lens.sum() / 1e6, len(lens), time.time() - t0))
         write_meta_files(prefix, pac, lens)

@@ -24,7 +24,12 @@ void *DevBuf::ensure(size_t bytes)
 	if (bytes > cap) {
 		if (p) HIP_OK(hipFree(p));
 		size_t want = bytes + bytes / 4 + 256;
-		HIP_OK(hipMalloc(&p, want));
+		if (hipMalloc(&p, want) != hipSuccess) {
+			size_t fr = 0, tot = 0;
+			(void)hipMemGetInfo(&fr, &tot);
+			die("device work buffer of %.2f GB does not fit: %.1f of %.1f GB free (index, dense SA and the work buffers of up to eight calls in flight share the HBM)",
+			    want / 1e9, fr / 1e9, tot / 1e9);
+		}
 		cap = want;
 	}
 	return p;

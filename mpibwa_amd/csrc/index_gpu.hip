@@ -195,16 +195,45 @@ __global__ void round_key_kernel(const u64 *__restrict__ u_pos, const u32 *__res
 	u64 r2 = q < N ? rank[q] : 0;   // rows start at 1, so 0 sorts before every real suffix
 	keys[j] = (u64)(gid_incl[j] - 1) << 34 | r2;
 }
-__global__ void round_post_kernel(EmitCtx E, const u64 *__restrict__ keys, const u64 *__restrict__ pos, const u32 *__restrict__ sstart,
-                                  u64 m, const u64 *__restrict__ g_row, const u64 *__restrict__ g_idx, u64 *__restrict__ new_rank,
-                                  u64 *__restrict__ o_pos, u64 *__restrict__ o_row, u64 *o_count)
+// ---- more than 2^30 tied suffixes (a genome that is half repeats): the group number no longer fits next to the 34-bit rank in
+// one 64-bit key, so the round's sort is two stable passes over a permutation — by rank[pos + h], then by group — and the group
+// numbers travel in an array of their own.
+__global__ void wide_key_kernel(const u64 *__restrict__ u_pos, u64 m, u64 h, u64 N, const u64 *__restrict__ rank, u64 *__restrict__ r2, u32 *__restrict__ iota)
+{
+	u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= m) return;
+	u64 q = u_pos[j] + h;
+	r2[j] = q < N ? rank[q] : 0;
+	iota[j] = (u32)j;
+}
+__global__ void wide_gather_gid_kernel(const u32 *__restrict__ perm, const u32 *__restrict__ gid_incl, u64 m, u32 *__restrict__ out)
+{
+	u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j < m) out[j] = gid_incl[perm[j]] - 1;
+}
+__global__ void wide_gather_kernel(const u32 *__restrict__ perm, const u64 *__restrict__ r2, const u64 *__restrict__ pos, u64 m, u64 *__restrict__ r2_out,
+                                   u64 *__restrict__ pos_out)
+{
+	u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j < m) { const u32 s = perm[j]; r2_out[j] = r2[s]; pos_out[j] = pos[s]; }
+}
+__global__ void wide_flag_kernel(const u32 *__restrict__ gid, const u64 *__restrict__ r2, u64 n, u32 *__restrict__ head)
+{
+	u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j < n) head[j] = (j == 0 || gid[j] != gid[j - 1] || r2[j] != r2[j - 1]) ? (u32)j : 0u;
+}
+
+template <bool WIDE>
+__global__ void round_post_kernel(EmitCtx E, const u64 *__restrict__ keys, const u32 *__restrict__ gid_sorted, const u64 *__restrict__ pos,
+                                  const u32 *__restrict__ sstart, u64 m, const u64 *__restrict__ g_row, const u64 *__restrict__ g_idx,
+                                  u64 *__restrict__ new_rank, u64 *__restrict__ o_pos, u64 *__restrict__ o_row, u64 *o_count)
 {
 	u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
 	bool tied = false;
 	u64 p = 0, srow = 0;
 	if (j < m) {
 		p = pos[j];
-		u32 g = (u32)(keys[j] >> 34);
+		u32 g = WIDE ? gid_sorted[j] : (u32)(keys[j] >> 34);
 		u32 s = sstart[j];
 		srow = g_row[g] + (s - g_idx[g]);            // first row of the sub-group
 		new_rank[j] = srow;
@@ -356,7 +385,7 @@ extern "C" int mi355x_index_build_gpu(int device, const uint8_t *pac, int64_t l_
 			u64 have = 0;
 			HIP_OK(hipMemcpy(&have, d_ucount.p, 8, hipMemcpyDeviceToHost));
 			if (have + n > u_cap) {
-				u64 ncap = std::max(u_cap * 2, have + n);
+				u64 ncap = std::max(u_cap + u_cap / 4, have + n);
 				Buf *np = new Buf(ncap * 8), *nr = new Buf(ncap * 8);
 				HIP_OK(hipMemcpy(np->p, u_pos->p, have * 8, hipMemcpyDeviceToDevice));
 				HIP_OK(hipMemcpy(nr->p, u_row->p, have * 8, hipMemcpyDeviceToDevice));
@@ -374,36 +403,66 @@ extern "C" int mi355x_index_build_gpu(int device, const uint8_t *pac, int64_t l_
 
 	u64 m = 0;
 	HIP_OK(hipMemcpy(&m, d_ucount.p, 8, hipMemcpyDeviceToHost));
-	if (m >= (1ull << 30)) die("index builder: %llu tied suffixes exceed the 2^30 dense-group budget", m);
+	if (m >= (1ull << 31) - 1024) die("index builder: %llu tied suffixes exceed the 2^31 budget of the doubling rounds", m);
+	// one composite key [group | rank] while the group number fits 30 bits, else two stable sort passes (MPIBWA_IDX_WIDE=1 forces them: tests)
+	const bool wide = m >= (1ull << 30) || getenv("MPIBWA_IDX_WIDE") != nullptr;
 	if (m) {
-		// the round-0 list was appended in arbitrary order: bring it into row order once (groups are contiguous row ranges)
-		Buf a_row(m * 8), a_pos(m * 8), b_row(m * 8), b_pos(m * 8), keys(m * 8), keys2(m * 8), nrank(m * 8), gflag(m * 4), gid(m * 4),
-		    sflag(m * 4), sst(m * 4), g_row(m * 8), g_idx(m * 8), d_sel(8);
-		size_t t1 = 0, t2 = 0, t3 = 0, t4 = 0;
-		hipcub::DeviceRadixSort::SortPairs(nullptr, t1, a_row.as<u64>(), b_row.as<u64>(), a_pos.as<u64>(), b_pos.as<u64>(), (int)m, 0, 34);
-		hipcub::DeviceRadixSort::SortPairs(nullptr, t2, keys.as<u64>(), keys2.as<u64>(), a_pos.as<u64>(), b_pos.as<u64>(), (int)m, 0, 64);
-		hipcub::DeviceScan::InclusiveSum(nullptr, t3, gflag.as<u32>(), gid.as<u32>(), (int)m);
-		hipcub::DeviceSelect::If(nullptr, t4, a_pos.as<u64>(), b_pos.as<u64>(), d_sel.as<u64>(), (int)m, NotDropped());
-		Buf tmp(std::max(std::max(t1, t2), std::max(t3, t4)) + 256);
+		// the round-0 list was appended in arbitrary order: bring it into row order once (groups are contiguous row ranges).
+		// Memory (a genome that is half repeats has 1.5 G tied suffixes): 48 bytes per item for the ping-pong arrays and the keys,
+		// 8 for the flag / scan arrays, 8 for the group table (a group has at least two items), 16 more for the wide rounds;
+		// arrays that are never alive together share storage (new ranks in `keys`, sorted ranks in `keys2`).
+		Buf a_row(m * 8), a_pos(m * 8), d_sel(8);
+		size_t t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
+		hipcub::DeviceRadixSort::SortPairs(nullptr, t1, a_row.as<u64>(), a_row.as<u64>(), a_pos.as<u64>(), a_pos.as<u64>(), (int)m, 0, 34);
+		hipcub::DeviceRadixSort::SortPairs(nullptr, t2, a_row.as<u64>(), a_row.as<u64>(), a_pos.as<u64>(), a_pos.as<u64>(), (int)m, 0, 64);
+		hipcub::DeviceScan::InclusiveSum(nullptr, t3, (u32 *)nullptr, (u32 *)nullptr, (int)m);
+		hipcub::DeviceSelect::If(nullptr, t4, a_pos.as<u64>(), a_pos.as<u64>(), d_sel.as<u64>(), (int)m, NotDropped());
+		hipcub::DeviceRadixSort::SortPairs(nullptr, t5, a_row.as<u64>(), a_row.as<u64>(), (u32 *)nullptr, (u32 *)nullptr, (int)m, 0, 34);
+		hipcub::DeviceRadixSort::SortPairs(nullptr, t6, (u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, (int)m, 0, 32);
+		Buf tmp(std::max(std::max(std::max(t1, t2), std::max(t3, t4)), std::max(t5, t6)) + 256);
 		size_t ts = t1;
 		HIP_OK(hipcub::DeviceRadixSort::SortPairs(tmp.p, ts, u_row->as<u64>(), a_row.as<u64>(), u_pos->as<u64>(), a_pos.as<u64>(), (int)m, 0, 34));
+		HIP_OK(hipDeviceSynchronize());
 		delete u_pos; delete u_row;
 		u_pos = u_row = nullptr;
+		Buf b_row(m * 8), b_pos(m * 8), keys(m * 8), keys2(m * 8), gflag(m * 4), gid(m * 4), g_row((m / 2 + 2) * 8), g_idx((m / 2 + 2) * 8);
+		Buf &nrank = keys;        // written by round_post_kernel, after the round's last reader of `keys`
+		Buf &sflag = gflag;       // the group flags are dead once the group numbers exist
+		Buf &sst = gid;           // ... and the group numbers once the keys are built
+		const u64 mw = wide ? m : 1;
+		Buf w_p1(mw * 4), w_p2(mw * 4), w_g1(mw * 4), w_g2(mw * 4);
+		Buf &w_r2 = keys2;        // the wide rounds read the sorted ranks of their first pass from nowhere: the slot takes the final order's
 		u64 *cur_row = a_row.as<u64>(), *cur_pos = a_pos.as<u64>(), *alt_row = b_row.as<u64>(), *alt_pos = b_pos.as<u64>();
 		for (u64 h = KMER; m > 0; h <<= 1) {
 			hipLaunchKernelGGL(dense_gid_kernel, dim3(grid_for(m, BS)), dim3(BS), 0, 0, cur_row, m, gflag.as<u32>());
 			ts = t3;
 			HIP_OK(hipcub::DeviceScan::InclusiveSum(tmp.p, ts, gflag.as<u32>(), gid.as<u32>(), (int)m));
 			hipLaunchKernelGGL(group_table_kernel, dim3(grid_for(m, BS)), dim3(BS), 0, 0, cur_row, gid.as<u32>(), m, g_row.as<u64>(), g_idx.as<u64>());
-			hipLaunchKernelGGL(round_key_kernel, dim3(grid_for(m, BS)), dim3(BS), 0, 0, cur_pos, gid.as<u32>(), m, h, N, d_rank.as<u64>(), keys.as<u64>());
-			ts = t2;
-			HIP_OK(hipcub::DeviceRadixSort::SortPairs(tmp.p, ts, keys.as<u64>(), keys2.as<u64>(), cur_pos, alt_pos, (int)m, 0, 64));
-			hipLaunchKernelGGL(flag_kernel, dim3(grid_for(m, BS)), dim3(BS), 0, 0, keys2.as<u64>(), m, sflag.as<u32>());
+			if (!wide) {
+				hipLaunchKernelGGL(round_key_kernel, dim3(grid_for(m, BS)), dim3(BS), 0, 0, cur_pos, gid.as<u32>(), m, h, N, d_rank.as<u64>(), keys.as<u64>());
+				ts = t2;
+				HIP_OK(hipcub::DeviceRadixSort::SortPairs(tmp.p, ts, keys.as<u64>(), keys2.as<u64>(), cur_pos, alt_pos, (int)m, 0, 64));
+				hipLaunchKernelGGL(flag_kernel, dim3(grid_for(m, BS)), dim3(BS), 0, 0, keys2.as<u64>(), m, sflag.as<u32>());
+			} else {
+				// stable by rank[pos + h], then stable by group: the order of the composite key
+				hipLaunchKernelGGL(wide_key_kernel, dim3(grid_for(m, BS)), dim3(BS), 0, 0, cur_pos, m, h, N, d_rank.as<u64>(), keys.as<u64>(), w_p1.as<u32>());
+				ts = t5;
+				HIP_OK(hipcub::DeviceRadixSort::SortPairs(tmp.p, ts, keys.as<u64>(), keys2.as<u64>(), w_p1.as<u32>(), w_p2.as<u32>(), (int)m, 0, 34));
+				hipLaunchKernelGGL(wide_gather_gid_kernel, dim3(grid_for(m, BS)), dim3(BS), 0, 0, w_p2.as<u32>(), gid.as<u32>(), m, w_g1.as<u32>());
+				ts = t6;
+				HIP_OK(hipcub::DeviceRadixSort::SortPairs(tmp.p, ts, w_g1.as<u32>(), w_g2.as<u32>(), w_p2.as<u32>(), w_p1.as<u32>(), (int)m, 0, 32));
+				hipLaunchKernelGGL(wide_gather_kernel, dim3(grid_for(m, BS)), dim3(BS), 0, 0, w_p1.as<u32>(), keys.as<u64>(), cur_pos, m, w_r2.as<u64>(), alt_pos);
+				hipLaunchKernelGGL(wide_flag_kernel, dim3(grid_for(m, BS)), dim3(BS), 0, 0, w_g2.as<u32>(), w_r2.as<u64>(), m, sflag.as<u32>());
+			}
 			ts = t3;
 			HIP_OK(hipcub::DeviceScan::InclusiveScan(tmp.p, ts, sflag.as<u32>(), sst.as<u32>(), MaxOp(), (int)m));
 			// alt_pos = positions in the new order; cur_pos/cur_row are rewritten with the survivors (dropped = ~0)
-			hipLaunchKernelGGL(round_post_kernel, dim3(grid_for(m, BS)), dim3(BS), 0, 0, E, keys2.as<u64>(), alt_pos, sst.as<u32>(), m, g_row.as<u64>(),
-			                   g_idx.as<u64>(), nrank.as<u64>(), cur_pos, cur_row, (u64 *)nullptr);
+			if (!wide)
+				hipLaunchKernelGGL(round_post_kernel<false>, dim3(grid_for(m, BS)), dim3(BS), 0, 0, E, keys2.as<u64>(), (const u32 *)nullptr, alt_pos, sst.as<u32>(), m,
+				                   g_row.as<u64>(), g_idx.as<u64>(), nrank.as<u64>(), cur_pos, cur_row, (u64 *)nullptr);
+			else
+				hipLaunchKernelGGL(round_post_kernel<true>, dim3(grid_for(m, BS)), dim3(BS), 0, 0, E, (const u64 *)nullptr, w_g2.as<u32>(), alt_pos, sst.as<u32>(), m,
+				                   g_row.as<u64>(), g_idx.as<u64>(), nrank.as<u64>(), cur_pos, cur_row, (u64 *)nullptr);
 			hipLaunchKernelGGL(scatter_rank_kernel, dim3(grid_for(m, BS)), dim3(BS), 0, 0, alt_pos, nrank.as<u64>(), m, d_rank.as<u64>());
 			// stable compaction of the survivors (dropped entries carry ~0 in both arrays)
 			ts = t4;

@@ -9,11 +9,17 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("mbp,seed", [(0.3, 3), (2.0, 5), (5.0, 38)])
-def test_gpu_builder_matches_cpu_builder(tmp_path, built, mbp, seed):
+@pytest.mark.parametrize("mbp,seed,wide", [(0.3, 3, False), (2.0, 5, False), (5.0, 38, False), (3.0, 7, True)])
+def test_gpu_builder_matches_cpu_builder(tmp_path, built, mbp, seed, wide, monkeypatch):
+    """wide: a repeat-rich genome (SURVEY §8d's generator, half of it repeats) through the doubling rounds' two-pass sort, the
+    path the builder takes by itself beyond 2^30 tied suffixes."""
     from mpibwa_amd import api, bigindex
     lib = api.load_library()
-    pac, lens = bigindex.synth_packed_genome(mbp * 1e6, seed=seed, n_contigs=3, repeat_frac=0.08)
+    if wide:
+        monkeypatch.setenv("MPIBWA_IDX_WIDE", "1")
+        pac, lens = bigindex.synth_packed_genome_grch38like(mbp * 1e6, seed=seed, n_contigs=3, repeat_frac=0.5)
+    else:
+        pac, lens = bigindex.synth_packed_genome(mbp * 1e6, seed=seed, n_contigs=3, repeat_frac=0.08)
     l_pac = int(lens.sum())
     # CPU path: FASTA -> mi355x_index_build
     lut = np.frombuffer(b"ACGT", dtype=np.uint8)
