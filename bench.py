@@ -62,6 +62,9 @@ def main():
                     help="uniform: i.i.d. bases + planted repeats of 2-40 copies (the headline workload since round 1); grch38like: SURVEY §8d's "
                          "generator (order-3 Markov, GC 41 %, repeat families of up to 10^4 copies, 0-5 % divergence), use with --repeat-frac 0.5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check-parity", action="store_true",
+                    help="every rank also aligns its chunks with the reference (oracle/_ref) and compares the SAM: `parity_all_ranks` "
+                         "(N > 1 runs carry no CPU baseline; for small configurations)")
     ap.add_argument("--in-flight", type=int, default=int(os.environ.get("MPIBWA_BENCH_IN_FLIGHT", "8")),
                     help="caller threads inside mem_process_seqs at once (the library runs up to eight calls side by side: "
                          "the GPU-bound half of one chunk overlaps the host-bound half of the previous one)")
@@ -333,6 +336,30 @@ def main():
                 out["cpu_baseline"] = None
         except Exception as e:  # the baseline must never take the bench line down
             out["cpu_baseline"] = {"error": repr(e)}
+    # ---- N > 1 (or on request): every rank checks its own chunks against the reference; the line carries the AND over the ranks ----
+    if args.check_parity:
+        ok_here = 1
+        try:
+            from oracle import pyoracle as po
+            ref = po.RefIndex(idx.prefix)
+            C.c_int.in_dll(ref.lib, "bwa_verbose").value = 1
+            ropt = ref.opt(flag=abi.MEM_F_PE, n_threads=cores)
+            for c in range(n_chunks):
+                sample = chunk_reads[c][:min(args.cpu_sample_pairs or len(chunk_reads[c]), len(chunk_reads[c]))]
+                rb = abi.SeqBatch(po.libc, sample)
+                ref.lib.mem_process_seqs(ropt, ref.bwt, ref.bns, ref.pac, 0, rb.n, rb.arr, None)
+                if eng.process(opt, sample) != rb.take_sam():
+                    ok_here = 0
+        except Exception as e:
+            log("rank %d: parity check failed to run: %r" % (rank, e))
+            ok_here = 0
+        if world > 1:
+            t = torch.tensor([ok_here], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok_here = int(t.item())
+        out["parity_all_ranks"] = bool(ok_here)
+    out["index_residency"] = {"rank0": "host upload", "other_ranks": "broadcast from rank 0 (torch.distributed, in place on the index arrays)" if world > 1 else None,
+                              "broadcast_s": round(eng.bcast_seconds, 3) if eng.bcast_seconds is not None else None}
     # the same bench on harder references (more repeats; SURVEY §8d's generator), measured in runs of their own with this very
     # script and committed under profiles/: attached for the reader, not part of `value`
     try:
@@ -346,7 +373,7 @@ def main():
     if world > 1:
         dist.destroy_process_group()
     # a throughput figure next to SAM that differs from the reference's is not a result: fail the run
-    if out.get("parity_on_sample") is False or out.get("all_steps_identical_to_checked_sam") is False:
+    if out.get("parity_on_sample") is False or out.get("all_steps_identical_to_checked_sam") is False or out.get("parity_all_ranks") is False:
         log("FAILED: SAM differs from the reference (parity_on_sample=%r, all_steps_identical_to_checked_sam=%r)" %
             (out.get("parity_on_sample"), out.get("all_steps_identical_to_checked_sam")))
         sys.exit(3)
