@@ -67,7 +67,7 @@ def build_driver(force=False, verbose=False):
     if force or _stale(exe, [src, OUT, os.path.join(HERE, "..", "include", "mpibwa_amd.h")]):
         cmd = ["gcc", "-O2", "-std=gnu99", "-Wall", "-I", os.path.join(HERE, "..", "include"), "-I", inc, src, "-o", exe,
                "-L", HERE, "-lmpibwa_amd", os.path.join(libdir, "libmpi.so"),
-               "-Wl,-rpath,/usr/lib/x86_64-linux-gnu:$ORIGIN:" + libdir, "-Wl,-rpath-link,/opt/rocm/lib"]
+               "-Wl,-rpath,/usr/lib/x86_64-linux-gnu:$ORIGIN:" + libdir, "-Wl,-rpath-link,/opt/rocm/lib", "-lpthread", "-lm"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

@@ -2,6 +2,7 @@
 #ifndef MBW_DEVICE_H
 #define MBW_DEVICE_H
 #include "internal.h"
+#include <mutex>
 
 namespace mbw {
 
@@ -39,12 +40,15 @@ struct DevIndex {
 	// what is resident, as the caller's host-side index describes itself (compared on every mem_process_seqs call)
 	uint64_t id_primary = 0, id_seq_len = 0, id_L2[5] = {0, 0, 0, 0, 0};
 	int id_n_seqs = 0;
+	uint64_t id_hash = 0;   // of the contig table (offsets, lengths, names) and the first occ block
 };
 DevIndex &dev_index();
 // true when (bwt, bns) describe the index that is resident; message = what differs
 bool index_matches(const bwt_t *bwt, const bntseq_t *bns, const char **what);
 // calls of mem_process_seqs currently inside the library (pipeline.hip); index upload / release need it to be 0
 int calls_in_flight();
+// serialises "is the index resident / the right one, then count the call in" (mem_process_seqs) against upload and release
+std::recursive_mutex &index_mutex();
 
 // SMEM seeding parameters (subset of mem_opt_t used by mem_collect_intv)
 struct SmemParams {

@@ -54,6 +54,19 @@ static void require_device(int local_rank)
 	g_idx.device = local_rank % n;
 }
 
+static uint64_t index_hash(const bwt_t *bwt, const bntseq_t *bns)
+{
+	uint64_t h = 1469598103934665603ull;   // FNV-1a
+	auto mix = [&](const void *p, size_t n) { const uint8_t *b = (const uint8_t *)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } };
+	for (int i = 0; i < bns->n_seqs; ++i) {
+		mix(&bns->anns[i].offset, sizeof bns->anns[i].offset);
+		mix(&bns->anns[i].len, sizeof bns->anns[i].len);
+		if (bns->anns[i].name) mix(bns->anns[i].name, strlen(bns->anns[i].name));
+	}
+	if (bwt->bwt && bwt->bwt_size >= 16) mix(bwt->bwt, 64);
+	return h;
+}
+
 bool index_matches(const bwt_t *bwt, const bntseq_t *bns, const char **what)
 {
 	const char *w = nullptr;
@@ -62,6 +75,7 @@ bool index_matches(const bwt_t *bwt, const bntseq_t *bns, const char **what)
 	else if (memcmp(bwt->L2, g_idx.id_L2, sizeof g_idx.id_L2) != 0) w = "L2";
 	else if (bns->l_pac != g_idx.l_pac) w = "l_pac";
 	else if (bns->n_seqs != g_idx.id_n_seqs) w = "n_seqs";
+	else if (index_hash(bwt, bns) != g_idx.id_hash) w = "contig table or BWT";
 	if (what) *what = w;
 	return w == nullptr;
 }
@@ -73,6 +87,7 @@ static void no_calls_in_flight(const char *who)
 
 static void alloc_index(const bwt_t *bwt, const bntseq_t *bns)
 {
+	std::lock_guard<std::recursive_mutex> lk(index_mutex());   // no call can pass its residency check while the buffers are replaced
 	no_calls_in_flight("index upload");
 	g_idx.ready = false;
 	if (g_idx.d_blk) { (void)hipFree(g_idx.d_blk); (void)hipFree(g_idx.d_sa); (void)hipFree(g_idx.d_pac); }
@@ -98,9 +113,12 @@ static void alloc_index(const bwt_t *bwt, const bntseq_t *bns)
 	fm.sa_shift = sh;
 	g_idx.l_pac = bns->l_pac;
 	g_idx.id_primary = bwt->primary; g_idx.id_seq_len = bwt->seq_len; g_idx.id_n_seqs = bns->n_seqs;
+	g_idx.id_hash = index_hash(bwt, bns);
 	memcpy(g_idx.id_L2, bwt->L2, sizeof g_idx.id_L2);
 	if (bwt->seq_len >= (1ull << 34))
 		die("reference of %llu symbols: this build packs SA-interval bounds into 34 bits (references up to 8.5 Gbp)", (unsigned long long)bwt->seq_len);
+	// the buffers are handed to collectives on other streams next (RCCL, torch): the memsets above must have landed
+	HIP_OK(hipDeviceSynchronize());
 }
 
 } // namespace mbw
@@ -231,6 +249,7 @@ extern "C" int mi355x_index_commit(void)
 
 extern "C" void mi355x_finalize(void)
 {
+	std::lock_guard<std::recursive_mutex> lk(index_mutex());
 	no_calls_in_flight("mi355x_finalize");
 	if (g_idx.d_blk) { (void)hipFree(g_idx.d_blk); (void)hipFree(g_idx.d_sa); (void)hipFree(g_idx.d_pac); }
 	if (g_idx.d_sa_full) (void)hipFree(g_idx.d_sa_full);

@@ -351,7 +351,9 @@ struct CallCtx {
 };
 static const int MAX_CALLS = 8;
 static CallCtx g_ctx[MAX_CALLS];
-static std::mutex g_ctx_mu, g_init_mu;
+static std::mutex g_ctx_mu;
+static std::recursive_mutex g_init_mu;
+std::recursive_mutex &index_mutex() { return g_init_mu; }
 static std::condition_variable g_ctx_cv;
 struct CtxLease {
 	CallCtx *c = nullptr;
@@ -451,7 +453,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 {
 	const double t_begin = now_ms(), c_begin = cpu_sec(), s_begin = sys_sec();
 	DevIndex &ix = dev_index();
-	std::unique_lock<std::mutex> init_lk(g_init_mu);
+	std::unique_lock<std::recursive_mutex> init_lk(g_init_mu);
 	if (!ix.ready) {
 		// first call and nobody called mi355x_init / mi355x_index_upload: make the index resident (one rank per GPU, the GPU
 		// named by the launcher's local rank).  Several ranks on the node and no local rank known = every rank would pile

@@ -1,6 +1,9 @@
 /* mpibwa_gpu.c — a thin MPI host program around the C ABI of libmpibwa_amd.so: one rank per GPU,
  *
- *     mpiexec -n N mpibwa_gpu mem [-t threads] [-K bases] [-P chunks in flight] [-C] [--dry-run] -o OUT PREFIX R1.fastq [R2.fastq]
+ *     mpiexec -n N mpibwa_gpu mem [bwa mem options] [-K bases] [--in-flight chunks] [--dry-run] -o OUT PREFIX R1.fastq [R2.fastq]
+ *
+ * The `mem` options are the reference's (src/mainParallel.c:311-398: -k -w -A -B -O -E -L -U -T -c -d -r -D -m -s -G -N -W -y -X -h -Q -I -R -H
+ * -P -a -M -S -Y -V -5 -q -j -C -v -t -K -o); -p, -x, -b, -g, -f and -z are not offered.
  *
  * It does, with this repo's own code, what mpiBWA's main does around mem_process_seqs():
  *   - every rank takes a byte slice of each FASTQ file, finds the first record boundary in it and scans its records
@@ -18,7 +21,7 @@
  * from the node's first rank; where ranks outnumber GPUs (tests on a one-GPU box) every rank uploads its own copy.
  *
  * Reading, aligning and writing overlap (the reference's docs/TODO:4, "overlaping reading, aligning and writing"): the
- * chunk loop runs on -P worker threads per rank (default 6), each of them fetching the next chunk number, reading its bytes
+ * chunk loop runs on --in-flight worker threads per rank (default 6), each of them fetching the next chunk number, reading its bytes
  * with MPI-IO, building the bseq1_t array, calling mem_process_seqs() — the library runs up to eight calls side by side,
  * the GPU half of one chunk under the host half of another — and appending the SAM text through the shared file pointer.
  * With MPI_THREAD_MULTIPLE the workers call MPI concurrently; with MPI_THREAD_SERIALIZED a mutex takes turns; below that
@@ -33,6 +36,8 @@
 #include <string.h>
 #include <stdint.h>
 #include <pthread.h>
+#include <ctype.h>
+#include <math.h>
 #include "mpibwa_amd.h"
 
 #define DIE(...) do { fprintf(stderr, "[mpibwa_gpu] " __VA_ARGS__); fputc('\n', stderr); MPI_Abort(MPI_COMM_WORLD, 1); } while (0)
@@ -139,20 +144,26 @@ static void fq_open(fq_t *f, const char *path)
 }
 
 /* bases of records [i0, i1) of `f` (global indices) as this rank needs them for the chunk rule over both files: the two
- * files are sliced by bytes, so the mate of a local R1 record may have been scanned by another rank */
+ * files are sliced by bytes, so the mate of a local R1 record may have been scanned by another rank.  Every rank sends each
+ * other rank exactly the part of its own records that rank asked for (MPI_Alltoallv): nothing is replicated. */
 static int32_t *bases_for_range(const fq_t *f, int64_t i0, int64_t i1)
 {
-	int *cnt = malloc(sizeof(int) * (size_t)g_size), *dsp = malloc(sizeof(int) * (size_t)g_size);
-	long long nl = f->n_local;
-	long long *alln = malloc(sizeof(long long) * (size_t)g_size);
-	MPI_OK(MPI_Allgather(&nl, 1, MPI_LONG_LONG, alln, 1, MPI_LONG_LONG, MPI_COMM_WORLD));
-	long long tot = 0;
-	for (int r = 0; r < g_size; ++r) { if (alln[r] > 0x7fffffff || tot > 0x7fffffff) DIE("too many records for the gather"); cnt[r] = (int)alln[r]; dsp[r] = (int)tot; tot += alln[r]; }
-	int32_t *all = malloc(sizeof(int32_t) * (size_t)(tot + 1));
-	MPI_OK(MPI_Allgatherv(f->bases, (int)f->n_local, MPI_INT, all, cnt, dsp, MPI_INT, MPI_COMM_WORLD));
+	long long mine[4] = {f->first_index, f->first_index + f->n_local, i0, i1};
+	long long *all = malloc(sizeof(long long) * 4 * (size_t)g_size);
+	MPI_OK(MPI_Allgather(mine, 4, MPI_LONG_LONG, all, 4, MPI_LONG_LONG, MPI_COMM_WORLD));
+	int *scnt = calloc((size_t)g_size, sizeof(int)), *sdsp = calloc((size_t)g_size, sizeof(int));
+	int *rcnt = calloc((size_t)g_size, sizeof(int)), *rdsp = calloc((size_t)g_size, sizeof(int));
+	for (int r = 0; r < g_size; ++r) {
+		/* what rank r wants of my records */
+		long long lo = all[4 * r + 2] > mine[0] ? all[4 * r + 2] : mine[0], hi = all[4 * r + 3] < mine[1] ? all[4 * r + 3] : mine[1];
+		if (hi > lo) { if (hi - lo > 0x7fffffff) DIE("too many records in one exchange"); scnt[r] = (int)(hi - lo); sdsp[r] = (int)(lo - mine[0]); }
+		/* what I want of rank r's records */
+		lo = i0 > all[4 * r] ? i0 : all[4 * r]; hi = i1 < all[4 * r + 1] ? i1 : all[4 * r + 1];
+		if (hi > lo) { if (hi - lo > 0x7fffffff) DIE("too many records in one exchange"); rcnt[r] = (int)(hi - lo); rdsp[r] = (int)(lo - i0); }
+	}
 	int32_t *out = malloc(sizeof(int32_t) * (size_t)(i1 - i0 + 1));
-	memcpy(out, all + i0, sizeof(int32_t) * (size_t)(i1 - i0));
-	free(all); free(cnt); free(dsp); free(alln);
+	MPI_OK(MPI_Alltoallv(f->bases, scnt, sdsp, MPI_INT, out, rcnt, rdsp, MPI_INT, MPI_COMM_WORLD));
+	free(all); free(scnt); free(sdsp); free(rcnt); free(rdsp);
 	return out;
 }
 
@@ -169,6 +180,7 @@ typedef struct {
 	const long long *tab;        /* per chunk: first record, byte offset in R1, byte offset in R2 (+ one closing row) */
 	long long n_chunks;
 	int paired, lockstep, trimmed, copy_comment;
+	const mem_pestat_t *pes0;    /* -I */
 	int serialize;               /* MPI_THREAD_SERIALIZED: one thread inside MPI at a time */
 	pthread_mutex_t mpi_mu, fetch_mu;
 	int64_t n_fetched;           /* reads of the chunks this rank has taken so far (trimmed pairs: n_processed) */
@@ -230,7 +242,7 @@ static void *chunk_worker(void *arg)
 		if (mi355x_fastq_fill(buf1, o1, buf2, o2, 0, count, L->copy_comment, L->lockstep, seqs) < 0) DIE("malformed record in chunk %lld", c);
 		const double t2 = MPI_Wtime();
 		/* n_processed: 0 for single end and equal-size pairs, the reads this rank has done for trimmed pairs (src/mainParallel.c:1314, 2355-2357, 3093) */
-		mem_process_seqs(L->opt, L->idx->bwt, L->idx->bns, L->idx->pac, L->trimmed ? n_before : 0, n, seqs, 0);
+		mem_process_seqs(L->opt, L->idx->bwt, L->idx->bns, L->idx->pac, L->trimmed ? n_before : 0, n, seqs, L->pes0);
 		const double t3 = MPI_Wtime();
 		const size_t sam_len = mi355x_collect_sam_into(seqs, n, &sam, &csam);
 		const double t4 = MPI_Wtime();
@@ -257,28 +269,122 @@ int main(int argc, char **argv)
 	MPI_Comm_rank(MPI_COMM_WORLD, &g_rank);
 	MPI_Comm_size(MPI_COMM_WORLD, &g_size);
 	int n_threads = 0, copy_comment = 0, dry = 0, n_workers = 6;
+	int scale_a = 0, set_b = 0, set_T = 0, set_U = 0, set_d = 0, set_O = 0, set_E = 0, set_L = 0;
 	int64_t K = 0;
 	const char *out_path = 0, *pos[4];
 	int n_pos = 0;
 	if (argc < 2 || strcmp(argv[1], "mem") != 0) {
-		if (g_rank == 0) fprintf(stderr, "usage: mpiexec -n N %s mem [-t threads] [-K bases] [-P chunks in flight] [-C] [--dry-run] -o OUT PREFIX R1.fastq [R2.fastq]\n", argv[0]);
+		if (g_rank == 0) fprintf(stderr, "usage: mpiexec -n N %s mem [bwa mem options] [-K bases] [--in-flight chunks] [--dry-run] -o OUT PREFIX R1.fastq [R2.fastq]\n", argv[0]);
 		MPI_Finalize();
 		return 1;
 	}
+	/* the reference's `mem` options (src/mainParallel.c:311-398), same letters and meanings; plus --in-flight and --dry-run */
+	mem_opt_t *opt = mem_opt_init();
+	int ignore_alt = 0;
+	char *rg_line = 0, *hdr_line = 0;
+	mem_pestat_t pes[4], *pes0 = 0;
+	memset(pes, 0, sizeof pes);
 	for (int i = 2; i < argc; ++i) {
-		if (!strcmp(argv[i], "-t") && i + 1 < argc) n_threads = atoi(argv[++i]);
-		else if (!strcmp(argv[i], "-K") && i + 1 < argc) K = atoll(argv[++i]);
-		else if (!strcmp(argv[i], "-o") && i + 1 < argc) out_path = argv[++i];
-		else if (!strcmp(argv[i], "-P") && i + 1 < argc) n_workers = atoi(argv[++i]);
-		else if (!strcmp(argv[i], "-C")) copy_comment = 1;
-		else if (!strcmp(argv[i], "--dry-run")) dry = 1;
-		else if (argv[i][0] == '-') DIE("unknown option %s", argv[i]);
-		else if (n_pos < 3) pos[n_pos++] = argv[i];
+		const char *a = argv[i];
+		if (!strcmp(a, "--dry-run")) { dry = 1; continue; }
+		if (!strcmp(a, "--in-flight") && i + 1 < argc) { n_workers = atoi(argv[++i]); continue; }
+		if (a[0] != '-' || !a[1]) { if (n_pos < 3) pos[n_pos++] = a; continue; }
+		if (a[2]) DIE("unknown option %s (options take their value as the next argument)", a);
+		const char c = a[1];
+		if (strchr("PapMSYV5qjC", c)) {   /* flags */
+			if (c == 'P') opt->flag |= MEM_F_NOPAIRING;
+			else if (c == 'a') opt->flag |= MEM_F_ALL;
+			else if (c == 'p') DIE("-p (interleaved pairs in one file) is not supported: give R1 and R2");
+			else if (c == 'M') opt->flag |= MEM_F_NO_MULTI;
+			else if (c == 'S') opt->flag |= MEM_F_NO_RESCUE;
+			else if (c == 'Y') opt->flag |= MEM_F_SOFTCLIP;
+			else if (c == 'V') opt->flag |= MEM_F_REF_HDR;
+			else if (c == '5') opt->flag |= MEM_F_PRIMARY5 | MEM_F_KEEP_SUPP_MAPQ;
+			else if (c == 'q') opt->flag |= MEM_F_KEEP_SUPP_MAPQ;
+			else if (c == 'j') ignore_alt = 1;
+			else if (c == 'C') copy_comment = 1;
+			continue;
+		}
+		if (!strchr("kwABTUtcdvrDmsGNWyKXhQOELRHIo", c)) DIE("unknown or unsupported option %s", a);
+		if (i + 1 >= argc) DIE("option %s needs a value", a);
+		char *v = argv[++i], *e = 0;
+		if (c == 'k') opt->min_seed_len = atoi(v);
+		else if (c == 'w') opt->w = atoi(v);
+		else if (c == 'A') { opt->a = atoi(v); scale_a = 1; }
+		else if (c == 'B') { opt->b = atoi(v); set_b = 1; }
+		else if (c == 'T') { opt->T = atoi(v); set_T = 1; }
+		else if (c == 'U') { opt->pen_unpaired = atoi(v); set_U = 1; }
+		else if (c == 't') n_threads = atoi(v);
+		else if (c == 'c') opt->max_occ = atoi(v);
+		else if (c == 'd') { opt->zdrop = atoi(v); set_d = 1; }
+		else if (c == 'v') bwa_verbose = atoi(v);
+		else if (c == 'r') opt->split_factor = (float)atof(v);
+		else if (c == 'D') opt->drop_ratio = (float)atof(v);
+		else if (c == 'm') opt->max_matesw = atoi(v);
+		else if (c == 's') opt->split_width = atoi(v);
+		else if (c == 'G') opt->max_chain_gap = atoi(v);
+		else if (c == 'N') opt->max_chain_extend = atoi(v);
+		else if (c == 'W') opt->min_chain_weight = atoi(v);
+		else if (c == 'y') opt->max_mem_intv = (uint64_t)atol(v);
+		else if (c == 'K') K = atoll(v);
+		else if (c == 'X') opt->mask_level = (float)atof(v);
+		else if (c == 'h') {
+			opt->max_XA_hits = opt->max_XA_hits_alt = (int)strtol(v, &e, 10);
+			if (*e != 0 && ispunct((unsigned char)*e) && isdigit((unsigned char)e[1])) opt->max_XA_hits_alt = (int)strtol(e + 1, &e, 10);
+		} else if (c == 'Q') {
+			opt->mapQ_coef_len = (float)atoi(v);
+			opt->mapQ_coef_fac = opt->mapQ_coef_len > 0 ? (int)log(opt->mapQ_coef_len) : 0;
+		} else if (c == 'O') {
+			opt->o_del = opt->o_ins = (int)strtol(v, &e, 10); set_O = 1;
+			if (*e != 0 && ispunct((unsigned char)*e) && isdigit((unsigned char)e[1])) opt->o_ins = (int)strtol(e + 1, &e, 10);
+		} else if (c == 'E') {
+			opt->e_del = opt->e_ins = (int)strtol(v, &e, 10); set_E = 1;
+			if (*e != 0 && ispunct((unsigned char)*e) && isdigit((unsigned char)e[1])) opt->e_ins = (int)strtol(e + 1, &e, 10);
+		} else if (c == 'L') {
+			opt->pen_clip5 = opt->pen_clip3 = (int)strtol(v, &e, 10); set_L = 1;
+			if (*e != 0 && ispunct((unsigned char)*e) && isdigit((unsigned char)e[1])) opt->pen_clip3 = (int)strtol(e + 1, &e, 10);
+		} else if (c == 'R') {
+			if ((rg_line = bwa_set_rg(v)) == 0) DIE("malformed read group line %s", v);
+		} else if (c == 'H') {
+			if (v[0] != '@') {   /* a file of header lines */
+				FILE *fp = fopen(v, "r");
+				if (!fp) DIE("cannot read the header file %s", v);
+				char *buf = calloc(1, 0x10000);
+				while (fgets(buf, 0xffff, fp)) {
+					size_t l = strlen(buf);
+					if (l && buf[l - 1] == '\n') buf[l - 1] = 0;
+					hdr_line = bwa_insert_header(buf, hdr_line);
+				}
+				free(buf);
+				fclose(fp);
+			} else hdr_line = bwa_insert_header(v, hdr_line);
+		} else if (c == 'I') {   /* the insert size distribution given by the user (src/mainParallel.c:377-396) */
+			pes0 = pes;
+			pes[0].failed = pes[2].failed = pes[3].failed = 1;
+			pes[1].failed = 0;
+			pes[1].avg = strtod(v, &e);
+			pes[1].std = pes[1].avg * .1;
+			if (*e != 0 && ispunct((unsigned char)*e) && isdigit((unsigned char)e[1])) pes[1].std = strtod(e + 1, &e);
+			pes[1].high = (int)(pes[1].avg + 4. * pes[1].std + .499);
+			pes[1].low = (int)(pes[1].avg - 4. * pes[1].std + .499);
+			if (pes[1].low < 1) pes[1].low = 1;
+			if (*e != 0 && ispunct((unsigned char)*e) && isdigit((unsigned char)e[1])) pes[1].high = (int)(strtod(e + 1, &e) + .499);
+			if (*e != 0 && ispunct((unsigned char)*e) && isdigit((unsigned char)e[1])) pes[1].low = (int)(strtod(e + 1, &e) + .499);
+		} else if (c == 'o') out_path = v;
 	}
+	if (scale_a && opt->a != 1) {   /* -A scales the penalties the user did not set (src/mainParallel.c:430-440) */
+		if (!set_b) opt->b *= opt->a;
+		if (!set_T) opt->T *= opt->a;
+		if (!set_O) { opt->o_del *= opt->a; opt->o_ins *= opt->a; }
+		if (!set_E) { opt->e_del *= opt->a; opt->e_ins *= opt->a; }
+		if (!set_d) opt->zdrop *= opt->a;
+		if (!set_L) { opt->pen_clip5 *= opt->a; opt->pen_clip3 *= opt->a; }
+		if (!set_U) opt->pen_unpaired *= opt->a;
+	}
+	bwa_fill_scmat(opt->a, opt->b, opt->mat);
 	if (n_pos < 2 || (!out_path && !dry)) DIE("need -o OUT PREFIX R1 [R2]");
 	const char *prefix = pos[0];
 	const int paired = n_pos == 3;
-	mem_opt_t *opt = mem_opt_init();
 	if (n_threads > 0) opt->n_threads = n_threads;
 	if (paired) opt->flag |= MEM_F_PE;
 	if (K <= 0) K = (int64_t)opt->chunk_size * opt->n_threads;   /* src/mainParallel.c:635 */
@@ -357,15 +463,22 @@ int main(int argc, char **argv)
 		mi355x_comm_t comm = {local_rank, local_size, bcast_cb, &node};
 		mi355x_init(local_rank, idx, &comm);
 	} else mi355x_init(local_rank % n_dev, idx, 0);
-	bwa_verbose = g_rank == 0 ? 3 : 1;
+	if (ignore_alt)   /* -j (src/parallel_aux.c:1831-1833) */
+		for (int i = 0; i < idx->bns->n_seqs; ++i) idx->bns->anns[i].is_alt = 0;
+	if (g_rank != 0 && bwa_verbose > 1) bwa_verbose = 1;
 
 	/* ---- output: rank 0 writes the header, then everybody appends through the shared file pointer ---- */
 	MPI_File out;
 	if (g_rank == 0) {
 		FILE *fp = fopen(out_path, "w");
 		if (!fp) DIE("cannot create %s", out_path);
+		/* the reference's header (src/parallel_aux.c:1846-1915): @SQ lines, the -H lines, the read group, the program line */
 		for (int i = 0; i < idx->bns->n_seqs; ++i) fprintf(fp, "@SQ\tSN:%s\tLN:%d\n", idx->bns->anns[i].name, idx->bns->anns[i].len);
-		fprintf(fp, "@PG\tID:mpibwa_gpu\tPN:mpibwa_gpu\tVN:r2\n");
+		if (hdr_line) fprintf(fp, "%s\n", hdr_line);
+		if (rg_line) fprintf(fp, "%s\n", rg_line);
+		fprintf(fp, "@PG\tID:mpibwa_gpu\tPN:mpibwa_gpu\tVN:r3\tCL:%s", argv[0]);
+		for (int i = 1; i < argc; ++i) fprintf(fp, " %s", argv[i]);
+		fputc('\n', fp);
 		fclose(fp);
 	}
 	MPI_Barrier(MPI_COMM_WORLD);
@@ -384,7 +497,7 @@ int main(int argc, char **argv)
 	loop_t L;
 	memset(&L, 0, sizeof L);
 	L.opt = opt; L.idx = idx; L.win = win; L.out = out; L.f1 = f1.fh; L.f2 = paired ? f2.fh : MPI_FILE_NULL;
-	L.tab = tab_all; L.n_chunks = n_chunks; L.paired = paired; L.lockstep = lockstep; L.trimmed = trimmed; L.copy_comment = copy_comment;
+	L.tab = tab_all; L.n_chunks = n_chunks; L.paired = paired; L.lockstep = lockstep; L.trimmed = trimmed; L.copy_comment = copy_comment; L.pes0 = pes0;
 	L.serialize = provided < MPI_THREAD_MULTIPLE;
 	L.t_start = t_loop;
 	pthread_mutex_init(&L.mpi_mu, 0);

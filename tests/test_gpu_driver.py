@@ -68,3 +68,34 @@ def test_driver_reproduces_the_mpibwa_binary_and_is_rank_count_independent(examp
     out = os.path.join(d, "se.sam")
     _run(2, ["-K", "400000", "-o", out, prefix, fq[0]], d)
     assert sorted(_body(out)) == sorted(se.splitlines(keepends=True))
+
+
+@pytest.mark.skipif(mpiexec() is None or not os.path.exists(EXE), reason="mpibwa_gpu or mpiexec not present")
+def test_driver_takes_the_reference_mem_options(example):
+    """-R / -M / -T / -k / -H through the driver's own option parser (the reference's letters, src/mainParallel.c:311-398), three
+    chunks in flight: same records as the single-process loop with the same mem_opt_t and read group; the header carries the
+    @SQ lines, the -H line, the read group and a @PG line."""
+    import ctypes as C
+    from mpibwa_amd import abi, api, fastq
+    d, prefix, fq = example
+    lib = api.load_library()
+    lib.mi355x_finalize()
+    lib.bwa_set_rg.restype = C.c_void_p
+    lib.bwa_set_rg.argtypes = [C.c_char_p]
+    eng = api.Engine(prefix, device=0)
+    try:
+        p = lib.bwa_set_rg(b"@RG\\tID:lane7\\tSM:s1")
+        assert p
+        api.libc.free(C.c_void_p(p))
+        want, counts = fastq.align_files(eng, eng.opt(flag=abi.MEM_F_PE | abi.MEM_F_NO_MULTI, T=20, min_seed_len=17), fq[0], fq[1], K=1_000_000)
+    finally:
+        C.memset((C.c_char * 256).in_dll(lib, "bwa_rg_id"), 0, 256)
+    lib.mi355x_finalize()
+    out = os.path.join(d, "opts.sam")
+    _run(2, ["-K", "1000000", "-M", "-T", "20", "-k", "17", "-R", "@RG\\tID:lane7\\tSM:s1", "-H", "@CO\tmade by the test", "--in-flight", "3", "-o", out,
+             prefix] + fq, d)
+    assert sorted(_body(out)) == sorted(want.splitlines(keepends=True))
+    head = [ln for ln in open(out, "rb").read().splitlines() if ln.startswith(b"@")]
+    assert head[0].startswith(b"@SQ\tSN:") and b"@CO\tmade by the test" in head and b"@RG\tID:lane7\tSM:s1" in head
+    assert head[-1].startswith(b"@PG\tID:mpibwa_gpu")
+    assert all(b"\tRG:Z:lane7" in ln for ln in _body(out))

@@ -47,7 +47,7 @@ env = dict(os.environ); env.pop("LD_LIBRARY_PATH", None); env["MPIBWA_DRV_PROF"]
 for P in [int(x) for x in os.environ.get("E2E_P", "1,4,8").split(",")]:
     o = os.path.join(wd, "e2e_drv.sam")
     t0 = time.time()
-    r = subprocess.run([mpiexec(), "-n", "1", EXE, "mem", "-t", str(cores), "-K", "100000000", "-P", str(P), "-o", o, idx.prefix, r1, r2],
+    r = subprocess.run([mpiexec(), "-n", "1", EXE, "mem", "-t", str(cores), "-K", "100000000", "--in-flight", str(P), "-o", o, idx.prefix, r1, r2],
                        capture_output=True, text=True, env=env, timeout=1500)
     wall = time.time() - t0
     m = re.search(r"chunk loop: (\d+) reads in (\d+) chunks.* ([\d.]+) s = ([\d.]+) Mreads/s", r.stderr)
