@@ -42,6 +42,11 @@ class HRegV {
 	HReg *p_ = nullptr;
 	uint32_t n_ = 0, cap_ = 0;
 	bool own_ = false;
+public:
+	// true while the list is a fixed point of sort_dedup_patch without patching (set by it; cleared by whoever adds a hit):
+	// another such pass would return the list as it is
+	bool settled = false;
+private:
 	void grow(uint32_t want)
 	{
 		uint32_t nc = cap_ ? cap_ * 2 : 4;
@@ -56,10 +61,10 @@ public:
 	~HRegV() { if (own_) free(p_); }
 	HRegV(const HRegV &) = delete;
 	HRegV &operator=(const HRegV &) = delete;
-	HRegV(HRegV &&o) noexcept : p_(o.p_), n_(o.n_), cap_(o.cap_), own_(o.own_) { o.p_ = nullptr; o.n_ = o.cap_ = 0; o.own_ = false; }
+	HRegV(HRegV &&o) noexcept : p_(o.p_), n_(o.n_), cap_(o.cap_), own_(o.own_), settled(o.settled) { o.p_ = nullptr; o.n_ = o.cap_ = 0; o.own_ = false; o.settled = false; }
 	HRegV &operator=(HRegV &&o) noexcept { swap(o); return *this; }
-	void attach(HReg *ext, uint32_t cap) { if (own_) free(p_); p_ = ext; n_ = 0; cap_ = cap; own_ = false; }
-	void swap(HRegV &o) { std::swap(p_, o.p_); std::swap(n_, o.n_); std::swap(cap_, o.cap_); std::swap(own_, o.own_); }
+	void attach(HReg *ext, uint32_t cap) { if (own_) free(p_); p_ = ext; n_ = 0; cap_ = cap; own_ = false; settled = false; }
+	void swap(HRegV &o) { std::swap(p_, o.p_); std::swap(n_, o.n_); std::swap(cap_, o.cap_); std::swap(own_, o.own_); std::swap(settled, o.settled); }
 	size_t size() const { return n_; }
 	bool empty() const { return n_ == 0; }
 	HReg *data() { return p_; }

@@ -276,10 +276,16 @@ static int matesw(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac,
 				size_t at = 0;
 				while (at < ma.size() && !(ma[at].score < b.score)) ++at;
 				ma.insert(ma.begin() + at, b);
+				ma.settled = false;
 			}
 			++n;
 		}
-		if (n) sort_dedup_patch(opt, 0, 0, 0, ma);
+		// The reference re-runs mem_sort_dedup_patch(opt, 0, 0, 0, ...) after every orientation once an alignment has been
+		// attempted (src/bwamem_pair.c:176).  On a list that is already a fixed point of that pass — every pair of survivors was
+		// compared while both were alive, nothing is patched without the reference (bns = 0), the final order is total on
+		// (score, rb, qb) — the call returns the list as it is: it is only made when a hit was added since the last pass (or
+		// phase 1 merged two hits, HRegV::settled).
+		if (n && !ma.settled) sort_dedup_patch(opt, 0, 0, 0, ma);
 	}
 	return n;
 }

@@ -55,6 +55,7 @@ static int patch_reg(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *p
 int sort_dedup_patch(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, uint8_t *query, HRegV &v)
 {
 	int n = (int)v.size();
+	v.settled = true;    // (unless two hits are merged below: the merged hit has not been compared with its new neighbours)
 	if (n <= 1) return n;
 	HProf hp_(HP_DEDUP);
 	HReg *a = v.data();
@@ -83,6 +84,7 @@ int sort_dedup_patch(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *p
 				p->truesc = p->score = score;
 				p->w = w;
 				q->qb = q->qe;
+				v.settled = false;
 			}
 		}
 	}

@@ -37,6 +37,10 @@
 #include <stdint.h>
 #include <pthread.h>
 #include <ctype.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <math.h>
 #include "mpibwa_amd.h"
 
@@ -451,7 +455,28 @@ int main(int argc, char **argv)
 	}
 
 	/* ---- index: host copy from the bwa files, device copy through mi355x_init ---- */
-	bwaidx_t *idx = bwa_idx_load_from_disk(prefix, 7);
+	/* PREFIX.map present (mpiBWAIdx / mi355x_write_map): the ranks of a node share ONE host copy of the index — a private
+	 * file mapping whose bulk (BWT, SA, pac: read-only) stays in the page cache; only the pages bwa_mem2idx writes pointers
+	 * into become private (the reference maps the image into an MPI shared window, src/parallel_aux.c:1745-1838).
+	 * Otherwise every rank reads the five bwa files. */
+	bwaidx_t *idx = 0, idx_map;
+	{
+		char *mp = malloc(strlen(prefix) + 8);
+		sprintf(mp, "%s.map", prefix);
+		int fd = open(mp, O_RDONLY);
+		if (fd >= 0) {
+			struct stat sb;
+			if (fstat(fd, &sb) != 0) DIE("cannot stat %s", mp);
+			void *img = mmap(0, (size_t)sb.st_size, PROT_READ | PROT_WRITE, MAP_PRIVATE, fd, 0);
+			if (img == MAP_FAILED) DIE("cannot map %s", mp);
+			close(fd);
+			memset(&idx_map, 0, sizeof idx_map);
+			if (bwa_mem2idx((int64_t)sb.st_size, (uint8_t *)img, &idx_map) != 0) DIE("%s is not an index image", mp);
+			idx = &idx_map;
+			if (g_rank == 0) fprintf(stderr, "[mpibwa_gpu] index attached from %s (%.2f GB, shared by the ranks of a node)\n", mp, sb.st_size / 1e9);
+		} else idx = bwa_idx_load_from_disk(prefix, 7);
+		free(mp);
+	}
 	if (!idx) DIE("cannot load the index %s", prefix);
 	MPI_Comm node;
 	MPI_OK(MPI_Comm_split_type(MPI_COMM_WORLD, MPI_COMM_TYPE_SHARED, g_rank, MPI_INFO_NULL, &node));

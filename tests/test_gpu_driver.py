@@ -99,3 +99,12 @@ def test_driver_takes_the_reference_mem_options(example):
     assert head[0].startswith(b"@SQ\tSN:") and b"@CO\tmade by the test" in head and b"@RG\tID:lane7\tSM:s1" in head
     assert head[-1].startswith(b"@PG\tID:mpibwa_gpu")
     assert all(b"\tRG:Z:lane7" in ln for ln in _body(out))
+    # with PREFIX.map next to the index the ranks attach that image (one host copy per node) instead of the five files
+    assert lib.mi355x_write_map(prefix.encode(), (prefix + ".map").encode()) == 0
+    out2 = os.path.join(d, "opts_map.sam")
+    env = dict(os.environ); env.pop("LD_LIBRARY_PATH", None)
+    r = subprocess.run([mpiexec(), "-n", "2", EXE, "mem", "-K", "1000000", "-M", "-T", "20", "-k", "17", "-R", "@RG\\tID:lane7\\tSM:s1", "-o", out2, prefix] + fq,
+                       capture_output=True, text=True, timeout=900, env=env, cwd=d)
+    os.remove(prefix + ".map")
+    assert r.returncode == 0 and "index attached from" in r.stderr, r.stderr[-2000:]
+    assert sorted(_body(out2)) == sorted(want.splitlines(keepends=True))
