@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc_kernels
 rm -rf $OUT; mkdir -p $OUT
-for k in smem_kernel smem_p3_kernel c2a_kernel msw_kernel aln_kernel; do
+for k in smem_kernel smem_p3_kernel c2a_kernel msw_kernel aln_kernel pair_simple_kernel; do
   i=0
   for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU"; do
     i=$((i+1))
