@@ -114,7 +114,7 @@ def main():
                    for c in range(n_chunks)]
     import hashlib
     import threading
-    n_fly = max(1, min(args.in_flight, 8))
+    n_fly = max(1, min(args.in_flight, 12))
     # every caller thread owns a bseq1_t[] (and its .sam) per chunk
     batches = [[abi.SeqBatch(api.libc, chunk_reads[c]) for c in range(n_chunks)] for _ in range(n_fly)]
     cores = int(lib.mi355x_host_cpus())

@@ -349,7 +349,7 @@ struct CallCtx {
 	bool busy = false;
 	const bseq1_t *seq_lo = nullptr, *seq_hi = nullptr;   // the caller's array while the call runs
 };
-static const int MAX_CALLS = 8;
+static const int MAX_CALLS = 12;
 static CallCtx g_ctx[MAX_CALLS];
 static std::mutex g_ctx_mu;
 static std::recursive_mutex g_init_mu;

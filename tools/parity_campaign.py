@@ -26,12 +26,16 @@ for c in range(cases):
     indel = float(rng.choice([0.0002, 0.001, 0.004]))
     fm = float(rng.uniform(2.0, 3.5)) * L
     kw = dict(flag=abi.MEM_F_PE)
-    pick = int(rng.integers(0, 6))
+    pick = int(rng.integers(0, 10))
     if pick == 1: kw.update(T=int(rng.integers(20, 60)))
     if pick == 2: kw.update(flag=abi.MEM_F_PE | abi.MEM_F_NO_RESCUE)
     if pick == 3: kw.update(max_matesw=int(rng.integers(5, 100)), w=int(rng.integers(40, 160)))
     if pick == 4: kw.update(flag=abi.MEM_F_PE | abi.MEM_F_ALL)
     if pick == 5: kw.update(flag=abi.MEM_F_PE | abi.MEM_F_SOFTCLIP | abi.MEM_F_NO_MULTI, pen_unpaired=int(rng.integers(5, 30)))
+    if pick == 6: kw.update(o_del=int(rng.integers(3, 9)), e_del=int(rng.integers(1, 3)), o_ins=int(rng.integers(3, 9)), e_ins=int(rng.integers(1, 3)), pen_clip5=int(rng.integers(0, 8)))
+    if pick == 7: kw.update(XA_drop_ratio=float(rng.choice([0.5, 0.9])), mask_level=float(rng.choice([0.3, 0.7])), min_seed_len=int(rng.integers(15, 24)))
+    if pick == 8: kw.update(flag=abi.MEM_F_PE | abi.MEM_F_PRIMARY5 | abi.MEM_F_KEEP_SUPP_MAPQ, drop_ratio=float(rng.choice([0.3, 0.6])))
+    if pick == 9: kw.update(mapQ_coef_len=float(rng.choice([0, 30, 80])), max_XA_hits=int(rng.integers(1, 8)))
     reads = idx.simulate_pairs(pairs, seed=7000 + c, read_len=L, frag_mean=fm, frag_sd=fm / 8, sub=sub, indel=indel,
                                frac_random=float(rng.choice([0.0, 0.02, 0.1])))
     shape = int(rng.integers(0, 4))
