@@ -915,7 +915,9 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	// Sub-batches overlap the GPU and host stages of ONE call.  When enough other calls are in flight they provide that
 	// overlap, and one launch per kernel over the whole chunk is cheaper than three (one tail instead of three: the SMEM
 	// kernel needs 23 ms for the chunk in one launch, 3 x 10 ms in three).
-	int n_sub = lease.others >= 2 ? 1 : 3, n_lanes = 3;
+	// (two sub-batches since round 3: with the pairing decisions on the device the host stages of a sub-batch are short, and a
+	// third sub-batch only adds a third tail to every big kernel: 93.5 vs 103-105 ms per chunk with one call in flight)
+	int n_sub = lease.others >= 2 ? 1 : 2, n_lanes = 2;
 	if (const char *e = getenv("MPIBWA_SUBBATCH")) n_sub = atoi(e);
 	if (const char *e = getenv("MPIBWA_LANES")) n_lanes = atoi(e);
 	n_sub = std::max(1, std::min(n_sub, 16));
