@@ -336,6 +336,9 @@ struct Workspace {
 	// pairs decided on the device (pair_kernel.hip): first region / region count per read, flags, tables, requests, descriptors
 	DevBuf pr_first, pr_nfirst, pr_ok, pr_status, pr_ptab, pr_ltab, pr_req, pr_desc;
 	PinBuf h_pr_ok, h_pr_status, h_pr_tab;
+	// ... and their CIGAR / SAM-text job per part, launched right behind the pairing kernel
+	DevBuf dj_hdr[2], dj_pool[2], dj_cnt[2], dj_list[2], dj_base[2], dj_arena[2], dj_used[2], dj_ooff[2], dj_olen[2];
+	PinBuf hj_hdr[2], hj_pool[2], hj_arena[2], hj_ooff[2], hj_olen[2], hj_base[2];
 };
 static const int MAX_LANES = 4;
 // Everything one mem_process_seqs() call owns between its first and last line.  Eight of them: eight caller threads may be inside
@@ -345,7 +348,7 @@ struct CallCtx {
 	Workspace ws[MAX_LANES];   // one per concurrent sub-batch
 	HostBuf reg_arena[16];     // one per sub-batch: the regions live until the SAM stage
 	Workspace gws;             // batch-wide buffers (packed reads, CIGAR requests)
-	hipStream_t p_streams[MAX_LANES] = {nullptr}, a_streams[2] = {nullptr, nullptr};
+	hipStream_t p_streams[MAX_LANES] = {nullptr}, a_streams[2] = {nullptr, nullptr}, d_streams[2] = {nullptr, nullptr};
 	bool busy = false;
 	const bseq1_t *seq_lo = nullptr, *seq_hi = nullptr;   // the caller's array while the call runs
 };
@@ -493,6 +496,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		const int pp = pe && *pe == 'p' ? hi_p : 0, pa = !pe || *pe == 'a' ? hi_p : 0;
 		for (int l = 0; l < MAX_LANES; ++l) HIP_OK(hipStreamCreateWithPriority(&C.p_streams[l], hipStreamNonBlocking, pp));
 		for (int l = 0; l < 2; ++l) HIP_OK(hipStreamCreateWithPriority(&C.a_streams[l], hipStreamNonBlocking, pa));
+		for (int l = 0; l < 2; ++l) HIP_OK(hipStreamCreateWithPriority(&C.d_streams[l], hipStreamNonBlocking, pa));
 	}
 	hipStream_t st = C.p_streams[0];   // never the null stream: another call may be in flight
 	Workspace &W = C.gws;
@@ -988,7 +992,16 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		AlnHdrH *hdr = nullptr;           // results, in page-locked staging buffers
 		uint8_t *pool = nullptr;
 		int slot = 0;
-		size_t off2 = 0;                  // request slots of the pairs decided on the device, in front of `req`
+		// the pairs decided on the device: their two CIGAR requests each (pair_kernel's array, in place) and their records
+		struct DevJob {
+			bool launched = false;
+			hipStream_t st = 0;
+			size_t n_req = 0, pool_bytes = 0, arena_bytes = 0;
+			AlnHdr *d_hdr = nullptr; uint8_t *d_pool = nullptr; unsigned long long *d_cnt = nullptr;
+			EvTimer ev;
+			const AlnHdrH *hdr = nullptr; const uint8_t *pool = nullptr;   // host copies: only fetched when the device hands a record back
+			const uint8_t *sarena = nullptr; const unsigned long long *sooff = nullptr; const int *solen = nullptr;
+		} dj;
 		unsigned long long cnt[8] = {0};
 		// mate-rescue alignments of the part: requests of unit k are mreq[mbase[k] .. mbase[k+1])
 		MswReqH *mreq = nullptr; MswResH *mres = nullptr;
@@ -1139,7 +1152,6 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		}
 		pair_dev_ms = now_ms() - tp0;
 	}
-	const size_t dev_slots = pstat ? 2 : 0;   // request slots per unit in front of the host's requests of a part
 
 	// mate rescue on the device: list the local alignments the pairs of a part will ask for, run them in one launch
 	static_assert(sizeof(MswReq) == sizeof(MswReqH) && sizeof(MswRes) == sizeof(MswResH), "host/device record layouts differ");
@@ -1261,11 +1273,84 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		plan_ms += now_ms() - ta;
 		cpu_collect += cpu_sec() - ca;
 	};
+	// The pairs decided on the device need nothing from the host any more: their CIGARs and records are queued right behind the
+	// pairing kernel, on a stream of their own, and run under the host's rescue listing, planning and the mate-rescue kernel.
+	auto launch_dev = [&](Part &P, int slot) {
+		if (!pstat) return;
+		Part::DevJob &J = P.dj;
+		const int nu = P.hi - P.lo, r0 = P.lo << 1, nr = nu << 1;
+		J.n_req = (size_t)nr;
+		if (!J.n_req) return;
+		J.st = C.d_streams[slot];
+		J.pool_bytes = J.n_req * 96 + ((size_t)48 << 20);
+		J.d_hdr = (AlnHdr *)W.dj_hdr[slot].ensure(J.n_req * sizeof(AlnHdr));
+		J.d_pool = (uint8_t *)W.dj_pool[slot].ensure(J.pool_bytes);
+		J.d_cnt = (unsigned long long *)W.dj_cnt[slot].ensure(256);
+		HIP_OK(hipMemsetAsync(J.d_cnt, 0, 256, J.st));
+		AlnParams ap;
+		ap.l_pac = bns->l_pac; ap.a = opt->a; ap.w = opt->w;
+		ExtParams ep;
+		memcpy(ep.mat, opt->mat, 25);
+		ep.o_del = opt->o_del; ep.e_del = opt->e_del; ep.o_ins = opt->o_ins; ep.e_ins = opt->e_ins; ep.zdrop = opt->zdrop;
+		int *d_lists = (int *)W.dj_list[slot].ensure(J.n_req * 3 * sizeof(int));
+		J.ev.start(J.st);
+		launch_aln(J.st, ap, ep, (int)J.n_req, d_pr_req + r0, d_seq, d_off, (const uint8_t *)ix.d_pac, d_gap, J.d_hdr, J.d_pool, J.d_cnt, J.pool_bytes, max_len,
+		           max_len + 256, d_lists);
+		J.ev.stop(J.st);
+		int *hb = (int *)W.hj_base[slot].ensure((size_t)(nu + 1) * 4 + 64);
+		for (int k = 0; k <= nu; ++k) hb[k] = 2 * k;
+		int *d_base = (int *)W.dj_base[slot].ensure((size_t)(nu + 1) * 4);
+		J.arena_bytes = (size_t)nr * (size_t)(2 * max_len + 320) + (1 << 20);
+		uint8_t *d_arena = (uint8_t *)W.dj_arena[slot].ensure(J.arena_bytes);
+		unsigned long long *d_used = (unsigned long long *)W.dj_used[slot].ensure(64);
+		unsigned long long *d_ooff = (unsigned long long *)W.dj_ooff[slot].ensure((size_t)nr * 8);
+		int *d_olen = (int *)W.dj_olen[slot].ensure((size_t)nr * 4);
+		HIP_OK(hipMemcpyAsync(d_base, hb, (size_t)(nu + 1) * 4, hipMemcpyHostToDevice, J.st));
+		HIP_OK(hipMemsetAsync(d_used, 0, 64, J.st));
+		launch_sam_emit(J.st, sam_par, nr, d_pr_desc + r0, d_base, J.d_hdr, J.d_pool, d_seq, d_off + r0, d_len + r0, d_qual, d_names, d_noff + r0, d_ann_off,
+		                d_ann_names, d_ann_noff, d_arena, J.arena_bytes, d_used, d_ooff, d_olen);
+		J.launched = true;
+	};
+	auto finish_dev = [&](Part &P, int slot) {
+		Part::DevJob &J = P.dj;
+		if (!J.launched) return;
+		double ta = now_ms();
+		const int nr = (P.hi - P.lo) << 1;
+		stream_wait(J.st);
+		HIP_OK(hipGetLastError());
+		STAT.k_aln_ms += J.ev.ms();
+		STAT.n_aln += J.n_req;
+		unsigned long long used = 0;
+		HIP_OK(hipMemcpyAsync(&used, W.dj_used[slot].p, 8, hipMemcpyDeviceToHost, J.st));
+		HIP_OK(hipStreamSynchronize(J.st));
+		used = std::min<unsigned long long>(used, J.arena_bytes);
+		uint8_t *ha = (uint8_t *)W.hj_arena[slot].ensure((size_t)used + 64);
+		unsigned long long *ho = (unsigned long long *)W.hj_ooff[slot].ensure((size_t)nr * 8 + 64);
+		int *hl = (int *)W.hj_olen[slot].ensure((size_t)nr * 4 + 64);
+		if (used) HIP_OK(hipMemcpyAsync(ha, W.dj_arena[slot].p, (size_t)used, hipMemcpyDeviceToHost, J.st));
+		HIP_OK(hipMemcpyAsync(ho, W.dj_ooff[slot].p, (size_t)nr * 8, hipMemcpyDeviceToHost, J.st));
+		HIP_OK(hipMemcpyAsync(hl, W.dj_olen[slot].p, (size_t)nr * 4, hipMemcpyDeviceToHost, J.st));
+		HIP_OK(hipStreamSynchronize(J.st));
+		J.sarena = ha; J.sooff = ho; J.solen = hl;
+		// a record handed back (CIGAR declined, row overflow): the host redoes that pair and needs the CIGAR results of the job
+		bool any_back = false;
+		for (int k = 0; k < (P.hi - P.lo) && !any_back; ++k)
+			if (pstat[P.lo + k] == 1 && (hl[2 * k] < 0 || hl[2 * k + 1] < 0)) any_back = true;
+		if (any_back) {
+			unsigned long long cnt8[8];
+			HIP_OK(hipMemcpy(cnt8, J.d_cnt, sizeof cnt8, hipMemcpyDeviceToHost));
+			const size_t pu = std::min<size_t>(cnt8[0], J.pool_bytes);
+			AlnHdrH *hh = (AlnHdrH *)W.hj_hdr[slot].ensure(J.n_req * sizeof(AlnHdr) + 64);
+			uint8_t *hp = (uint8_t *)W.hj_pool[slot].ensure(pu + 64);
+			HIP_OK(hipMemcpy(hh, J.d_hdr, J.n_req * sizeof(AlnHdr), hipMemcpyDeviceToHost));
+			if (pu) HIP_OK(hipMemcpy(hp, J.d_pool, pu, hipMemcpyDeviceToHost));
+			J.hdr = hh; J.pool = hp;
+		}
+		aln_wait_ms += now_ms() - ta;
+	};
 	auto launch = [&](Part &P, int slot) {   // B (asynchronous)
-		const size_t n_host_req = P.req.size();
-		const size_t off2 = dev_slots * (size_t)(P.hi - P.lo);   // the slots of the pairs decided on the device come first
-		const size_t n_req = off2 + n_host_req;
-		P.slot = slot; P.off2 = off2;
+		const size_t n_req = P.req.size();
+		P.slot = slot;
 		if (!gpu_aln || n_req == 0) return;
 		static_assert(sizeof(AlnReq) == sizeof(AlnReqH) && sizeof(AlnHdr) == sizeof(AlnHdrH), "host/device record layouts differ");
 		P.st = a_streams[slot];
@@ -1274,8 +1359,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		P.d_hdr = (AlnHdr *)(slot ? W.ahdr2 : W.ahdr).ensure(n_req * sizeof(AlnHdr));
 		P.d_pool = (uint8_t *)(slot ? W.apool2 : W.apool).ensure(P.pool_bytes);
 		P.d_cnt = (unsigned long long *)(slot ? W.acnt2 : W.acnt).ensure(256);
-		if (off2) HIP_OK(hipMemcpyAsync(d_req, d_pr_req + 2 * (size_t)P.lo, off2 * sizeof(AlnReq), hipMemcpyDeviceToDevice, P.st));
-		if (n_host_req) HIP_OK(hipMemcpyAsync(d_req + off2, P.req.data(), n_host_req * sizeof(AlnReq), hipMemcpyHostToDevice, P.st));
+		HIP_OK(hipMemcpyAsync(d_req, P.req.data(), n_req * sizeof(AlnReq), hipMemcpyHostToDevice, P.st));
 		HIP_OK(hipMemsetAsync(P.d_cnt, 0, 256, P.st));
 		AlnParams ap;
 		ap.l_pac = bns->l_pac; ap.a = opt->a; ap.w = opt->w;
@@ -1291,7 +1375,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			const int r0 = P.lo << 1, nr = (P.hi - P.lo) << 1, nu = P.hi - P.lo;
 			SamDesc *d_desc = (SamDesc *)W.sdesc.ensure((size_t)n * sizeof(SamDesc));
 			int *hb = (int *)W.h_sbase[slot].ensure((size_t)(nu + 1) * 4 + 64);
-			for (int k = 0; k <= nu; ++k) hb[k] = (k < nu && pstat && pstat[P.lo + k] == 1) ? 2 * k : (int)(off2 + P.base[k]);
+			for (int k = 0; k <= nu; ++k) hb[k] = (int)P.base[k];
 			int *d_base = (int *)W.sbase[slot].ensure((size_t)(nu + 1) * 4);
 			P.arena_bytes = (size_t)nr * (size_t)(2 * max_len + 320) + (1 << 20);
 			uint8_t *d_arena = (uint8_t *)W.sarena[slot].ensure(P.arena_bytes);
@@ -1299,7 +1383,6 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			unsigned long long *d_ooff = (unsigned long long *)W.sooff[slot].ensure((size_t)nr * 8);
 			int *d_olen = (int *)W.solen[slot].ensure((size_t)nr * 4);
 			HIP_OK(hipMemcpyAsync(d_desc + r0, sdesc + r0, (size_t)nr * sizeof(SamDesc), hipMemcpyHostToDevice, P.st));
-			if (pstat) launch_desc_overlay(P.st, nu, d_pstat + P.lo, d_pr_desc + r0, d_desc + r0);
 			HIP_OK(hipMemcpyAsync(d_base, hb, (size_t)(nu + 1) * 4, hipMemcpyHostToDevice, P.st));
 			HIP_OK(hipMemsetAsync(d_used, 0, 64, P.st));
 			launch_sam_emit(P.st, sam_par, nr, d_desc + r0, d_base, P.d_hdr, P.d_pool, d_seq, d_off + r0, d_len + r0, d_qual, d_names, d_noff + r0,
@@ -1308,7 +1391,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		}
 	};
 	auto finish = [&](Part &P) {   // wait for B, fetch the pool
-		const size_t n_req = P.off2 + P.req.size();
+		const size_t n_req = P.req.size();
 		if (!gpu_aln || n_req == 0) return;
 		double ta = now_ms();
 		stream_wait(P.st);
@@ -1356,13 +1439,17 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 				unsigned long long n_dev = 0, tsc = 0;
 				for (int k = k_lo; k < k_hi; ++k) {
 					const int i = P.lo + k;
-					if (P.solen && P.solen[2 * k] >= 0 && P.solen[2 * k + 1] >= 0) {   // both records were written by sam_kernel
+					const bool dev_pair_k = pstat && pstat[i] == 1;
+					const int *solen = dev_pair_k ? P.dj.solen : P.solen;
+					const unsigned long long *sooff = dev_pair_k ? P.dj.sooff : P.sooff;
+					const uint8_t *sarena = dev_pair_k ? P.dj.sarena : P.sarena;
+					if (solen && solen[2 * k] >= 0 && solen[2 * k + 1] >= 0) {   // both records were written by sam_kernel
 						const unsigned long long tq0 = s_cpusec ? __builtin_ia32_rdtsc() : 0;
 						for (int e = 0; e < 2; ++e) {
-							const int len = P.solen[2 * k + e];
+							const int len = solen[2 * k + e];
 							char *sam = (char *)malloc((size_t)len + 1);   // ownership passes to the caller, who free()s it
 							if (!sam) die("out of memory");
-							memcpy(sam, P.sarena + P.sooff[2 * k + e], (size_t)len);
+							memcpy(sam, sarena + sooff[2 * k + e], (size_t)len);
 							sam[len] = 0;
 							seqs[(i << 1) + e].sam = sam;
 						}
@@ -1371,10 +1458,10 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 						continue;
 					}
 					AlnCtx ctx;
-					if (gpu_aln) { ctx.mode = AlnCtx::REPLAY; ctx.hdr = P.hdr; ctx.pool = P.pool; ctx.cursor = P.off2 + P.base[k]; }
-					if (pstat && pstat[i] == 1) {   // the device decided the pair but handed a record back: the host decides it again (same two requests, same order)
+					if (gpu_aln) { ctx.mode = AlnCtx::REPLAY; ctx.hdr = P.hdr; ctx.pool = P.pool; ctx.cursor = P.base[k]; }
+					if (dev_pair_k) {   // the device decided the pair but handed a record back: the host decides it again (same two requests, same order)
 						sam_pe_plan(opt, bns, pac, pes, (uint64_t)((n_processed >> 1) + i), &seqs[i << 1], &regs[i << 1], plans[i], nullptr, i << 1);
-						ctx.cursor = 2 * (size_t)k;
+						ctx.hdr = P.dj.hdr; ctx.pool = P.dj.pool; ctx.cursor = 2 * (size_t)k;
 					}
 					sam_pe_emit(opt, bns, pac, pes, &seqs[i << 1], &regs[i << 1], plans[i], gpu_aln ? &ctx : nullptr, i << 1);
 				}
@@ -1392,21 +1479,29 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		cpu_emit += cpu_sec() - ca;
 		sys_emit += sys_sec() - sa_; pf_emit += page_faults() - pf;
 	};
+	const bool dev_late = getenv("MPIBWA_DEV_JOB_LATE") != nullptr;   // A/B: the device pairs' job next to the host pairs' instead of right away
 	if (n_parts == 1) {
 		parts[0].lo = 0; parts[0].hi = n_units;
+		if (!dev_late) launch_dev(parts[0], 0);
 		mcollect(parts[0], 0); mlaunch(parts[0], 0);
 		collect(parts[0], 0); mfinish(parts[0]); collect(parts[0], 1);
-		launch(parts[0], 0); finish(parts[0]);
+		if (dev_late) launch_dev(parts[0], 0);
+		launch(parts[0], 0); finish(parts[0]); finish_dev(parts[0], 0);
 		hprof_report("decisions + request lists");
 		replay(parts[0]);
 	} else {
 		parts[0].lo = 0; parts[0].hi = n_units / 2; parts[1].lo = n_units / 2; parts[1].hi = n_units;
+		if (!dev_late) { launch_dev(parts[0], 0); launch_dev(parts[1], 1); }
 		mcollect(parts[0], 0); mlaunch(parts[0], 0);
 		mcollect(parts[1], 1); mlaunch(parts[1], 1);
-		collect(parts[0], 0); mfinish(parts[0]); collect(parts[0], 1); launch(parts[0], 0);
-		collect(parts[1], 0); mfinish(parts[1]); collect(parts[1], 1); launch(parts[1], 1);
-		finish(parts[0]); replay(parts[0]);
-		finish(parts[1]); replay(parts[1]);
+		collect(parts[0], 0); mfinish(parts[0]); collect(parts[0], 1);
+		if (dev_late) launch_dev(parts[0], 0);
+		launch(parts[0], 0);
+		collect(parts[1], 0); mfinish(parts[1]); collect(parts[1], 1);
+		if (dev_late) launch_dev(parts[1], 1);
+		launch(parts[1], 1);
+		finish(parts[0]); finish_dev(parts[0], 0); replay(parts[0]);
+		finish(parts[1]); finish_dev(parts[1], 1); replay(parts[1]);
 	}
 	STAT.plan_ms = plan_ms; STAT.aln_ms = aln_wait_ms; STAT.msw_ms = msw_ms; STAT.emit_ms = emit_ms;
 	STAT.n_sam_dev = n_sam_dev.load();
