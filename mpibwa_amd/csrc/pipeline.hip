@@ -1430,7 +1430,9 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	};
 	double emit_ms = 0;
 	std::atomic<unsigned long long> n_sam_dev(0), tsc_devcopy(0);
-	auto replay = [&](Part &P) {   // C
+	// which: 0 = the records of the pairs decided on the device (as soon as their job is back: the copies run under the kernels
+	// of the other pairs), 1 = everything else, 2 = both
+	auto replay = [&](Part &P, int which = 2) {   // C
 		const double ta = now_ms(), ca = cpu_sec(), sa_ = sys_sec();
 		const long pf = page_faults();
 		if (pe) {
@@ -1443,6 +1445,8 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 					const int *solen = dev_pair_k ? P.dj.solen : P.solen;
 					const unsigned long long *sooff = dev_pair_k ? P.dj.sooff : P.sooff;
 					const uint8_t *sarena = dev_pair_k ? P.dj.sarena : P.sarena;
+					const bool early = dev_pair_k && solen && solen[2 * k] >= 0 && solen[2 * k + 1] >= 0;   // pass 0's pairs
+					if (which != 2 && early != (which == 0)) continue;
 					if (solen && solen[2 * k] >= 0 && solen[2 * k + 1] >= 0) {   // both records were written by sam_kernel
 						const unsigned long long tq0 = s_cpusec ? __builtin_ia32_rdtsc() : 0;
 						for (int e = 0; e < 2; ++e) {
@@ -1467,7 +1471,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 				}
 				n_sam_dev += n_dev; tsc_devcopy += tsc;
 			});
-		} else {
+		} else if (which != 0) {
 			parallel_for(n_thr, P.hi - P.lo, 256, [&](int k) {
 				const int i = P.lo + k;
 				AlnCtx ctx;
@@ -1479,29 +1483,42 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		cpu_emit += cpu_sec() - ca;
 		sys_emit += sys_sec() - sa_; pf_emit += page_faults() - pf;
 	};
-	const bool dev_late = getenv("MPIBWA_DEV_JOB_LATE") != nullptr;   // A/B: the device pairs' job next to the host pairs' instead of right away
+	// When does the device pairs' job go out?  Alone, right behind the pairing kernel (its kernels and the copies of its records run
+	// under the host's work on the other pairs: 94.8-96.8 vs 98.7-102.8 ms per chunk); with other calls in flight, next to the host
+	// pairs' job (their kernels fill the gaps anyway and an early launch only delays their seeding: 12.0-12.7 vs 10.9-11.3 Mreads/s).
+	// MPIBWA_DEV_JOB_LATE=0/1 forces either.
+	const char *dle = getenv("MPIBWA_DEV_JOB_LATE");
+	const bool dev_late = dle ? atoi(dle) != 0 : lease.others >= 2;
 	if (n_parts == 1) {
 		parts[0].lo = 0; parts[0].hi = n_units;
 		if (!dev_late) launch_dev(parts[0], 0);
 		mcollect(parts[0], 0); mlaunch(parts[0], 0);
+		if (!dev_late) { finish_dev(parts[0], 0); replay(parts[0], 0); }
 		collect(parts[0], 0); mfinish(parts[0]); collect(parts[0], 1);
 		if (dev_late) launch_dev(parts[0], 0);
-		launch(parts[0], 0); finish(parts[0]); finish_dev(parts[0], 0);
+		launch(parts[0], 0); finish(parts[0]);
+		if (dev_late) { finish_dev(parts[0], 0); replay(parts[0], 0); }
 		hprof_report("decisions + request lists");
-		replay(parts[0]);
+		replay(parts[0], 1);
 	} else {
 		parts[0].lo = 0; parts[0].hi = n_units / 2; parts[1].lo = n_units / 2; parts[1].hi = n_units;
 		if (!dev_late) { launch_dev(parts[0], 0); launch_dev(parts[1], 1); }
 		mcollect(parts[0], 0); mlaunch(parts[0], 0);
 		mcollect(parts[1], 1); mlaunch(parts[1], 1);
+		if (!dev_late) { finish_dev(parts[0], 0); replay(parts[0], 0); }   // (the mate-rescue kernels of both parts are running)
 		collect(parts[0], 0); mfinish(parts[0]); collect(parts[0], 1);
 		if (dev_late) launch_dev(parts[0], 0);
 		launch(parts[0], 0);
+		if (!dev_late) { finish_dev(parts[1], 1); replay(parts[1], 0); }
 		collect(parts[1], 0); mfinish(parts[1]); collect(parts[1], 1);
 		if (dev_late) launch_dev(parts[1], 1);
 		launch(parts[1], 1);
-		finish(parts[0]); finish_dev(parts[0], 0); replay(parts[0]);
-		finish(parts[1]); finish_dev(parts[1], 1); replay(parts[1]);
+		finish(parts[0]);
+		if (dev_late) { finish_dev(parts[0], 0); replay(parts[0], 0); }
+		replay(parts[0], 1);
+		finish(parts[1]);
+		if (dev_late) { finish_dev(parts[1], 1); replay(parts[1], 0); }
+		replay(parts[1], 1);
 	}
 	STAT.plan_ms = plan_ms; STAT.aln_ms = aln_wait_ms; STAT.msw_ms = msw_ms; STAT.emit_ms = emit_ms;
 	STAT.n_sam_dev = n_sam_dev.load();
