@@ -258,7 +258,18 @@ pair_simple_kernel(PairParams P, int n_pairs, const DevReg *__restrict__ first, 
 	desc[2 * k].req = -1; desc[2 * k + 1].req = -1;
 	status[k] = 0;
 	int n[2] = {nfirst[2 * k], nfirst[2 * k + 1]};
-	if (!pair_ok[k] || n[0] < 1 || n[1] < 1) { status[k] = 2; return; }
+	if (!pair_ok[k]) { status[k] = 2; return; }
+	if (n[0] == 0 && n[1] == 0) {   // no hit on either end: the two "unmapped" records need no decision at all (src/bwamem_pair.c:363-391, flags 77 / 141)
+		for (int e = 0; e < 2; ++e) {
+			SamDesc d;
+			d.rb = d.re = 0; d.qb = d.qe = 0; d.req = -3; d.rid = -1;
+			d.flag = 0x1 | 0x4 | 0x8 | 0x40 << e; d.mapq = 0; d.score = 0; d.sub = 0;
+			desc[2 * k + e] = d;
+		}
+		status[k] = 1;
+		return;
+	}
+	if (n[0] < 1 || n[1] < 1) { status[k] = 2; return; }
 	if (n[0] > PR_MAXREG || n[1] > PR_MAXREG) { status[k] = 3; return; }
 	PReg a[2][PR_MAXREG];
 	for (int e = 0; e < 2; ++e) {

@@ -3,7 +3,7 @@
 // Device counterpart of the tail of mem_reg2aln (src/bwamem.c:1123-1157: position, strand, squeeze of a leading /
 // trailing deletion, soft clips) and of mem_aln2sam (src/bwamem.c:825-946) for the case that makes up the bulk of a
 // chunk: a pair that mem_sam_pe reports through its "paired" branch (src/bwamem_pair.c:315-345) with ONE line per read —
-// no supplementary / ALT line, no XA, no pa tag, no comment, no XR.  Everything else (unpaired ends, supplementary
+// no supplementary / ALT line, no XA, no pa tag, no comment, no XR — and (round 3) the two records of a pair without any hit.  Everything else (unpaired ends, supplementary
 // lines, XA, -a, -C, -V, single-end input) stays with the host's formatter (host_regs.cpp: aln2sam), and the host takes
 // a pair back whenever the device flags one of its reads (CIGAR computed by the host, record longer than the staging
 // buffer).  The host decides WHICH records are written here and all their numbers that involve floating point
@@ -140,7 +140,25 @@ sam_emit_kernel(SamParams P, int n_reads, const SamDesc *__restrict__ desc, cons
 		const uint8_t *md = nullptr;
 		if (r < n_reads) {
 			const SamDesc D = desc[r];
-			if (D.req >= 0) {
+			if (D.req == -3) {   // a read of a pair without any hit: "QNAME FLAG * 0 0 * * 0 0 SEQ QUAL AS:i:0 XS:i:0 [RG]" (src/bwamem.c:853-858, 928-929)
+				lq = lens[r];
+				Sink S;
+				S.row = rows + lane * SAM_ROW; S.len = 0;
+				name_at = name_off[r]; name_len = name_off[r + 1] - name_at;
+				S.ch('\t'); S.num32((uint32_t)(D.flag & 0xffff)); S.ch('\t');
+				e_a = S.len;
+				S.lit("*\t0\t0\t*\t");
+				e_b = S.len;
+				S.lit("*\t0\t0\t");
+				e_c = S.len;
+				if (!P.has_qual) S.ch('*');
+				e_d = S.len;
+				S.lit("\tAS:i:0\tXS:i:0");
+				if (P.rg_len) S.lit("\tRG:Z:");
+				is_rev = 0; sq_at = off[r];
+				total = name_len + S.len + lq + 1 + (P.has_qual ? lq : 0) + P.rg_len + 1;
+				status = total;
+			} else if (D.req >= 0) {
 				const SamDesc M = desc[r ^ 1];
 				const int unit = r >> 1, lm = lens[r ^ 1];
 				lq = lens[r];
