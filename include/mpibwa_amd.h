@@ -208,6 +208,8 @@ typedef struct {
 int  mi355x_init(int local_rank, const bwaidx_t *idx, const mi355x_comm_t *comm);
 /* GPUs visible to this process (a host program that starts more ranks than that lets ranks share a device) */
 int  mi355x_device_count(void);
+/* free / total bytes of HBM on the device the index lives on; 0 on success */
+int  mi355x_device_memory(size_t *free_bytes, size_t *total_bytes);
 /* seconds spent in the RCCL broadcast of the last mi355x_init (0 when none took place) */
 double mi355x_init_bcast_seconds(void);
 

@@ -188,6 +188,17 @@ extern "C" int mi355x_device_count(void)
 	return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
 
+// free / total bytes of the device the index lives on (0 on success), through this library's own HIP runtime
+extern "C" int mi355x_device_memory(size_t *free_bytes, size_t *total_bytes)
+{
+	size_t fr = 0, tot = 0;
+	if (g_idx.device >= 0 && hipSetDevice(g_idx.device) != hipSuccess) return -1;
+	if (hipMemGetInfo(&fr, &tot) != hipSuccess) return -1;
+	if (free_bytes) *free_bytes = fr;
+	if (total_bytes) *total_bytes = tot;
+	return 0;
+}
+
 extern "C" int mi355x_index_alloc(int local_rank, const bwt_t *bwt, const bntseq_t *bns)
 {
 	require_device(local_rank);

@@ -1116,6 +1116,9 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			pp.low[d] = pes[d].low; pp.high[d] = pes[d].high; pp.failed[d] = pes[d].failed ? 1 : 0;
 			pp.tab_off[d] = (int)n_tab;
 			if (!pes[d].failed) {
+				// (a degenerate distribution — std 0, as a user's -I can give — makes the pair score NaN / infinite for some distances,
+				// and the conversion of those to int is the one place where the host's and the device's arithmetic differ: host path)
+				if (!(pes[d].std > 0) || !std::isfinite(pes[d].avg) || !std::isfinite(pes[d].std)) usable = false;
 				if (pes[d].high < pes[d].low || (int64_t)pes[d].high - pes[d].low > (1 << 20)) usable = false;
 				else n_tab += (size_t)(pes[d].high - pes[d].low + 1);
 			}

@@ -131,6 +131,12 @@ def test_scoring_matrix_and_misc_inputs(both, reads_pe):
     pes[1].failed = 0
     pes[1].avg, pes[1].std, pes[1].low, pes[1].high = 400.0, 50.0, 100, 700
     _cmp(eng, ref, ra, dict(flag=abi.MEM_F_PE), pes0=pes)
+    assert eng.stats()["n_pair_dev"] > 0
+    # a degenerate user distribution (-I 400,0): the pair score is infinite / NaN for some distances; the pairs go to the host's arithmetic
+    pes[1].std = 0.0
+    pes[1].low, pes[1].high = 330, 470
+    _cmp(eng, ref, ra, dict(flag=abi.MEM_F_PE), pes0=pes)
+    assert eng.stats()["n_pair_dev"] == 0
 
 
 @needs_ref

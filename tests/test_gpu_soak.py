@@ -22,12 +22,9 @@ def test_sixty_chunks_leave_memory_where_it_was(genome, built):
     lib = api.load_library()
     lib.mi355x_finalize()
     eng = api.Engine(genome["prefix"], device=0)
-    hip = api._hip()
-    hip.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
-
-    def dev_used():
+    def dev_used():   # (through the library's own HIP runtime: the test runner's process may carry a second one, e.g. an imported torch's)
         fr, tot = C.c_size_t(0), C.c_size_t(0)
-        assert hip.hipMemGetInfo(C.byref(fr), C.byref(tot)) == 0
+        assert lib.mi355x_device_memory(C.byref(fr), C.byref(tot)) == 0
         return (tot.value - fr.value) / 1e6
     C.c_int.in_dll(lib, "bwa_verbose").value = 1
     opt = eng.opt(flag=abi.MEM_F_PE)
