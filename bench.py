@@ -32,6 +32,21 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def cgroup_throttle():
+    """(events, microseconds) the container's CPU quota has stopped this process group so far (cgroup v2 cpu.stat)."""
+    ev = us = 0
+    try:
+        for l in open("/sys/fs/cgroup/cpu.stat"):
+            k, v = l.split()
+            if k == "nr_throttled":
+                ev = int(v)
+            if k == "throttled_usec":
+                us = int(v)
+    except OSError:
+        pass
+    return ev, us
+
+
 def kernel_sources_sha256(root):
     """what tools/pmc_smem.sh records next to its FETCH_SIZE figures: the seeding kernels' sources"""
     import hashlib
@@ -226,6 +241,11 @@ def main():
     writer = Writer() if os.environ.get("MPIBWA_BENCH_WRITER", "0") == "1" else None   # (A/B: 8.5-8.7 vs 10.9-13.1 Mreads/s with eight calls in flight: it takes 0.45 CPU-s per step)
     t0 = time.perf_counter()
     c0 = time.process_time()
+    sys0 = os.times().system
+    grow0 = int(lib.mi355x_buffer_growths())
+    if os.environ.get("MPIBWA_GROWTH_LOG"):
+        print("[bench] timed region starts", file=sys.stderr, flush=True)
+    thr0 = cgroup_throttle()
     acc = {}
     run_steps(args.steps, acc)
     torch.cuda.synchronize()
@@ -233,6 +253,11 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     host_cpu_s = time.process_time() - c0
+    host_sys_s = os.times().system - sys0
+    grown = int(lib.mi355x_buffer_growths()) - grow0
+    if os.environ.get("MPIBWA_GROWTH_LOG"):
+        print("[bench] timed region ends", file=sys.stderr, flush=True)
+    thr1 = cgroup_throttle()
     if writer:
         writer.finish()      # what the writer had not got to yet is collected outside the timed region
     drain()
@@ -314,10 +339,12 @@ def main():
         "sam_records_written_by_device_frac": round(acc.get("n_sam_dev", 0) / max(1, acc.get("n_reads", 1)), 4),
         "one_call_in_flight": {"value": round(2 * args.pairs * n_chunks * world / alone_s / 1e6, 4), "unit": "Mreads/s",
                                "ms_per_step": round(alone_s / n_chunks * 1e3, 2), "steps": n_chunks},
-        "host_cpu_s_per_step": round(host_cpu_s / args.steps, 3), "host_cpu_busy_frac": round(host_cpu_s / (elapsed * max(cores, 1)), 3),
+        "host_cpu_s_per_step": round(host_cpu_s / args.steps, 3), "host_sys_s_per_step": round(host_sys_s / args.steps, 3),
+        "timed_region_disturbances": {"work_buffer_reallocations": grown, "cgroup_cpu_throttle_events": thr1[0] - thr0[0], "cgroup_cpu_throttled_ms": round((thr1[1] - thr0[1]) / 1e3, 1)}, "host_cpu_busy_frac": round(host_cpu_s / (elapsed * max(cores, 1)), 3),
         "roofline": roofline,
         "stage_ms_per_step": {k: round(acc[k] / args.steps, 2) for k in
                               ("total_ms", "h2d_ms", "phase1_ms", "smem_ms", "sa_ms", "chain_ms", "ext_ms", "regs_ms", "pestat_ms", "sam_ms", "msw_ms", "plan_ms", "aln_ms", "emit_ms", "k_smem_ms", "k_sa_ms", "k_ext_ms", "k_msw_ms", "k_aln_ms")},
+        "work_per_step": {k: int(acc.get(k, 0) / args.steps) for k in ("n_intv", "n_seeds", "n_chains", "n_ext", "n_msw", "n_aln", "n_pair_dev", "n_sam_dev")},
         "aux_kernels": {
             "sa_kernel_GBps": round(acc["sa_bytes"] / (acc["k_sa_ms"] * 1e-3) / 1e9, 1) if acc.get("k_sa_ms") else None,
             "c2a_kernel_GCUPS": round(acc["ext_cells"] / (acc["k_ext_ms"] * 1e-3) / 1e9, 2) if acc.get("k_ext_ms") else None},

@@ -210,6 +210,9 @@ int  mi355x_init(int local_rank, const bwaidx_t *idx, const mi355x_comm_t *comm)
 int  mi355x_device_count(void);
 /* free / total bytes of HBM on the device the index lives on; 0 on success */
 int  mi355x_device_memory(size_t *free_bytes, size_t *total_bytes);
+/* (re)allocations of device / page-locked work buffers since the library was loaded: they stall every stream of the device, so
+ * the number should stand still once every call context has seen its largest chunk */
+unsigned long long mi355x_buffer_growths(void);
 /* seconds spent in the RCCL broadcast of the last mi355x_init (0 when none took place) */
 double mi355x_init_bcast_seconds(void);
 

@@ -18,7 +18,7 @@ EXPORTS = [
     "mi355x_index_upload", "mi355x_index_alloc", "mi355x_index_buffers", "mi355x_index_d2d", "mi355x_index_commit",
     "mi355x_finalize", "mi355x_index_build", "mi355x_index_build_gpu",
     "mi355x_smem_batch", "mi355x_sa_batch", "mi355x_sa_batch2", "mi355x_sa_dense_info", "mi355x_extend_batch", "mi355x_matesw_batch", "mi355x_chain_batch", "mi355x_fastq_scan", "mi355x_fastq_chunks", "mi355x_fastq_fill", "mi355x_last_stats", "mi355x_host_cpus", "mi355x_collect_sam", "mi355x_collect_sam_into", "mi355x_host_ksw_align2",
-    "bwa_set_rg", "bwa_insert_header", "bwa_idx2mem", "mi355x_write_map", "mi355x_init", "mi355x_init_bcast_seconds", "mi355x_global_batch", "mi355x_device_count", "mi355x_device_memory",
+    "bwa_set_rg", "bwa_insert_header", "bwa_idx2mem", "mi355x_write_map", "mi355x_init", "mi355x_init_bcast_seconds", "mi355x_global_batch", "mi355x_device_count", "mi355x_device_memory", "mi355x_buffer_growths",
 ]
 
 
@@ -85,6 +85,7 @@ def load_library(build_if_missing=True):
     sig("mi355x_init_bcast_seconds", C.c_double, [])
     sig("mi355x_device_count", C.c_int, [])
     sig("mi355x_device_memory", C.c_int, [P(C.c_size_t), P(C.c_size_t)])
+    sig("mi355x_buffer_growths", C.c_ulonglong, [])
     sig("mi355x_global_batch", C.c_int, [P(abi.mem_opt_t), C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 7 +
         [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, P(C.c_double)])
     _LIB = lib

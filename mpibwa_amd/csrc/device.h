@@ -49,6 +49,7 @@ bool index_matches(const bwt_t *bwt, const bntseq_t *bns, const char **what);
 int calls_in_flight();
 // serialises "is the index resident / the right one, then count the call in" (mem_process_seqs) against upload and release
 std::recursive_mutex &index_mutex();
+void note_buffer_growth(size_t from, size_t to, const char *kind);   // counted by mi355x_buffer_growths()
 
 // SMEM seeding parameters (subset of mem_opt_t used by mem_collect_intv)
 struct SmemParams {

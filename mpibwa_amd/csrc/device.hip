@@ -1,5 +1,6 @@
 // device.hip — device management, index residency in HBM and the stage-level C entry points.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -19,11 +20,22 @@ namespace mbw {
 
 static DevIndex g_idx;
 DevIndex &dev_index() { return g_idx; }
+static std::atomic<unsigned long long> g_buf_growths(0);
+void note_buffer_growth(size_t from, size_t to, const char *kind)
+{
+	++g_buf_growths;
+	static const bool log = getenv("MPIBWA_GROWTH_LOG") != nullptr;
+	if (log) fprintf(stderr, "[growth] %s buffer %zu -> %zu bytes (reallocation %llu)\n", kind, from, to, g_buf_growths.load());
+}
+// (re)allocations of device and page-locked work buffers so far: hipFree / hipMalloc / hipHostMalloc stall every stream of the
+// device, so a caller that sees this number move in steady state knows where a slow chunk came from
+extern "C" unsigned long long mi355x_buffer_growths(void) { return g_buf_growths.load(); }
 void *DevBuf::ensure(size_t bytes)
 {
 	if (bytes > cap) {
-		if (p) HIP_OK(hipFree(p));
 		size_t want = bytes + bytes / 4 + 256;
+		note_buffer_growth(cap, want, "device");
+		if (p) HIP_OK(hipFree(p));
 		if (hipMalloc(&p, want) != hipSuccess) {
 			size_t fr = 0, tot = 0;
 			(void)hipMemGetInfo(&fr, &tot);

@@ -54,7 +54,7 @@ namespace mbw {
 static mi355x_stats_t g_stats;
 
 // CPUs this process may actually use: the cgroup CPU quota when there is one, else the online CPU count
-static int usable_cpus()
+static int usable_cpus_now()
 {
 	int hw = (int)std::thread::hardware_concurrency();
 	if (hw <= 0) hw = 1;
@@ -70,6 +70,9 @@ static int usable_cpus()
 	}
 	return hw;
 }
+// (asked once: every call used to open the cgroup file again, and under eight calls in flight that open alone held a call up
+// for milliseconds)
+static int usable_cpus() { static const int c = usable_cpus_now(); return c; }
 
 // Which GPU a lazily uploading rank takes, and how many ranks share the node: the launcher's environment
 // (torchrun, Open MPI, MVAPICH2, Slurm/PMI, Intel MPI / MPICH hydra).  -1 / 0 when the launcher says nothing.
@@ -275,9 +278,72 @@ static double cpu_sec()
 // Wait for a stream without burning a core: hipStreamSynchronize spins, and a spinning thread counts against the
 // container's CPU quota like a working one (the host stages are the other half of the bottleneck).  Polling with a short
 // sleep costs at most ~0.1 ms per wait.
+// MPIBWA_SAMPLE=1: where the calls in flight are, sampled every 250 us (which stage, waiting for a kernel or working on the
+// host), printed when the process exits: which stages the calls sit in while nobody keeps the GPU busy, and the other way round
+static const int SAMPLE_SLOTS = 64, SAMPLE_STAGES = 64, STG_WAIT = 0x100;
+static std::atomic<int> g_stage[SAMPLE_SLOTS];
+static thread_local std::atomic<int> *t_stage = nullptr;
+static inline void stage(int id) { if (t_stage) t_stage->store(id, std::memory_order_relaxed); }
+struct StageSampler {
+	std::thread th;
+	std::atomic<bool> stop{false};
+	uint64_t n_samples = 0, in_stage[SAMPLE_STAGES][2] = {{0}}, by_wait[SAMPLE_SLOTS + 1] = {0}, by_host[SAMPLE_SLOTS + 1] = {0};
+	uint64_t host_when_idle[SAMPLE_STAGES] = {0}, n_gpu_idle = 0, n_host_idle = 0;
+	int min_calls = 1;   // MPIBWA_SAMPLE=n: only samples with at least n calls in flight count
+	void run()
+	{
+		while (!stop.load()) {
+			int nw = 0, nh = 0, st[SAMPLE_SLOTS], ns = 0;
+			for (int i = 0; i < SAMPLE_SLOTS; ++i) {
+				const int v = g_stage[i].load(std::memory_order_relaxed);
+				if (!v) continue;
+				st[ns++] = v;
+				const int id = v & 63, w = (v & STG_WAIT) != 0;
+				if (w) ++nw; else if (id != 20 && id != 50) ++nh;
+			}
+			if (ns >= min_calls) {
+				++n_samples; ++by_wait[nw]; ++by_host[nh];
+				for (int k = 0; k < ns; ++k) ++in_stage[st[k] & 63][(st[k] & STG_WAIT) != 0];
+				if (!nw) { ++n_gpu_idle; for (int k = 0; k < ns; ++k) ++host_when_idle[st[k] & 63]; }
+				if (!nh) ++n_host_idle;
+			}
+			usleep(250);
+		}
+	}
+	void report()
+	{
+		if (!n_samples) return;
+		fprintf(stderr, "[sample] %llu samples with a call in flight; no call waiting for the GPU in %.1f %%, no call on the host in %.1f %%\n",
+		        (unsigned long long)n_samples, 100.0 * n_gpu_idle / n_samples, 100.0 * n_host_idle / n_samples);
+		fprintf(stderr, "[sample] calls waiting for the GPU:");
+		for (int k = 0; k <= 12; ++k) fprintf(stderr, " %d:%.1f%%", k, 100.0 * by_wait[k] / n_samples);
+		fprintf(stderr, "\n[sample] calls working on the host:");
+		for (int k = 0; k <= 12; ++k) fprintf(stderr, " %d:%.1f%%", k, 100.0 * by_host[k] / n_samples);
+		fprintf(stderr, "\n[sample] stage: mean calls in it on the host / waiting for the GPU / on the host while no call waits for the GPU\n");
+		for (int id = 0; id < SAMPLE_STAGES; ++id)
+			if (in_stage[id][0] + in_stage[id][1])
+				fprintf(stderr, "[sample]   %2d: %.3f %.3f %.3f\n", id, (double)in_stage[id][0] / n_samples, (double)in_stage[id][1] / n_samples,
+				        n_gpu_idle ? (double)host_when_idle[id] / n_gpu_idle : 0.0);
+	}
+};
+static StageSampler *g_sampler = nullptr;
+void sampler_report()
+{
+	if (!g_sampler) return;
+	g_sampler->stop.store(true);
+	g_sampler->th.join();
+	g_sampler->report();
+	delete g_sampler;
+	g_sampler = nullptr;
+}
+
 static void stream_wait(hipStream_t st)
 {
 	static const bool spin = getenv("MPIBWA_SPIN_WAIT") != nullptr;
+	struct Mark {
+		Mark() { if (t_stage) t_stage->fetch_or(STG_WAIT, std::memory_order_relaxed); }
+		~Mark() { if (t_stage) t_stage->fetch_and(~STG_WAIT, std::memory_order_relaxed); }
+	} mark;
 	if (!spin) {
 		for (;;) {
 			hipError_t e = hipStreamQuery(st);
@@ -312,6 +378,7 @@ struct PinBuf {
 	void *ensure(size_t bytes)
 	{
 		if (bytes > cap) {
+			note_buffer_growth(cap, bytes + bytes / 4 + 4096, "page-locked");
 			if (p) HIP_OK(hipHostFree(p));
 			cap = bytes + bytes / 4 + 4096;
 			HIP_OK(hipHostMalloc(&p, cap, hipHostMallocDefault));
@@ -322,6 +389,9 @@ struct PinBuf {
 
 struct Workspace {
 	PinBuf h_nch, h_cbeg, h_ccnt, h_rbeg, h_nseeds, h_lrep, h_nintv;
+	// (every copy to or from the device uses page-locked host memory: a pageable target makes hipMemcpyAsync wait — spinning —
+	// for the kernels queued before it, and a pageable source is pinned page by page at every call)
+	PinBuf h_cnt, h_off, h_len, h_seed_off, h_small;
 	DevBuf nch, chain_cnt, reg_pos, regs_packed, ann_off, ann_alt, pack_tmp, order, chain_gen, c2a_stat;
 	PinBuf h_c2a_stat;
 	PinBuf h_order;
@@ -485,6 +555,18 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	if (n <= 0) return;
 	CtxLease lease(seqs, n);
 	CallCtx &C = *lease.c;
+	static std::once_flag sampler_once;
+	std::call_once(sampler_once, [] {
+		if (!getenv("MPIBWA_SAMPLE")) return;
+		g_sampler = new StageSampler;
+		g_sampler->min_calls = std::max(1, atoi(getenv("MPIBWA_SAMPLE")));
+		g_sampler->th = std::thread([] { g_sampler->run(); });
+		atexit(sampler_report);
+	});
+	struct StageOwner {
+		StageOwner(int slot) { t_stage = &g_stage[slot]; stage(1); }
+		~StageOwner() { t_stage->store(0); t_stage = nullptr; }
+	} stage_owner((int)(&C - g_ctx));
 	const int n_thr = host_threads(opt);
 	const bool pe = (opt->flag & MEM_F_PE) != 0;
 	if (!C.a_streams[0]) {
@@ -494,38 +576,66 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		HIP_OK(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
 		const char *pe = getenv("MPIBWA_PRIO");
 		const int pp = pe && *pe == 'p' ? hi_p : 0, pa = !pe || *pe == 'a' ? hi_p : 0;
-		for (int l = 0; l < MAX_LANES; ++l) HIP_OK(hipStreamCreateWithPriority(&C.p_streams[l], hipStreamNonBlocking, pp));
-		for (int l = 0; l < 2; ++l) HIP_OK(hipStreamCreateWithPriority(&C.a_streams[l], hipStreamNonBlocking, pa));
-		for (int l = 0; l < 2; ++l) HIP_OK(hipStreamCreateWithPriority(&C.d_streams[l], hipStreamNonBlocking, pa));
+		// The runtime spreads the streams of one priority over its few hardware queues in the order they are created: without the
+		// rotation from call to call the first stream of every call shares ONE hardware queue, and that queue — 50 ms of phase-1
+		// kernels and copies per chunk, strictly one after the other — is the bottleneck of eight calls in flight.  Rotated, the
+		// kernels of different calls overlap: 13.0-13.7 vs 12.3-12.7 Mreads/s in alternating runs (the seeding launches stretch
+		// from 15-18 to 17-21 ms in that company).  MPIBWA_STREAM_ROT=0: no rotation.
+		hipStream_t ps[MAX_LANES], hs[4];
+		for (int l = 0; l < MAX_LANES; ++l) HIP_OK(hipStreamCreateWithPriority(&ps[l], hipStreamNonBlocking, pp));
+		for (int l = 0; l < 4; ++l) HIP_OK(hipStreamCreateWithPriority(&hs[l], hipStreamNonBlocking, pa));
+		const char *re = getenv("MPIBWA_STREAM_ROT");
+		const int rot = re && atoi(re) == 0 ? 0 : (int)(&C - g_ctx);
+		for (int l = 0; l < MAX_LANES; ++l) C.p_streams[l] = ps[(l + rot) % MAX_LANES];
+		for (int l = 0; l < 2; ++l) { C.a_streams[l] = hs[(l + rot) % 4]; C.d_streams[l] = hs[(2 + l + rot) % 4]; }
 	}
 	hipStream_t st = C.p_streams[0];   // never the null stream: another call may be in flight
 	Workspace &W = C.gws;
 
 	// ---- 1. encode + pack ----
-	std::vector<int64_t> off(n + 1);   // 16-byte aligned slot of every read in the packed buffer
-	std::vector<int> lens(n);
-	off[0] = 0;
+	stage(29);
+	int64_t *off = (int64_t *)W.h_off.ensure((size_t)(n + 1) * 8 + 64);   // 16-byte aligned slot of every read in the packed buffer
+	int *lens = (int *)W.h_len.ensure((size_t)n * 4 + 64);
 	int max_len = 0;
 	int64_t total_bases = 0;
-	for (int i = 0; i < n; ++i) {
-		lens[i] = seqs[i].l_seq;
-		off[i + 1] = off[i] + ((seqs[i].l_seq + 15) & ~15);
-		max_len = std::max(max_len, seqs[i].l_seq);
-		total_bases += seqs[i].l_seq;
+	{   // lengths and a prefix sum over 667 000 records the caller has just written: by blocks, on all threads
+		const int BLK = 8192, nb = (n + BLK - 1) / BLK;
+		std::vector<int64_t> bsum(nb + 1, 0), bbases(nb, 0);
+		std::vector<int> bmax(nb, 0);
+		parallel_for(n_thr, nb, 1, [&](int b) {
+			const int lo = b * BLK, hi = std::min(n, lo + BLK);
+			int64_t sl = 0, tb = 0;
+			int m = 0;
+			for (int i = lo; i < hi; ++i) {
+				const int l = seqs[i].l_seq;
+				lens[i] = l; sl += (l + 15) & ~15; tb += l; m = std::max(m, l);
+			}
+			bsum[b + 1] = sl; bbases[b] = tb; bmax[b] = m;
+		});
+		for (int b = 0; b < nb; ++b) { bsum[b + 1] += bsum[b]; total_bases += bbases[b]; max_len = std::max(max_len, bmax[b]); }
+		parallel_for(n_thr, nb, 1, [&](int b) {
+			const int lo = b * BLK, hi = std::min(n, lo + BLK);
+			int64_t o = bsum[b];
+			for (int i = lo; i < hi; ++i) { off[i] = o; o += (lens[i] + 15) & ~15; }
+		});
+		off[n] = bsum[nb];
 	}
+	stage(30);
 	const size_t flat_bytes = (size_t)off[n] + 16;
 	uint8_t *flat = (uint8_t *)W.h_flat.ensure(flat_bytes);
 	if ((size_t)max_len + 2 > 9000) die("read of %d bp exceeds the on-chip band buffers of this build (max 8998 bp)", max_len);
 	double t1 = now_ms();
 	const double c1 = cpu_sec();
+	stage(22);
 	uint8_t *d_seq = (uint8_t *)W.seq.ensure(flat_bytes);
 	int64_t *d_off = (int64_t *)W.off.ensure((size_t)(n + 1) * 8);
 	int *d_len = (int *)W.len.ensure((size_t)n * 4);
 	// the bases themselves are encoded and uploaded per sub-batch, on the sub-batch's own stream (phase1 below)
-	HIP_OK(hipMemcpyAsync(d_off, off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
-	HIP_OK(hipMemcpyAsync(d_len, lens.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+	HIP_OK(hipMemcpyAsync(d_off, off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+	HIP_OK(hipMemcpyAsync(d_len, lens, (size_t)n * 4, hipMemcpyHostToDevice, st));
 	HIP_OK(hipStreamSynchronize(st));
 	unsigned long long *d_cnt = (unsigned long long *)W.cnt.ensure(256);
+	stage(23);
 	// contig table for the chaining kernel: start of every contig (+ l_pac) and its ALT flag
 	std::vector<int64_t> ann_off(bns->n_seqs + 1);
 	std::vector<uint8_t> ann_alt(bns->n_seqs + 1, 0);
@@ -537,9 +647,89 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	HIP_OK(hipMemcpyAsync(d_ann_alt, ann_alt.data(), ann_alt.size(), hipMemcpyHostToDevice, st));
 	HIP_OK(hipStreamSynchronize(st));
 
+	// ---- inputs of the SAM stage (names, qualities, contig names, the gap table of the CIGAR kernel): packed and uploaded by a
+	// thread of their own on a side stream while phase 1 runs — 100 MB of qualities per chunk that nothing before the SAM stage reads
+	// (reads so long that one request's arrays do not fit the LDS of a CU — beyond ~1 700 bp — get their CIGARs from the library's host code)
+	const bool gpu_aln = getenv("MPIBWA_HOST_CIGAR") == nullptr && aln_lds_per_block(max_len, max_len + 256) <= (size_t)160 * 1024;
+	int *d_gap = nullptr;
+	bool gpu_sam = false;
+	SamDescH *sdesc = nullptr;
+	SamParams sam_par;
+	const uint8_t *d_qual = nullptr, *d_names = nullptr;
+	const int *d_noff = nullptr, *d_ann_noff = nullptr;
+	const char *d_ann_names = nullptr;
+	struct Joiner {   // (a call that dies on the way out must not leave the thread running on its buffers)
+		std::thread t;
+		void join() { if (t.joinable()) t.join(); }
+		~Joiner() { join(); }
+	} sam_inputs;
+	sam_inputs.t = std::thread([&] {
+		HIP_OK(hipSetDevice(ix.device));
+		hipStream_t sst = C.d_streams[1];
+		std::vector<int> gaptab(max_len + 2);
+		for (int l = 0; l <= max_len + 1; ++l) {   // max_gap of bwa_gen_cigar2 (src/bwa.c:155-158), a function of l_query only
+			int max_ins = (int)((double)(((l + 1) >> 1) * opt->mat[0] - opt->o_ins) / opt->e_ins + 1.);
+			int max_del = (int)((double)(((l + 1) >> 1) * opt->mat[0] - opt->o_del) / opt->e_del + 1.);
+			int g = max_ins > max_del ? max_ins : max_del;
+			gaptab[l] = g > 1 ? g : 1;
+		}
+		d_gap = (int *)W.agap.ensure(gaptab.size() * 4);
+		HIP_OK(hipMemcpyAsync(d_gap, gaptab.data(), gaptab.size() * 4, hipMemcpyHostToDevice, sst));
+		// ---- SAM text of confidently paired reads on the device (sam_kernel.hip) ----
+		// The COLLECT pass describes the two lines of every pair that qualifies (AlnCtx::desc); the kernel runs right behind the
+		// CIGAR kernel of the part; the REPLAY pass only copies those records out of the arena and formats the rest itself.
+		static_assert(sizeof(SamDesc) == sizeof(SamDescH), "host/device record layouts differ");
+		gpu_sam = pe && gpu_aln && getenv("MPIBWA_HOST_SAM") == nullptr && !(opt->flag & (MEM_F_ALL | MEM_F_REF_HDR));
+		if (gpu_sam) {
+			bool any_q = false, all_q = true;
+			for (int i = 0; i < n; ++i) { if (seqs[i].qual) any_q = true; else all_q = false; }
+			if (any_q && !all_q) gpu_sam = false;   // a mix of reads with and without qualities: the host formats the chunk
+			sam_par.l_pac = bns->l_pac; sam_par.has_qual = any_q ? 1 : 0;
+			sam_par.rg_len = (int)strnlen(bwa_rg_id, sizeof bwa_rg_id);
+			memset(sam_par.rg, 0, sizeof sam_par.rg);
+			memcpy(sam_par.rg, bwa_rg_id, (size_t)sam_par.rg_len);
+		}
+		if (gpu_sam) {
+			sdesc = (SamDescH *)W.h_sdesc.ensure((size_t)n * sizeof(SamDescH) + 64);
+			int *noff = (int *)W.h_noff.ensure((size_t)(n + 1) * 4 + 64);
+			std::vector<int> nlen(n);
+			parallel_for(n_thr, n, 8192, [&](int i) { sdesc[i].req = -1; nlen[i] = (int)strlen(seqs[i].name); });
+			noff[0] = 0;
+			for (int i = 0; i < n; ++i) noff[i + 1] = noff[i] + nlen[i];
+			uint8_t *names = (uint8_t *)W.h_names.ensure((size_t)noff[n] + 64);
+			uint8_t *hq = sam_par.has_qual ? (uint8_t *)W.h_qual.ensure(flat_bytes) : nullptr;
+			parallel_for(n_thr, n, 4096, [&](int i) {
+				memcpy(names + noff[i], seqs[i].name, (size_t)nlen[i]);
+				if (hq) memcpy(hq + off[i], seqs[i].qual, (size_t)seqs[i].l_seq);
+			});
+			uint8_t *dn = (uint8_t *)W.snames.ensure((size_t)noff[n] + 64);
+			int *dno = (int *)W.snoff.ensure((size_t)(n + 1) * 4);
+			HIP_OK(hipMemcpyAsync(dn, names, (size_t)noff[n], hipMemcpyHostToDevice, sst));
+			HIP_OK(hipMemcpyAsync(dno, noff, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, sst));
+			if (hq) {
+				uint8_t *dq = (uint8_t *)W.squal.ensure(flat_bytes);
+				HIP_OK(hipMemcpyAsync(dq, hq, flat_bytes, hipMemcpyHostToDevice, sst));
+				d_qual = dq;
+			}
+			// contig names
+			std::vector<int> cno(bns->n_seqs + 1, 0);
+			for (int k = 0; k < bns->n_seqs; ++k) cno[k + 1] = cno[k] + (int)strlen(bns->anns[k].name);
+			std::vector<char> cn((size_t)cno[bns->n_seqs] + 1);
+			for (int k = 0; k < bns->n_seqs; ++k) memcpy(cn.data() + cno[k], bns->anns[k].name, (size_t)(cno[k + 1] - cno[k]));
+			char *dcn = (char *)W.sann_names.ensure(cn.size() + 64);
+			int *dcno = (int *)W.sann_noff.ensure(cno.size() * 4);
+			HIP_OK(hipMemcpyAsync(dcn, cn.data(), cn.size(), hipMemcpyHostToDevice, sst));
+			HIP_OK(hipMemcpyAsync(dcno, cno.data(), cno.size() * 4, hipMemcpyHostToDevice, sst));
+			stream_wait(sst);
+			d_names = dn; d_noff = dno; d_ann_names = dcn; d_ann_noff = dcno;
+		}
+		stream_wait(sst);
+	});
+
 	// ---- 2-6. seeding -> SA -> chaining -> extension -> region clean-up, in sub-batches ----
 	// The stages of one sub-batch are strictly dependent (GPU, host, GPU, host), so several sub-batches run on their own host
 	// threads with their own HIP stream and workspace: the GPU work of one overlaps the host work of the other.
+	stage(24);
 	std::vector<HRegV> regs(n);
 	// insert-size votes are gathered sub-batch by sub-batch (when they will be needed and can be counted)
 	std::vector<uint64_t> pes_hist_v;
@@ -553,12 +743,14 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	int *d_pr_nfirst = dev_pair ? (int *)W.pr_nfirst.ensure((size_t)n * 4) : nullptr;
 	struct P1 { double k_smem = 0, k_sa = 0, k_ext = 0, smem = 0, sa = 0, chain = 0, ext = 0, regs = 0; uint64_t smem_bytes = 0, smem_tab_bytes = 0, sa_bytes = 0, cells = 0, n_ext = 0, n_intv = 0, n_seeds = 0, n_chains = 0; };
 	const int n_all = n;
+	static const bool take_turns = !(getenv("MPIBWA_TURNS") && atoi(getenv("MPIBWA_TURNS")) == 0);
 	auto phase1 = [&](int lo, int hi, Workspace &W, HostBuf &reg_arena, hipStream_t st, int n_thr, P1 &ps) {
 		const int n = hi - lo;
 		bseq1_t *seqs_r = seqs + lo;
 		const int64_t *d_off_r = d_off + lo;
 		const int *d_len_r = d_len + lo;
 		HIP_OK(hipSetDevice(ix.device));
+		stage(2);
 		// nt4-encode this sub-batch in place (the caller sees the codes, src/bwamem.c:1057-1058) and into the staging buffer
 		parallel_for(n_thr, n, 4096, [&](int i) {
 			char *s = seqs_r[i].seq;
@@ -571,7 +763,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		HIP_OK(hipMemcpyAsync(d_seq + off[lo], flat + off[lo], (size_t)(off[hi] - off[lo]) + (hi == n_all ? 16 : 0), hipMemcpyHostToDevice, st));
 		EvTimer ev_smem, ev_sa, ev_ext;
 		unsigned long long *d_cnt = (unsigned long long *)W.cnt.ensure(256);
-		unsigned long long cnt[8];
+		unsigned long long *cnt = (unsigned long long *)W.h_cnt.ensure(256);
 		std::vector<int> gap_h(max_len + 2);
 		for (int l = 0; l < max_len + 2; ++l) gap_h[l] = cal_max_gap(opt, l);
 		// length tables for the device (the floating-point decisions of the reference, resolved per length on the host)
@@ -612,7 +804,10 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			HIP_OK(hipMemsetAsync(d_cnt, 0, 256, st));
 			// the sub-batches (and the other calls in flight) take turns on the big kernels: each one fills the chip by itself, and running them one
 			// after the other staggers the sub-batches so that the host stages of one fall under the kernels of the other
-			std::unique_lock<std::mutex> turn(g_smem_turn);
+			stage(20);
+			std::unique_lock<std::mutex> turn(g_smem_turn, std::defer_lock);
+			if (take_turns) turn.lock();
+			stage(21);
 			ev_smem.start(st);
 			launch_smem(st, ix.fm, smem_params(opt), n, d_seq, d_off_r, d_len_r, cap, d_intv, d_nintv, max_len, d_cnt, d_scr, per_quad, n_quads, count_blocks);
 			ev_smem.stop(st);
@@ -624,7 +819,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			HIP_OK(hipMemcpyAsync(nintv, d_nintv, (size_t)n * 4, hipMemcpyDeviceToHost, st));
 			stream_wait(st);
 			HIP_OK(hipGetLastError());
-			turn.unlock();
+			if (take_turns) turn.unlock();
 			ps.k_smem += ev_smem.ms();
 			if (cnt[2] == 0) break;
 			cap *= 4;
@@ -632,9 +827,10 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		ps.smem_bytes = count_blocks ? cnt[1] * 64 + range_bases : 0;
 		ps.smem_tab_bytes = cnt[4] * 64;
 		double t2 = now_ms();
+		stage(3);
 
 		// seed enumeration + SA lookup (+ chaining on the device)
-		std::vector<int64_t> seed_off(n + 1);
+		int64_t *seed_off = (int64_t *)W.h_seed_off.ensure((size_t)(n + 1) * 8 + 64);
 		seed_off[0] = 0;
 		uint64_t n_intv = 0;
 		for (int i = 0; i < n; ++i) { seed_off[i + 1] = seed_off[i] + nseeds[i]; n_intv += nintv[i]; }
@@ -653,7 +849,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			int64_t *d_seed_off = (int64_t *)W.seed_off.ensure((size_t)(n + 1) * 8);
 			uint64_t *d_rows = (uint64_t *)W.rows.ensure((size_t)S * 8), *d_sa = (uint64_t *)W.sa.ensure((size_t)S * 8);
 			int32_t *d_qbl = (int32_t *)W.qbl.ensure((size_t)S * 8);
-			HIP_OK(hipMemcpyAsync(d_seed_off, seed_off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+			HIP_OK(hipMemcpyAsync(d_seed_off, seed_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
 			launch_seed_enum(st, n, cap, d_intv, d_nintv, opt->max_occ, d_seed_off, d_rows, d_qbl);
 			if (S > 0x7fffffff) die("too many seeds in one batch");
 			HIP_OK(hipMemsetAsync(d_cnt, 0, 256, st));
@@ -688,6 +884,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			ps.sa_bytes = ix.fm.sa_full ? (uint64_t)S * 16 : cnt[1] * 64 + (uint64_t)S * 8;
 		}
 		double t3 = now_ms();
+		stage(4);
 
 		// chaining and chain filters (host).  Each block of reads is chained by one thread with recycled scratch and packed
 		// straight into the device layout (block-local offsets); the blocks are then concatenated after a prefix sum.
@@ -798,6 +995,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		ps.n_chains = n_chains_total;
 		const int64_t n_slots = base + NS;    // size of the seed / order / region arrays on the device
 		double t4 = now_ms();
+		stage(5);
 
 		// chain -> regions on the GPU
 		int *nregs = (int *)W.h_nregs.ensure((size_t)n * 4 + 8);
@@ -838,7 +1036,10 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			ExtParams ep;
 			memcpy(ep.mat, opt->mat, 25);
 			ep.o_del = opt->o_del; ep.e_del = opt->e_del; ep.o_ins = opt->o_ins; ep.e_ins = opt->e_ins; ep.zdrop = opt->zdrop;
-			std::unique_lock<std::mutex> turn(g_c2a_turn);
+			stage(50);
+			std::unique_lock<std::mutex> turn(g_c2a_turn, std::defer_lock);
+			if (take_turns) turn.lock();
+			stage(51);
 			ev_ext.start(st);
 			// one wavefront per read (any read length)
 			launch_c2a(st, cp, ep, n, d_seq, d_off_r, d_len_r, d_chain_beg, d_chain_cnt, d_chains, d_seeds, d_srt, d_reg_beg, d_regs, d_nregs,
@@ -860,7 +1061,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			HIP_OK(hipMemcpyAsync(hregs, d_packed, (size_t)guess * sizeof(DevReg), hipMemcpyDeviceToHost, st));
 			stream_wait(st);
 			HIP_OK(hipGetLastError());
-			turn.unlock();
+			if (take_turns) turn.unlock();
 			ps.k_ext = ev_ext.ms();
 			for (int k = 0; k < 4; ++k) { cnt[k] = 0; for (int sl = 0; sl < C2A_STAT_SLOTS; ++sl) cnt[k] += stat_h[sl * 8 + k]; }
 			ps.cells = cnt[0]; ps.n_ext = cnt[1];
@@ -876,6 +1077,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			}
 		}
 		double t5 = now_ms();
+		stage(6);
 
 		// region post-processing (host); every read gets a slice of the batch-wide arena: its regions + room for rescued mates
 		const int SLACK = 4;
@@ -967,6 +1169,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	const double c6 = cpu_sec();
 
 	// ---- 7. insert-size statistics over the whole batch ----
+	stage(7);
 	mem_pestat_t pes[4];
 	if (pe) {
 		if (pes0) memcpy(pes, pes0, 4 * sizeof(mem_pestat_t));
@@ -976,13 +1179,12 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	double t7 = now_ms();
 
 	// ---- 8. pairing decisions, then CIGAR/MD/NM on the GPU, then SAM text ----
+	stage(8);
 	// Per part of the chunk:  A  decisions + a COLLECT pass that records which regions need a global re-alignment
 	// (mem_reg2aln's DP);  B  aln_kernel does them all at once;  C  the same emission again (REPLAY) with the results
 	// plugged in.  Two parts are software-pipelined so that B of one part runs while the host does A / C of the other.
 	const int n_units = pe ? n >> 1 : n;
 	std::vector<PairPlan> plans(pe ? n_units : 0);
-	// (reads so long that one request's arrays do not fit the LDS of a CU — beyond ~1 700 bp — get their CIGARs from the library's host code)
-	const bool gpu_aln = getenv("MPIBWA_HOST_CIGAR") == nullptr && aln_lds_per_block(max_len, max_len + 256) <= (size_t)160 * 1024;
 	int n_parts = (gpu_aln && n_units >= 20000 && n_sub > 1) ? 2 : 1;
 	if (const char *e = getenv("MPIBWA_SAM_PARTS")) n_parts = std::max(1, std::min(2, atoi(e)));
 	struct Part {
@@ -1025,71 +1227,10 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	};
 	Part parts[2];
 	hipStream_t *a_streams = C.a_streams;
-	std::vector<int> gaptab(max_len + 2);
-	for (int l = 0; l <= max_len + 1; ++l) {   // max_gap of bwa_gen_cigar2 (src/bwa.c:155-158), a function of l_query only
-		int max_ins = (int)((double)(((l + 1) >> 1) * opt->mat[0] - opt->o_ins) / opt->e_ins + 1.);
-		int max_del = (int)((double)(((l + 1) >> 1) * opt->mat[0] - opt->o_del) / opt->e_del + 1.);
-		int g = max_ins > max_del ? max_ins : max_del;
-		gaptab[l] = g > 1 ? g : 1;
-	}
-	int *d_gap = (int *)W.agap.ensure(gaptab.size() * 4);
-	HIP_OK(hipMemcpyAsync(d_gap, gaptab.data(), gaptab.size() * 4, hipMemcpyHostToDevice, st));
-	HIP_OK(hipStreamSynchronize(st));
 	double plan_ms = 0, aln_wait_ms = 0;
 
-	// ---- SAM text of confidently paired reads on the device (sam_kernel.hip) ----
-	// The COLLECT pass describes the two lines of every pair that qualifies (AlnCtx::desc); the kernel runs right behind the
-	// CIGAR kernel of the part; the REPLAY pass only copies those records out of the arena and formats the rest itself.
-	static_assert(sizeof(SamDesc) == sizeof(SamDescH), "host/device record layouts differ");
-	bool gpu_sam = pe && gpu_aln && getenv("MPIBWA_HOST_SAM") == nullptr && !(opt->flag & (MEM_F_ALL | MEM_F_REF_HDR));
-	SamDescH *sdesc = nullptr;
-	SamParams sam_par;
-	const uint8_t *d_qual = nullptr, *d_names = nullptr;
-	const int *d_noff = nullptr, *d_ann_noff = nullptr;
-	const char *d_ann_names = nullptr;
-	if (gpu_sam) {
-		bool any_q = false, all_q = true;
-		for (int i = 0; i < n; ++i) { if (seqs[i].qual) any_q = true; else all_q = false; }
-		if (any_q && !all_q) gpu_sam = false;   // a mix of reads with and without qualities: the host formats the chunk
-		sam_par.l_pac = bns->l_pac; sam_par.has_qual = any_q ? 1 : 0;
-		sam_par.rg_len = (int)strnlen(bwa_rg_id, sizeof bwa_rg_id);
-		memset(sam_par.rg, 0, sizeof sam_par.rg);
-		memcpy(sam_par.rg, bwa_rg_id, (size_t)sam_par.rg_len);
-	}
-	if (gpu_sam) {
-		sdesc = (SamDescH *)W.h_sdesc.ensure((size_t)n * sizeof(SamDescH) + 64);
-		int *noff = (int *)W.h_noff.ensure((size_t)(n + 1) * 4 + 64);
-		std::vector<int> nlen(n);
-		parallel_for(n_thr, n, 8192, [&](int i) { sdesc[i].req = -1; nlen[i] = (int)strlen(seqs[i].name); });
-		noff[0] = 0;
-		for (int i = 0; i < n; ++i) noff[i + 1] = noff[i] + nlen[i];
-		uint8_t *names = (uint8_t *)W.h_names.ensure((size_t)noff[n] + 64);
-		uint8_t *hq = sam_par.has_qual ? (uint8_t *)W.h_qual.ensure(flat_bytes) : nullptr;
-		parallel_for(n_thr, n, 4096, [&](int i) {
-			memcpy(names + noff[i], seqs[i].name, (size_t)nlen[i]);
-			if (hq) memcpy(hq + off[i], seqs[i].qual, (size_t)seqs[i].l_seq);
-		});
-		uint8_t *dn = (uint8_t *)W.snames.ensure((size_t)noff[n] + 64);
-		int *dno = (int *)W.snoff.ensure((size_t)(n + 1) * 4);
-		HIP_OK(hipMemcpyAsync(dn, names, (size_t)noff[n], hipMemcpyHostToDevice, st));
-		HIP_OK(hipMemcpyAsync(dno, noff, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, st));
-		if (hq) {
-			uint8_t *dq = (uint8_t *)W.squal.ensure(flat_bytes);
-			HIP_OK(hipMemcpyAsync(dq, hq, flat_bytes, hipMemcpyHostToDevice, st));
-			d_qual = dq;
-		}
-		// contig names
-		std::vector<int> cno(bns->n_seqs + 1, 0);
-		for (int k = 0; k < bns->n_seqs; ++k) cno[k + 1] = cno[k] + (int)strlen(bns->anns[k].name);
-		std::vector<char> cn((size_t)cno[bns->n_seqs] + 1);
-		for (int k = 0; k < bns->n_seqs; ++k) memcpy(cn.data() + cno[k], bns->anns[k].name, (size_t)(cno[k + 1] - cno[k]));
-		char *dcn = (char *)W.sann_names.ensure(cn.size() + 64);
-		int *dcno = (int *)W.sann_noff.ensure(cno.size() * 4);
-		HIP_OK(hipMemcpyAsync(dcn, cn.data(), cn.size(), hipMemcpyHostToDevice, st));
-		HIP_OK(hipMemcpyAsync(dcno, cno.data(), cno.size() * 4, hipMemcpyHostToDevice, st));
-		HIP_OK(hipStreamSynchronize(st));
-		d_names = dn; d_noff = dno; d_ann_names = dcn; d_ann_noff = dcno;
-	}
+	stage(25);
+	sam_inputs.join();
 
 	// ---- pairs with one plain hit per end: decided on the device (pair_kernel.hip) ----
 	// status[k] = 1: the pair's two CIGAR requests and line descriptors exist on the device; the host neither lists rescue
@@ -1102,6 +1243,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	double pair_dev_ms = 0;
 	if (dev_pair && gpu_sam && gpu_aln) {
 		const double tp0 = now_ms();
+		stage(9);
 		PairParams pp;
 		memset(&pp, 0, sizeof pp);
 		pp.l_pac = bns->l_pac; pp.a = opt->a; pp.b = opt->b; pp.pen_unpaired = opt->pen_unpaired; pp.min_seed_len = opt->min_seed_len; pp.w = opt->w;
@@ -1135,6 +1277,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			double *ltab = tab + n_tab;
 			ltab[0] = 1.;
 			for (int l = 1; l < pp.ltab_n; ++l) ltab[l] = l < opt->mapQ_coef_len ? 1. : opt->mapQ_coef_fac / log(l);   // src/bwamem.c:964
+			stage(28);
 			uint8_t *ok = (uint8_t *)W.h_pr_ok.ensure((size_t)n_units + 64);
 			parallel_for(n_thr, n_units, 8192, [&](int k) {
 				ok[k] = !seqs[2 * k].comment && !seqs[2 * k + 1].comment && strcmp(seqs[2 * k].name, seqs[2 * k + 1].name) == 0;
@@ -1167,6 +1310,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	double cpu_msw = 0, cpu_collect = 0, cpu_emit = 0, sys_emit = 0;
 	long pf_emit = 0;
 	auto mcollect = [&](Part &P, int slot) {
+		stage(10);
 		if (!gpu_msw) return;
 		double ta = now_ms();
 		const double ca = cpu_sec();
@@ -1195,6 +1339,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		cpu_msw += cpu_sec() - ca;
 	};
 	auto mlaunch = [&](Part &P, int slot) {   // asynchronous
+		stage(11);
 		if (!gpu_msw || P.n_mreq == 0) return;
 		P.st = a_streams[slot];
 		int max_t = 1;
@@ -1217,6 +1362,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		P.m_launched = true;
 	};
 	auto mfinish = [&](Part &P) {
+		stage(12);
 		if (!P.m_launched) return;
 		double ta = now_ms();
 		stream_wait(P.st);
@@ -1229,6 +1375,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	// A: decisions + the list of CIGARs to compute.  Two rounds, so that the units that asked for no mate-rescue alignment
 	// (most of them) are done while msw_kernel is still running: round 0 = those units, round 1 = the rest + the flat list.
 	auto collect = [&](Part &P, int round) {
+		stage(13);
 		double ta = now_ms();
 		const double ca = cpu_sec();
 		const int nu = P.hi - P.lo, n_blk = (nu + 255) / 256;
@@ -1279,6 +1426,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	// The pairs decided on the device need nothing from the host any more: their CIGARs and records are queued right behind the
 	// pairing kernel, on a stream of their own, and run under the host's rescue listing, planning and the mate-rescue kernel.
 	auto launch_dev = [&](Part &P, int slot) {
+		stage(14);
 		if (!pstat) return;
 		Part::DevJob &J = P.dj;
 		const int nu = P.hi - P.lo, r0 = P.lo << 1, nr = nu << 1;
@@ -1315,6 +1463,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		J.launched = true;
 	};
 	auto finish_dev = [&](Part &P, int slot) {
+		stage(15);
 		Part::DevJob &J = P.dj;
 		if (!J.launched) return;
 		double ta = now_ms();
@@ -1325,7 +1474,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		STAT.n_aln += J.n_req;
 		unsigned long long used = 0;
 		HIP_OK(hipMemcpyAsync(&used, W.dj_used[slot].p, 8, hipMemcpyDeviceToHost, J.st));
-		HIP_OK(hipStreamSynchronize(J.st));
+		stream_wait(J.st);
 		used = std::min<unsigned long long>(used, J.arena_bytes);
 		uint8_t *ha = (uint8_t *)W.hj_arena[slot].ensure((size_t)used + 64);
 		unsigned long long *ho = (unsigned long long *)W.hj_ooff[slot].ensure((size_t)nr * 8 + 64);
@@ -1333,7 +1482,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		if (used) HIP_OK(hipMemcpyAsync(ha, W.dj_arena[slot].p, (size_t)used, hipMemcpyDeviceToHost, J.st));
 		HIP_OK(hipMemcpyAsync(ho, W.dj_ooff[slot].p, (size_t)nr * 8, hipMemcpyDeviceToHost, J.st));
 		HIP_OK(hipMemcpyAsync(hl, W.dj_olen[slot].p, (size_t)nr * 4, hipMemcpyDeviceToHost, J.st));
-		HIP_OK(hipStreamSynchronize(J.st));
+		stream_wait(J.st);
 		J.sarena = ha; J.sooff = ho; J.solen = hl;
 		// a record handed back (CIGAR declined, row overflow): the host redoes that pair and needs the CIGAR results of the job
 		bool any_back = false;
@@ -1352,6 +1501,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		aln_wait_ms += now_ms() - ta;
 	};
 	auto launch = [&](Part &P, int slot) {   // B (asynchronous)
+		stage(16);
 		const size_t n_req = P.req.size();
 		P.slot = slot;
 		if (!gpu_aln || n_req == 0) return;
@@ -1394,13 +1544,14 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		}
 	};
 	auto finish = [&](Part &P) {   // wait for B, fetch the pool
+		stage(17);
 		const size_t n_req = P.req.size();
 		if (!gpu_aln || n_req == 0) return;
 		double ta = now_ms();
 		stream_wait(P.st);
 		HIP_OK(hipGetLastError());
 		HIP_OK(hipMemcpyAsync(P.cnt, P.d_cnt, 64, hipMemcpyDeviceToHost, P.st));
-		HIP_OK(hipStreamSynchronize(P.st));
+		stream_wait(P.st);
 		STAT.k_aln_ms += P.ev.ms();
 		if (s_cpusec) {
 			unsigned long long c[16];
@@ -1412,13 +1563,13 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		P.pool = (uint8_t *)W.h_apool[P.slot].ensure(used + 64);
 		HIP_OK(hipMemcpyAsync(P.hdr, P.d_hdr, n_req * sizeof(AlnHdr), hipMemcpyDeviceToHost, P.st));
 		if (used) HIP_OK(hipMemcpyAsync(P.pool, P.d_pool, used, hipMemcpyDeviceToHost, P.st));
-		HIP_OK(hipStreamSynchronize(P.st));
+		stream_wait(P.st);
 		STAT.n_aln += n_req;
 		if (P.sam_launched) {
 			const int nr = (P.hi - P.lo) << 1;
 			unsigned long long used = 0;
 			HIP_OK(hipMemcpyAsync(&used, W.sused[P.slot].p, 8, hipMemcpyDeviceToHost, P.st));
-			HIP_OK(hipStreamSynchronize(P.st));
+			stream_wait(P.st);
 			used = std::min<unsigned long long>(used, P.arena_bytes);
 			uint8_t *ha = (uint8_t *)W.h_sarena[P.slot].ensure((size_t)used + 64);
 			unsigned long long *ho = (unsigned long long *)W.h_sooff[P.slot].ensure((size_t)nr * 8 + 64);
@@ -1426,7 +1577,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			if (used) HIP_OK(hipMemcpyAsync(ha, W.sarena[P.slot].p, (size_t)used, hipMemcpyDeviceToHost, P.st));
 			HIP_OK(hipMemcpyAsync(ho, W.sooff[P.slot].p, (size_t)nr * 8, hipMemcpyDeviceToHost, P.st));
 			HIP_OK(hipMemcpyAsync(hl, W.solen[P.slot].p, (size_t)nr * 4, hipMemcpyDeviceToHost, P.st));
-			HIP_OK(hipStreamSynchronize(P.st));
+			stream_wait(P.st);
 			P.sarena = ha; P.sooff = ho; P.solen = hl;
 		}
 		aln_wait_ms += now_ms() - ta;
@@ -1436,6 +1587,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	// which: 0 = the records of the pairs decided on the device (as soon as their job is back: the copies run under the kernels
 	// of the other pairs), 1 = everything else, 2 = both
 	auto replay = [&](Part &P, int which = 2) {   // C
+		stage(18);
 		const double ta = now_ms(), ca = cpu_sec(), sa_ = sys_sec();
 		const long pf = page_faults();
 		if (pe) {
@@ -1535,6 +1687,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	}
 	STAT.plan_ms += pair_dev_ms;
 	double t8 = now_ms();
+	stage(19);
 	hprof_report("sam stage");
 	if (s_cpusec) fprintf(stderr, "[plan Mcycles] sam_pe_plan %.0f  emit(collect) %.0f  device-record copy %.0f (%llu records)\n", tsc_plan.load() * 1e-6, tsc_emitc.load() * 1e-6, tsc_devcopy.load() * 1e-6, n_sam_dev.load());
 	if (g_hprof_on || s_cpusec)
