@@ -391,7 +391,7 @@ struct Workspace {
 	PinBuf h_nch, h_cbeg, h_ccnt, h_rbeg, h_nseeds, h_lrep, h_nintv;
 	// (every copy to or from the device uses page-locked host memory: a pageable target makes hipMemcpyAsync wait — spinning —
 	// for the kernels queued before it, and a pageable source is pinned page by page at every call)
-	PinBuf h_cnt, h_off, h_len, h_seed_off, h_small;
+	PinBuf h_cnt, h_off, h_len, h_seed_off, h_areq[2];
 	DevBuf nch, chain_cnt, reg_pos, regs_packed, ann_off, ann_alt, pack_tmp, order, chain_gen, c2a_stat;
 	PinBuf h_c2a_stat;
 	PinBuf h_order;
@@ -876,10 +876,34 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 				HIP_OK(hipMemcpyAsync(nch, d_nch, (size_t)n * 4, hipMemcpyDeviceToHost, st));
 			}
 			HIP_OK(hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, st));
-			HIP_OK(hipMemcpyAsync(sa, d_sa, (size_t)S * 8, hipMemcpyDeviceToHost, st));
-			HIP_OK(hipMemcpyAsync(qbl, d_qbl, (size_t)S * 8, hipMemcpyDeviceToHost, st));
+			// The seeds themselves (16 bytes each, 124 MB per chunk of 2x150 bp) only come back for the reads the host chains: all of
+			// them in host mode; in device mode the few reads chain_kernel declined, as a handful of spans once their list is known
+			// (one short round trip more) — or everything again when those reads are many (repeat-rich references).
+			bool seeds_fetched = false;
+			if (!dev_chain) {
+				HIP_OK(hipMemcpyAsync(sa, d_sa, (size_t)S * 8, hipMemcpyDeviceToHost, st));
+				HIP_OK(hipMemcpyAsync(qbl, d_qbl, (size_t)S * 8, hipMemcpyDeviceToHost, st));
+				seeds_fetched = true;
+			}
 			stream_wait(st);
 			HIP_OK(hipGetLastError());
+			if (!seeds_fetched) {
+				const int64_t GAP = 1 << 15;          // spans closer than this many seeds travel as one
+				std::vector<std::pair<int64_t, int64_t>> span;
+				int64_t covered = 0;
+				for (int i = 0; i < n; ++i) {
+					if (nch[i] >= 0 || nseeds[i] == 0) continue;
+					if (!span.empty() && seed_off[i] - span.back().second <= GAP) span.back().second = seed_off[i + 1];
+					else span.emplace_back(seed_off[i], seed_off[i + 1]);
+				}
+				for (auto &sp : span) covered += sp.second - sp.first;
+				if (span.size() > 256 || covered > S / 2) { span.clear(); span.emplace_back(0, S); }
+				for (auto &sp : span) {
+					HIP_OK(hipMemcpyAsync(sa + sp.first, d_sa + sp.first, (size_t)(sp.second - sp.first) * 8, hipMemcpyDeviceToHost, st));
+					HIP_OK(hipMemcpyAsync(qbl + 2 * sp.first, d_qbl + 2 * sp.first, (size_t)(sp.second - sp.first) * 8, hipMemcpyDeviceToHost, st));
+				}
+				if (!span.empty()) stream_wait(st);
+			}
 			ps.k_sa = ev_sa.ms();
 			ps.sa_bytes = ix.fm.sa_full ? (uint64_t)S * 16 : cnt[1] * 64 + (uint64_t)S * 8;
 		}
@@ -1189,7 +1213,8 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	if (const char *e = getenv("MPIBWA_SAM_PARTS")) n_parts = std::max(1, std::min(2, atoi(e)));
 	struct Part {
 		int lo = 0, hi = 0;
-		std::vector<AlnReqH> req;
+		AlnReqH *req = nullptr;           // CIGAR requests of the part, in a page-locked buffer of the call context
+		size_t n_req = 0;
 		std::vector<uint32_t> base;       // first request of every unit of the part
 		AlnHdrH *hdr = nullptr;           // results, in page-locked staging buffers
 		uint8_t *pool = nullptr;
@@ -1415,7 +1440,8 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		if (round == 1) {
 			P.base.assign(nu + 1, 0);
 			for (int i = 0; i < nu; ++i) P.base[i + 1] = P.base[i] + P.u_cnt[i];
-			P.req.resize(P.base[nu]);
+			P.n_req = P.base[nu];
+			P.req = (AlnReqH *)W.h_areq[&P - parts].ensure(P.n_req * sizeof(AlnReqH) + 64);
 			parallel_for(n_thr, nu, 4096, [&](int i) {
 				if (P.u_cnt[i]) memcpy(&P.req[P.base[i]], &P.blk_req[i >> 8][P.u_first[i]], (size_t)P.u_cnt[i] * sizeof(AlnReqH));
 			});
@@ -1502,7 +1528,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	};
 	auto launch = [&](Part &P, int slot) {   // B (asynchronous)
 		stage(16);
-		const size_t n_req = P.req.size();
+		const size_t n_req = P.n_req;
 		P.slot = slot;
 		if (!gpu_aln || n_req == 0) return;
 		static_assert(sizeof(AlnReq) == sizeof(AlnReqH) && sizeof(AlnHdr) == sizeof(AlnHdrH), "host/device record layouts differ");
@@ -1512,7 +1538,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		P.d_hdr = (AlnHdr *)(slot ? W.ahdr2 : W.ahdr).ensure(n_req * sizeof(AlnHdr));
 		P.d_pool = (uint8_t *)(slot ? W.apool2 : W.apool).ensure(P.pool_bytes);
 		P.d_cnt = (unsigned long long *)(slot ? W.acnt2 : W.acnt).ensure(256);
-		HIP_OK(hipMemcpyAsync(d_req, P.req.data(), n_req * sizeof(AlnReq), hipMemcpyHostToDevice, P.st));
+		HIP_OK(hipMemcpyAsync(d_req, P.req, n_req * sizeof(AlnReq), hipMemcpyHostToDevice, P.st));
 		HIP_OK(hipMemsetAsync(P.d_cnt, 0, 256, P.st));
 		AlnParams ap;
 		ap.l_pac = bns->l_pac; ap.a = opt->a; ap.w = opt->w;
@@ -1545,7 +1571,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	};
 	auto finish = [&](Part &P) {   // wait for B, fetch the pool
 		stage(17);
-		const size_t n_req = P.req.size();
+		const size_t n_req = P.n_req;
 		if (!gpu_aln || n_req == 0) return;
 		double ta = now_ms();
 		stream_wait(P.st);
