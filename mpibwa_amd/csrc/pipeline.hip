@@ -415,9 +415,13 @@ static const int MAX_LANES = 4;
 // the function at once (chunk i+1 seeding and extending on the GPU while the host pairs and prints chunk i — the stage that
 // keeps the GPU busy and the stage that keeps the host busy belong to different halves of a call).  A ninth caller waits.
 struct CallCtx {
-	Workspace ws[MAX_LANES];   // one per concurrent sub-batch
-	HostBuf reg_arena[16];     // one per sub-batch: the regions live until the SAM stage
+	// ws[0] / reg_arena[0]: the whole chunk in one piece (a call with neighbours in flight); ws[1 + lane] / reg_arena[1 + k]: the
+	// sub-batches of a lone call.  The two modes never share buffers: a context that has served both would otherwise regrow
+	// (hipFree + hipMalloc, which stall every stream) 65 buffers each time the mode changes to the bigger pieces.
+	Workspace ws[MAX_LANES + 1];
+	HostBuf reg_arena[17];     // the regions live until the SAM stage
 	Workspace gws;             // batch-wide buffers (packed reads, CIGAR requests)
+	Workspace gws_parts;       // the per-part buffers of a SAM stage that runs in two halves
 	hipStream_t p_streams[MAX_LANES] = {nullptr}, a_streams[2] = {nullptr, nullptr}, d_streams[2] = {nullptr, nullptr};
 	bool busy = false;
 	const bseq1_t *seq_lo = nullptr, *seq_hi = nullptr;   // the caller's array while the call runs
@@ -431,6 +435,9 @@ static std::condition_variable g_ctx_cv;
 struct CtxLease {
 	CallCtx *c = nullptr;
 	int others = 0;   // calls that were in flight when this one started
+	// ... or in the last two seconds: a caller that keeps several calls in flight is treated as such from its third call on, also
+	// when several of its calls happen to end together
+	bool crowded = false;
 	CtxLease(const bseq1_t *seqs, int n)
 	{
 		std::unique_lock<std::mutex> lk(g_ctx_mu);
@@ -448,6 +455,10 @@ struct CtxLease {
 				die("mem_process_seqs: called on seqs[] that another call in flight is still working on");
 		}
 		c->seq_lo = seqs; c->seq_hi = seqs + n;
+		static double last_crowded_ms = -1e30;   // (under g_ctx_mu)
+		const double now = now_ms();
+		if (others >= 2) last_crowded_ms = now;
+		crowded = now - last_crowded_ms < 2000.0;
 	}
 	~CtxLease()
 	{
@@ -1147,7 +1158,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	// kernel needs 23 ms for the chunk in one launch, 3 x 10 ms in three).
 	// (two sub-batches since round 3: with the pairing decisions on the device the host stages of a sub-batch are short, and a
 	// third sub-batch only adds a third tail to every big kernel: 93.5 vs 103-105 ms per chunk with one call in flight)
-	int n_sub = lease.others >= 2 ? 1 : 2, n_lanes = 2;
+	int n_sub = lease.crowded ? 1 : 2, n_lanes = 2;
 	if (const char *e = getenv("MPIBWA_SUBBATCH")) n_sub = atoi(e);
 	if (const char *e = getenv("MPIBWA_LANES")) n_lanes = atoi(e);
 	n_sub = std::max(1, std::min(n_sub, 16));
@@ -1170,7 +1181,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			for (;;) {
 				int k = next.fetch_add(1);
 				if (k >= n_sub) break;
-				phase1(cut[k], cut[k + 1], C.ws[l], C.reg_arena[k], s_streams[l], thr_each, ps[k]);
+				phase1(cut[k], cut[k + 1], C.ws[1 + l], C.reg_arena[1 + k], s_streams[l], thr_each, ps[k]);
 			}
 		};
 		std::vector<std::thread> th;
@@ -1251,6 +1262,8 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		const int *solen = nullptr;
 	};
 	Part parts[2];
+	// the per-part buffers of the SAM stage: a chunk in one part and a chunk in two halves use different sets (see CallCtx::ws)
+	Workspace &WS = n_parts == 1 ? C.gws : C.gws_parts;
 	hipStream_t *a_streams = C.a_streams;
 	double plan_ms = 0, aln_wait_ms = 0;
 
@@ -1355,8 +1368,8 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		P.mbase.assign(nu + 1, 0);
 		for (int i = 0; i < nu; ++i) P.mbase[i + 1] = P.mbase[i] + u_cnt[i];
 		P.n_mreq = P.mbase[nu];
-		P.mreq = (MswReqH *)W.h_mreq[slot].ensure(P.n_mreq * sizeof(MswReqH) + 64);
-		P.mres = (MswResH *)W.h_mres[slot].ensure(P.n_mreq * sizeof(MswResH) + 64);
+		P.mreq = (MswReqH *)WS.h_mreq[slot].ensure(P.n_mreq * sizeof(MswReqH) + 64);
+		P.mres = (MswResH *)WS.h_mres[slot].ensure(P.n_mreq * sizeof(MswResH) + 64);
 		parallel_for(n_thr, nu, 4096, [&](int i) {
 			if (u_cnt[i]) memcpy(&P.mreq[P.mbase[i]], &blk_req[i >> 8][u_first[i]], (size_t)u_cnt[i] * sizeof(MswReqH));
 		});
@@ -1369,12 +1382,12 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		P.st = a_streams[slot];
 		int max_t = 1;
 		for (size_t k = 0; k < P.n_mreq; ++k) max_t = std::max(max_t, (int)(P.mreq[k].re - P.mreq[k].rb));
-		MswReq *d_req = (MswReq *)W.mreq[slot].ensure(P.n_mreq * sizeof(MswReq));
-		MswRes *d_res = (MswRes *)W.mres[slot].ensure(P.n_mreq * sizeof(MswRes));
+		MswReq *d_req = (MswReq *)WS.mreq[slot].ensure(P.n_mreq * sizeof(MswReq));
+		MswRes *d_res = (MswRes *)WS.mres[slot].ensure(P.n_mreq * sizeof(MswRes));
 		// row-maximum scratch: at most 2 GiB at a time
 		size_t per = std::max<size_t>(64, (((size_t)1 << 31) / ((size_t)max_t * 2)) & ~(size_t)63);
 		per = std::min(per, (P.n_mreq + 63) & ~(size_t)63);
-		uint16_t *d_rows = (uint16_t *)W.mrows[slot].ensure(per * (size_t)max_t * 2);
+		uint16_t *d_rows = (uint16_t *)WS.mrows[slot].ensure(per * (size_t)max_t * 2);
 		HIP_OK(hipMemcpyAsync(d_req, P.mreq, P.n_mreq * sizeof(MswReq), hipMemcpyHostToDevice, P.st));
 		const MswParams mp = msw_params(opt, bns->l_pac);
 		P.mev.start(P.st);
@@ -1441,7 +1454,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			P.base.assign(nu + 1, 0);
 			for (int i = 0; i < nu; ++i) P.base[i + 1] = P.base[i] + P.u_cnt[i];
 			P.n_req = P.base[nu];
-			P.req = (AlnReqH *)W.h_areq[&P - parts].ensure(P.n_req * sizeof(AlnReqH) + 64);
+			P.req = (AlnReqH *)WS.h_areq[&P - parts].ensure(P.n_req * sizeof(AlnReqH) + 64);
 			parallel_for(n_thr, nu, 4096, [&](int i) {
 				if (P.u_cnt[i]) memcpy(&P.req[P.base[i]], &P.blk_req[i >> 8][P.u_first[i]], (size_t)P.u_cnt[i] * sizeof(AlnReqH));
 			});
@@ -1460,28 +1473,28 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		if (!J.n_req) return;
 		J.st = C.d_streams[slot];
 		J.pool_bytes = J.n_req * 96 + ((size_t)48 << 20);
-		J.d_hdr = (AlnHdr *)W.dj_hdr[slot].ensure(J.n_req * sizeof(AlnHdr));
-		J.d_pool = (uint8_t *)W.dj_pool[slot].ensure(J.pool_bytes);
-		J.d_cnt = (unsigned long long *)W.dj_cnt[slot].ensure(256);
+		J.d_hdr = (AlnHdr *)WS.dj_hdr[slot].ensure(J.n_req * sizeof(AlnHdr));
+		J.d_pool = (uint8_t *)WS.dj_pool[slot].ensure(J.pool_bytes);
+		J.d_cnt = (unsigned long long *)WS.dj_cnt[slot].ensure(256);
 		HIP_OK(hipMemsetAsync(J.d_cnt, 0, 256, J.st));
 		AlnParams ap;
 		ap.l_pac = bns->l_pac; ap.a = opt->a; ap.w = opt->w;
 		ExtParams ep;
 		memcpy(ep.mat, opt->mat, 25);
 		ep.o_del = opt->o_del; ep.e_del = opt->e_del; ep.o_ins = opt->o_ins; ep.e_ins = opt->e_ins; ep.zdrop = opt->zdrop;
-		int *d_lists = (int *)W.dj_list[slot].ensure(J.n_req * 3 * sizeof(int));
+		int *d_lists = (int *)WS.dj_list[slot].ensure(J.n_req * 3 * sizeof(int));
 		J.ev.start(J.st);
 		launch_aln(J.st, ap, ep, (int)J.n_req, d_pr_req + r0, d_seq, d_off, (const uint8_t *)ix.d_pac, d_gap, J.d_hdr, J.d_pool, J.d_cnt, J.pool_bytes, max_len,
 		           max_len + 256, d_lists);
 		J.ev.stop(J.st);
-		int *hb = (int *)W.hj_base[slot].ensure((size_t)(nu + 1) * 4 + 64);
+		int *hb = (int *)WS.hj_base[slot].ensure((size_t)(nu + 1) * 4 + 64);
 		for (int k = 0; k <= nu; ++k) hb[k] = 2 * k;
-		int *d_base = (int *)W.dj_base[slot].ensure((size_t)(nu + 1) * 4);
+		int *d_base = (int *)WS.dj_base[slot].ensure((size_t)(nu + 1) * 4);
 		J.arena_bytes = (size_t)nr * (size_t)(2 * max_len + 320) + (1 << 20);
-		uint8_t *d_arena = (uint8_t *)W.dj_arena[slot].ensure(J.arena_bytes);
-		unsigned long long *d_used = (unsigned long long *)W.dj_used[slot].ensure(64);
-		unsigned long long *d_ooff = (unsigned long long *)W.dj_ooff[slot].ensure((size_t)nr * 8);
-		int *d_olen = (int *)W.dj_olen[slot].ensure((size_t)nr * 4);
+		uint8_t *d_arena = (uint8_t *)WS.dj_arena[slot].ensure(J.arena_bytes);
+		unsigned long long *d_used = (unsigned long long *)WS.dj_used[slot].ensure(64);
+		unsigned long long *d_ooff = (unsigned long long *)WS.dj_ooff[slot].ensure((size_t)nr * 8);
+		int *d_olen = (int *)WS.dj_olen[slot].ensure((size_t)nr * 4);
 		HIP_OK(hipMemcpyAsync(d_base, hb, (size_t)(nu + 1) * 4, hipMemcpyHostToDevice, J.st));
 		HIP_OK(hipMemsetAsync(d_used, 0, 64, J.st));
 		launch_sam_emit(J.st, sam_par, nr, d_pr_desc + r0, d_base, J.d_hdr, J.d_pool, d_seq, d_off + r0, d_len + r0, d_qual, d_names, d_noff + r0, d_ann_off,
@@ -1499,15 +1512,15 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		STAT.k_aln_ms += J.ev.ms();
 		STAT.n_aln += J.n_req;
 		unsigned long long used = 0;
-		HIP_OK(hipMemcpyAsync(&used, W.dj_used[slot].p, 8, hipMemcpyDeviceToHost, J.st));
+		HIP_OK(hipMemcpyAsync(&used, WS.dj_used[slot].p, 8, hipMemcpyDeviceToHost, J.st));
 		stream_wait(J.st);
 		used = std::min<unsigned long long>(used, J.arena_bytes);
-		uint8_t *ha = (uint8_t *)W.hj_arena[slot].ensure((size_t)used + 64);
-		unsigned long long *ho = (unsigned long long *)W.hj_ooff[slot].ensure((size_t)nr * 8 + 64);
-		int *hl = (int *)W.hj_olen[slot].ensure((size_t)nr * 4 + 64);
-		if (used) HIP_OK(hipMemcpyAsync(ha, W.dj_arena[slot].p, (size_t)used, hipMemcpyDeviceToHost, J.st));
-		HIP_OK(hipMemcpyAsync(ho, W.dj_ooff[slot].p, (size_t)nr * 8, hipMemcpyDeviceToHost, J.st));
-		HIP_OK(hipMemcpyAsync(hl, W.dj_olen[slot].p, (size_t)nr * 4, hipMemcpyDeviceToHost, J.st));
+		uint8_t *ha = (uint8_t *)WS.hj_arena[slot].ensure((size_t)used + 64);
+		unsigned long long *ho = (unsigned long long *)WS.hj_ooff[slot].ensure((size_t)nr * 8 + 64);
+		int *hl = (int *)WS.hj_olen[slot].ensure((size_t)nr * 4 + 64);
+		if (used) HIP_OK(hipMemcpyAsync(ha, WS.dj_arena[slot].p, (size_t)used, hipMemcpyDeviceToHost, J.st));
+		HIP_OK(hipMemcpyAsync(ho, WS.dj_ooff[slot].p, (size_t)nr * 8, hipMemcpyDeviceToHost, J.st));
+		HIP_OK(hipMemcpyAsync(hl, WS.dj_olen[slot].p, (size_t)nr * 4, hipMemcpyDeviceToHost, J.st));
 		stream_wait(J.st);
 		J.sarena = ha; J.sooff = ho; J.solen = hl;
 		// a record handed back (CIGAR declined, row overflow): the host redoes that pair and needs the CIGAR results of the job
@@ -1518,8 +1531,8 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			unsigned long long cnt8[8];
 			HIP_OK(hipMemcpy(cnt8, J.d_cnt, sizeof cnt8, hipMemcpyDeviceToHost));
 			const size_t pu = std::min<size_t>(cnt8[0], J.pool_bytes);
-			AlnHdrH *hh = (AlnHdrH *)W.hj_hdr[slot].ensure(J.n_req * sizeof(AlnHdr) + 64);
-			uint8_t *hp = (uint8_t *)W.hj_pool[slot].ensure(pu + 64);
+			AlnHdrH *hh = (AlnHdrH *)WS.hj_hdr[slot].ensure(J.n_req * sizeof(AlnHdr) + 64);
+			uint8_t *hp = (uint8_t *)WS.hj_pool[slot].ensure(pu + 64);
 			HIP_OK(hipMemcpy(hh, J.d_hdr, J.n_req * sizeof(AlnHdr), hipMemcpyDeviceToHost));
 			if (pu) HIP_OK(hipMemcpy(hp, J.d_pool, pu, hipMemcpyDeviceToHost));
 			J.hdr = hh; J.pool = hp;
@@ -1534,10 +1547,10 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		static_assert(sizeof(AlnReq) == sizeof(AlnReqH) && sizeof(AlnHdr) == sizeof(AlnHdrH), "host/device record layouts differ");
 		P.st = a_streams[slot];
 		P.pool_bytes = n_req * 96 + ((size_t)48 << 20);   // + room for the partly used last slab of every wave (aln_kernel.hip: ALN_SLAB)
-		AlnReq *d_req = (AlnReq *)(slot ? W.areq2 : W.areq).ensure(n_req * sizeof(AlnReq));
-		P.d_hdr = (AlnHdr *)(slot ? W.ahdr2 : W.ahdr).ensure(n_req * sizeof(AlnHdr));
-		P.d_pool = (uint8_t *)(slot ? W.apool2 : W.apool).ensure(P.pool_bytes);
-		P.d_cnt = (unsigned long long *)(slot ? W.acnt2 : W.acnt).ensure(256);
+		AlnReq *d_req = (AlnReq *)(slot ? WS.areq2 : WS.areq).ensure(n_req * sizeof(AlnReq));
+		P.d_hdr = (AlnHdr *)(slot ? WS.ahdr2 : WS.ahdr).ensure(n_req * sizeof(AlnHdr));
+		P.d_pool = (uint8_t *)(slot ? WS.apool2 : WS.apool).ensure(P.pool_bytes);
+		P.d_cnt = (unsigned long long *)(slot ? WS.acnt2 : WS.acnt).ensure(256);
 		HIP_OK(hipMemcpyAsync(d_req, P.req, n_req * sizeof(AlnReq), hipMemcpyHostToDevice, P.st));
 		HIP_OK(hipMemsetAsync(P.d_cnt, 0, 256, P.st));
 		AlnParams ap;
@@ -1546,21 +1559,21 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		memcpy(ep.mat, opt->mat, 25);
 		ep.o_del = opt->o_del; ep.e_del = opt->e_del; ep.o_ins = opt->o_ins; ep.e_ins = opt->e_ins; ep.zdrop = opt->zdrop;
 		P.ev.start(P.st);
-		int *d_lists = (int *)W.alist[slot].ensure(n_req * 3 * sizeof(int));
+		int *d_lists = (int *)WS.alist[slot].ensure(n_req * 3 * sizeof(int));
 		launch_aln(P.st, ap, ep, (int)n_req, d_req, d_seq, d_off, (const uint8_t *)ix.d_pac, d_gap, P.d_hdr, P.d_pool, P.d_cnt, P.pool_bytes, max_len,
 		           max_len + 256, d_lists);
 		P.ev.stop(P.st);   // results are fetched in finish(): a D2H copy into pageable memory would block the host here
 		if (gpu_sam) {   // the records of the part's qualifying pairs, queued right behind their CIGARs
 			const int r0 = P.lo << 1, nr = (P.hi - P.lo) << 1, nu = P.hi - P.lo;
 			SamDesc *d_desc = (SamDesc *)W.sdesc.ensure((size_t)n * sizeof(SamDesc));
-			int *hb = (int *)W.h_sbase[slot].ensure((size_t)(nu + 1) * 4 + 64);
+			int *hb = (int *)WS.h_sbase[slot].ensure((size_t)(nu + 1) * 4 + 64);
 			for (int k = 0; k <= nu; ++k) hb[k] = (int)P.base[k];
-			int *d_base = (int *)W.sbase[slot].ensure((size_t)(nu + 1) * 4);
+			int *d_base = (int *)WS.sbase[slot].ensure((size_t)(nu + 1) * 4);
 			P.arena_bytes = (size_t)nr * (size_t)(2 * max_len + 320) + (1 << 20);
-			uint8_t *d_arena = (uint8_t *)W.sarena[slot].ensure(P.arena_bytes);
-			unsigned long long *d_used = (unsigned long long *)W.sused[slot].ensure(64);
-			unsigned long long *d_ooff = (unsigned long long *)W.sooff[slot].ensure((size_t)nr * 8);
-			int *d_olen = (int *)W.solen[slot].ensure((size_t)nr * 4);
+			uint8_t *d_arena = (uint8_t *)WS.sarena[slot].ensure(P.arena_bytes);
+			unsigned long long *d_used = (unsigned long long *)WS.sused[slot].ensure(64);
+			unsigned long long *d_ooff = (unsigned long long *)WS.sooff[slot].ensure((size_t)nr * 8);
+			int *d_olen = (int *)WS.solen[slot].ensure((size_t)nr * 4);
 			HIP_OK(hipMemcpyAsync(d_desc + r0, sdesc + r0, (size_t)nr * sizeof(SamDesc), hipMemcpyHostToDevice, P.st));
 			HIP_OK(hipMemcpyAsync(d_base, hb, (size_t)(nu + 1) * 4, hipMemcpyHostToDevice, P.st));
 			HIP_OK(hipMemsetAsync(d_used, 0, 64, P.st));
@@ -1585,8 +1598,8 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			fprintf(stderr, "[aln lists] %zu requests: same-length %llu, narrow DP %llu, full DP %llu\n", n_req, c[8], c[9], c[10]);
 		}
 		size_t used = std::min<size_t>(P.cnt[0], P.pool_bytes);
-		P.hdr = (AlnHdrH *)W.h_ahdr[P.slot].ensure(n_req * sizeof(AlnHdr) + 64);
-		P.pool = (uint8_t *)W.h_apool[P.slot].ensure(used + 64);
+		P.hdr = (AlnHdrH *)WS.h_ahdr[P.slot].ensure(n_req * sizeof(AlnHdr) + 64);
+		P.pool = (uint8_t *)WS.h_apool[P.slot].ensure(used + 64);
 		HIP_OK(hipMemcpyAsync(P.hdr, P.d_hdr, n_req * sizeof(AlnHdr), hipMemcpyDeviceToHost, P.st));
 		if (used) HIP_OK(hipMemcpyAsync(P.pool, P.d_pool, used, hipMemcpyDeviceToHost, P.st));
 		stream_wait(P.st);
@@ -1594,15 +1607,15 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		if (P.sam_launched) {
 			const int nr = (P.hi - P.lo) << 1;
 			unsigned long long used = 0;
-			HIP_OK(hipMemcpyAsync(&used, W.sused[P.slot].p, 8, hipMemcpyDeviceToHost, P.st));
+			HIP_OK(hipMemcpyAsync(&used, WS.sused[P.slot].p, 8, hipMemcpyDeviceToHost, P.st));
 			stream_wait(P.st);
 			used = std::min<unsigned long long>(used, P.arena_bytes);
-			uint8_t *ha = (uint8_t *)W.h_sarena[P.slot].ensure((size_t)used + 64);
-			unsigned long long *ho = (unsigned long long *)W.h_sooff[P.slot].ensure((size_t)nr * 8 + 64);
-			int *hl = (int *)W.h_solen[P.slot].ensure((size_t)nr * 4 + 64);
-			if (used) HIP_OK(hipMemcpyAsync(ha, W.sarena[P.slot].p, (size_t)used, hipMemcpyDeviceToHost, P.st));
-			HIP_OK(hipMemcpyAsync(ho, W.sooff[P.slot].p, (size_t)nr * 8, hipMemcpyDeviceToHost, P.st));
-			HIP_OK(hipMemcpyAsync(hl, W.solen[P.slot].p, (size_t)nr * 4, hipMemcpyDeviceToHost, P.st));
+			uint8_t *ha = (uint8_t *)WS.h_sarena[P.slot].ensure((size_t)used + 64);
+			unsigned long long *ho = (unsigned long long *)WS.h_sooff[P.slot].ensure((size_t)nr * 8 + 64);
+			int *hl = (int *)WS.h_solen[P.slot].ensure((size_t)nr * 4 + 64);
+			if (used) HIP_OK(hipMemcpyAsync(ha, WS.sarena[P.slot].p, (size_t)used, hipMemcpyDeviceToHost, P.st));
+			HIP_OK(hipMemcpyAsync(ho, WS.sooff[P.slot].p, (size_t)nr * 8, hipMemcpyDeviceToHost, P.st));
+			HIP_OK(hipMemcpyAsync(hl, WS.solen[P.slot].p, (size_t)nr * 4, hipMemcpyDeviceToHost, P.st));
 			stream_wait(P.st);
 			P.sarena = ha; P.sooff = ho; P.solen = hl;
 		}
@@ -1669,7 +1682,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	// pairs' job (their kernels fill the gaps anyway and an early launch only delays their seeding: 12.0-12.7 vs 10.9-11.3 Mreads/s).
 	// MPIBWA_DEV_JOB_LATE=0/1 forces either.
 	const char *dle = getenv("MPIBWA_DEV_JOB_LATE");
-	const bool dev_late = dle ? atoi(dle) != 0 : lease.others >= 2;
+	const bool dev_late = dle ? atoi(dle) != 0 : lease.crowded;
 	if (n_parts == 1) {
 		parts[0].lo = 0; parts[0].hi = n_units;
 		if (!dev_late) launch_dev(parts[0], 0);
