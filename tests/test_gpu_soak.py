@@ -1,4 +1,4 @@
-"""Soak: 60 chunks of four different sizes from four caller threads in flight.  Device memory must stay where it is once
+"""Soak: 60 chunks (after two warm-up rounds) of four different sizes from four caller threads in flight.  Device memory must stay where it is once
 every call context has seen its largest chunk, and the resident set must not creep (the SAM strings are allocated by the
 library's helper threads and freed by the caller: per-thread malloc arenas are where such a creep comes from)."""
 import ctypes as C
@@ -33,8 +33,15 @@ def test_sixty_chunks_leave_memory_where_it_was(genome, built):
     steps, lock, todo = 60, threading.Lock(), iter(range(60))
     marks = {}
 
+    gate = threading.Barrier(4)
+
     def caller(t):
         b = batches[t]
+        for _ in range(2):   # two rounds started together: all four call contexts are in use at once and get their work buffers
+            gate.wait(timeout=600)
+            eng.process_batch(opt, b)
+            p = lib.mi355x_collect_sam(b.arr, b.n, C.byref(C.c_size_t(0)))
+            api.libc.free(C.c_void_p(p))
         while True:
             with lock:
                 s = next(todo, None)
