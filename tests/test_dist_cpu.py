@@ -26,7 +26,8 @@ WORKER = textwrap.dedent("""
     elapsed = 0.25 * (rank + 1)
     out = {"rank": rank, "world": world, "lo": lo, "hi": hi, "n_sum": D.sum_over_ranks(d, len(mine)),
            "t_max": D.max_over_ranks(d, elapsed), "digest": digest}
-    print("RESULT " + json.dumps(out), flush=True)
+    sys.stdout.write(chr(10) + "RESULT " + json.dumps(out) + chr(10))   # one write: the ranks share the pipe
+    sys.stdout.flush()
     d.destroy_process_group()
 """) % ROOT
 
@@ -67,7 +68,8 @@ WORKER2 = textwrap.dedent("""
             h.update(C.string_at(int(rec["name"][i])) + b"|" + C.string_at(int(rec["seq"][i])) + b"|" + C.string_at(int(rec["qual"][i])) + b"\\n")
     out = {"rank": rank, "n_chunks": src.n_chunks, "lo": lo, "hi": hi, "reads": reads, "reads_all": D.sum_over_ranks(d, reads), "md5": h.hexdigest(),
            "starts": [int(x) for x in src.starts]}
-    print("RESULT " + json.dumps(out), flush=True)
+    sys.stdout.write(chr(10) + "RESULT " + json.dumps(out) + chr(10))   # one write: the ranks share the pipe
+    sys.stdout.flush()
     d.destroy_process_group()
 """) % ROOT
 
@@ -94,7 +96,7 @@ def test_two_ranks_shard_the_chunks_of_real_fastq_files(tmp_path, built):
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=240)
     assert r.returncode == 0, r.stderr[-2000:]
     import re
-    res = sorted((json.loads(m) for m in re.findall(r"RESULT (\{.*\})", r.stdout)), key=lambda x: x["rank"])
+    res = sorted((json.loads(m) for m in re.findall(r"RESULT (\{[^{}]*\})", r.stdout)), key=lambda x: x["rank"])
     assert len(res) == 2 and res[0]["starts"] == res[1]["starts"] and res[0]["n_chunks"] >= 4
     assert res[0]["lo"] == 0 and res[0]["hi"] == res[1]["lo"] and res[1]["hi"] == res[0]["n_chunks"]
     assert res[0]["reads"] + res[1]["reads"] == 2 * len(reads) == int(res[0]["reads_all"])
