@@ -239,6 +239,45 @@ def test_calls_in_flight_from_several_threads(both, reads_pe, monkeypatch):
 
 
 @needs_ref
+def test_work_buffers_stand_still_once_a_caller_is_warm(both, reads_pe, monkeypatch):
+    """A lone caller and a caller with several calls in flight use work buffers of their own (whole chunk / sub-batches, one
+    part / two parts of the SAM stage): once a context has seen a chunk in its mode, the same chunk again allocates nothing —
+    a reallocation stalls every stream of the device (mi355x_buffer_growths counts them)."""
+    import threading
+    import time
+    eng, ref = both
+    ra = simulate.reads_to_ascii(reads_pe)
+    monkeypatch.setenv("MPIBWA_SUBBATCH_MIN", "100")   # sub-batches and the two-part SAM stage as for big chunks
+    opt = eng.opt(flag=abi.MEM_F_PE)
+    want = ref.process(ref.opt(flag=abi.MEM_F_PE), ra)
+    time.sleep(2.1)                                    # (an earlier test's burst of calls is forgotten after two seconds)
+    for _ in range(2):
+        assert eng.process(opt, ra) == want            # lone caller: warm
+    g0 = int(eng.lib.mi355x_buffer_growths())
+    assert eng.process(opt, ra) == want
+    assert int(eng.lib.mi355x_buffer_growths()) == g0
+    gate, bad = threading.Barrier(4), []
+
+    def caller(rounds):
+        for _ in range(rounds):
+            gate.wait(timeout=600)
+            if eng.process(opt, ra) != want:
+                bad.append(1)
+
+    def burst(rounds):
+        th = [threading.Thread(target=caller, args=(rounds,)) for _ in range(4)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+    burst(3)                                           # four calls in flight, started together: every context warm in the busy mode
+    g1 = int(eng.lib.mi355x_buffer_growths())
+    burst(3)
+    assert not bad
+    assert int(eng.lib.mi355x_buffer_growths()) == g1
+
+
+@needs_ref
 def test_long_indels_take_the_wide_band_paths(both, genome):
     """Reads with insertions / deletions of 8 to 40 bp: their CIGARs need bands beyond the narrow direction matrix (the
     full-size variant of the CIGAR kernel, and the host for the few that outgrow that too).  Same bytes as the reference."""
