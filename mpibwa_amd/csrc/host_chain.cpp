@@ -246,7 +246,7 @@ struct ChainScratch::Impl {
 	std::vector<HChain> pool;
 	size_t used = 0;
 	std::vector<BTree::Node> nodes;
-	std::vector<int> order, kept;
+	std::vector<int> order, kept, kcol;
 };
 ChainScratch::ChainScratch() : p(new Impl()) {}
 ChainScratch::~ChainScratch() { delete p; }
@@ -321,34 +321,50 @@ void chain_filter(const mem_opt_t *opt, ChainScratch &S, std::vector<HChain *> &
 	int n = (int)a.size();
 	if (n == 0) return;   // (the reference would index a[0] here; min_chain_weight = 0 by default so this cannot happen there)
 	ks_introsort((size_t)n, a.data(), [](const HChain *x, const HChain *y) { return x->w > y->w; });
-	std::vector<int> &kept = S.p->kept;   // indices of chains that survived so far
+	// The chains that survived so far, as columns (query span, weight, ALT flag, the first chain each one shadows): a read of a
+	// high-copy repeat has hundreds of chains of equal weight that all overlap and all survive, so the test below runs n^2 / 2
+	// times — over contiguous ints instead of through every chain's seed vector (same comparisons, same order, same result).
+	ChainScratch::Impl &W = *S.p;
+	std::vector<int> &kept = W.kept;
 	kept.clear();
+	W.kcol.resize((size_t)5 * n);
+	int *kbeg = W.kcol.data(), *kend = kbeg + n, *kw = kend + n, *kalt = kw + n, *kfirst = kalt + n;
+	int nk = 0;
+	auto keep = [&](int i) {
+		kept.push_back(i);
+		kbeg[nk] = CHN_BEG(a[i]); kend[nk] = CHN_END(a[i]); kw[nk] = (int)a[i]->w; kalt[nk] = a[i]->is_alt ? 1 : 0; kfirst[nk] = -1;
+		++nk;
+	};
 	a[0]->kept = 3;
-	kept.push_back(0);
+	keep(0);
+	const float mask_level = opt->mask_level, drop_ratio = opt->drop_ratio;
+	const int max_chain_gap = opt->max_chain_gap, two_seeds = opt->min_seed_len << 1;
 	for (int i = 1; i < n; ++i) {
 		bool large_ovlp = false;
-		size_t kk;
-		for (kk = 0; kk < kept.size(); ++kk) {
-			int j = kept[kk];
-			int b_max = CHN_BEG(a[j]) > CHN_BEG(a[i]) ? CHN_BEG(a[j]) : CHN_BEG(a[i]);
-			int e_min = CHN_END(a[j]) < CHN_END(a[i]) ? CHN_END(a[j]) : CHN_END(a[i]);
-			if (e_min > b_max && (!a[j]->is_alt || a[i]->is_alt)) {
-				int li = CHN_END(a[i]) - CHN_BEG(a[i]), lj = CHN_END(a[j]) - CHN_BEG(a[j]);
-				int min_l = li < lj ? li : lj;
-				if (e_min - b_max >= min_l * opt->mask_level && min_l < opt->max_chain_gap) {
+		const int bi = CHN_BEG(a[i]), ei = CHN_END(a[i]), li = ei - bi, wi = (int)a[i]->w, alt_i = a[i]->is_alt ? 1 : 0;
+		int kk;
+		for (kk = 0; kk < nk; ++kk) {
+			const int b_max = kbeg[kk] > bi ? kbeg[kk] : bi;
+			const int e_min = kend[kk] < ei ? kend[kk] : ei;
+			if (e_min > b_max && (!kalt[kk] || alt_i)) {
+				const int lj = kend[kk] - kbeg[kk];
+				const int min_l = li < lj ? li : lj;
+				if (e_min - b_max >= min_l * mask_level && min_l < max_chain_gap) {
 					large_ovlp = true;
-					if (a[j]->first < 0) a[j]->first = i;
-					if ((int)a[i]->w < (int)a[j]->w * opt->drop_ratio && (int)a[j]->w - (int)a[i]->w >= opt->min_seed_len << 1) break;
+					if (kfirst[kk] < 0) kfirst[kk] = i;
+					if (wi < kw[kk] * drop_ratio && kw[kk] - wi >= two_seeds) break;
 				}
 			}
 		}
-		if (kk == kept.size()) {
-			kept.push_back(i);
+		if (kk == nk) {
 			a[i]->kept = large_ovlp ? 2 : 3;
+			keep(i);
 		}
 	}
-	for (int j : kept)
-		if (a[j]->first >= 0) a[a[j]->first]->kept = 1;
+	for (int kk = 0; kk < nk; ++kk) {
+		a[kept[kk]]->first = kfirst[kk];
+		if (kfirst[kk] >= 0) a[kfirst[kk]]->kept = 1;
+	}
 	int i = 0, cnt = 0;
 	for (; i < n; ++i) {   // at most max_chain_extend chains with kept = 1 or 2 are extended
 		if (a[i]->kept == 0 || a[i]->kept == 3) continue;

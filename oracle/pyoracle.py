@@ -302,7 +302,7 @@ def ref_chains(opt, bns, read_len, intervals, do_flt=True):
         iv[k] = (len(sa), 0, len(rbs), (qb << 32) | qe)
         sa += list(rbs)
     sa = np.array(sa if sa else [0], dtype=np.int64)
-    cap = 16 + 8 * n + 4 * len(sa) + 64
+    cap = 16 + 8 * n + 12 * len(sa) + 64   # (a chain of its own per hit: 6 + 3 numbers each)
     out = np.zeros(cap, dtype=np.int64)
     got = lib.inj_chain(opt, bns, int(read_len), n, iv.ctypes.data, sa.ctypes.data, 1 if do_flt else 0, out.ctypes.data, cap)
     assert got >= 0

@@ -47,6 +47,32 @@ def adversarial_interval_sets(rng, n_cases, l_pac, offs, n_seqs):
 
 
 
+def repeat_like_interval_sets(rng, n_cases, l_pac, offs, n_seqs):
+    """Reads of a high-copy repeat: two or three intervals with 100 to 400 hits each at unrelated positions, so mem_chain_flt
+    sees hundreds of chains of (nearly) equal weight that overlap completely on the query and mostly all survive — the quadratic
+    case of its kept-list scan."""
+    cases = []
+    for it in range(n_cases):
+        lq = int(rng.choice([100, 150, 250]))
+        n_copy = int(rng.integers(100, 400))
+        copies = []
+        for _ in range(n_copy):
+            k = int(rng.integers(0, n_seqs))
+            p = int(rng.integers(offs[k], max(offs[k] + 1, offs[k + 1] - lq - 1)))
+            if rng.random() < 0.5:
+                p = max(2 * l_pac - 1 - p - lq, l_pac)
+            copies.append(p)
+        ivs = {}
+        for j in range(int(rng.integers(2, 4))):
+            qb = int(rng.integers(0, lq - 40))
+            ln = int(rng.integers(19, min(lq - qb, 60) + 1))
+            # most copies carry the interval at its place, some a little off (a gap in the copy), some not at all
+            hits = sorted(min(max(c + qb + int(rng.choice([0, 0, 0, 0, 2, -3])), 0), 2 * l_pac - ln - 1) for c in copies if rng.random() < 0.9)
+            ivs[(qb, qb + ln)] = hits
+        cases.append((lq, [(qb, qe, h) for (qb, qe), h in ivs.items()]))
+    return cases
+
+
 def reference_chains(ref, ropt, cases):
     """-> (read lengths, seeds per read in mem_chain's visiting order, expected chains [(rid, frac_rep bits, seeds)])"""
     lens, seedsets, want = [], [], []
