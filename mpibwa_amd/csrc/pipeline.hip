@@ -415,13 +415,15 @@ static const int MAX_LANES = 4;
 // the function at once (chunk i+1 seeding and extending on the GPU while the host pairs and prints chunk i — the stage that
 // keeps the GPU busy and the stage that keeps the host busy belong to different halves of a call).  A ninth caller waits.
 struct CallCtx {
-	// ws[0] / reg_arena[0]: the whole chunk in one piece (a call with neighbours in flight); ws[1 + lane] / reg_arena[1 + k]: the
-	// sub-batches of a lone call.  The two modes never share buffers: a context that has served both would otherwise regrow
-	// (hipFree + hipMalloc, which stall every stream) 65 buffers each time the mode changes to the bigger pieces.
+	// ws[lane] / reg_arena[k]: a call with neighbours in flight runs its chunk in one piece through ws[0], a lone call its two
+	// sub-batches through ws[0] and ws[1].  The buffers only grow, so a context that has served a lone call regrows ws[0] ONCE,
+	// at its first whole chunk (65 buffers: hipFree + hipMalloc stall every stream) — a caller that wants that out of its
+	// measurements starts its first rounds of calls together, as bench.py's warm-up does.  (Separate buffer sets per mode
+	// were tried: no regrowth at all, but twice the footprint in the first two contexts, and the repeat-rich workload of §6.1
+	// no longer fitted with four calls in flight.)
 	Workspace ws[MAX_LANES + 1];
 	HostBuf reg_arena[17];     // the regions live until the SAM stage
 	Workspace gws;             // batch-wide buffers (packed reads, CIGAR requests)
-	Workspace gws_parts;       // the per-part buffers of a SAM stage that runs in two halves
 	hipStream_t p_streams[MAX_LANES] = {nullptr}, a_streams[2] = {nullptr, nullptr}, d_streams[2] = {nullptr, nullptr};
 	bool busy = false;
 	const bseq1_t *seq_lo = nullptr, *seq_hi = nullptr;   // the caller's array while the call runs
@@ -1181,7 +1183,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			for (;;) {
 				int k = next.fetch_add(1);
 				if (k >= n_sub) break;
-				phase1(cut[k], cut[k + 1], C.ws[1 + l], C.reg_arena[1 + k], s_streams[l], thr_each, ps[k]);
+				phase1(cut[k], cut[k + 1], C.ws[l], C.reg_arena[k], s_streams[l], thr_each, ps[k]);
 			}
 		};
 		std::vector<std::thread> th;
@@ -1262,8 +1264,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		const int *solen = nullptr;
 	};
 	Part parts[2];
-	// the per-part buffers of the SAM stage: a chunk in one part and a chunk in two halves use different sets (see CallCtx::ws)
-	Workspace &WS = n_parts == 1 ? C.gws : C.gws_parts;
+	Workspace &WS = C.gws;   // the per-part buffers of the SAM stage (slot 0: the whole chunk or its first half)
 	hipStream_t *a_streams = C.a_streams;
 	double plan_ms = 0, aln_wait_ms = 0;
 
