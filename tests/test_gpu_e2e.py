@@ -240,8 +240,8 @@ def test_calls_in_flight_from_several_threads(both, reads_pe, monkeypatch):
 
 @needs_ref
 def test_work_buffers_stand_still_once_a_caller_is_warm(both, reads_pe, monkeypatch):
-    """A lone caller and a caller with several calls in flight use work buffers of their own (whole chunk / sub-batches, one
-    part / two parts of the SAM stage): once a context has seen a chunk in its mode, the same chunk again allocates nothing —
+    """A lone caller runs its chunk in sub-batches, a caller with several calls in flight in one piece, through the same
+    grow-only work buffers: once a context has seen a chunk in the bigger of its modes, the same chunk again allocates nothing —
     a reallocation stalls every stream of the device (mi355x_buffer_growths counts them)."""
     import threading
     import time
