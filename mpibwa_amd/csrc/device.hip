@@ -39,7 +39,7 @@ void *DevBuf::ensure(size_t bytes)
 		if (hipMalloc(&p, want) != hipSuccess) {
 			size_t fr = 0, tot = 0;
 			(void)hipMemGetInfo(&fr, &tot);
-			die("device work buffer of %.2f GB does not fit: %.1f of %.1f GB free (index, dense SA and the work buffers of up to eight calls in flight share the HBM)",
+			die("device work buffer of %.2f GB does not fit: %.1f of %.1f GB free (index, dense SA and the work buffers of the calls in flight share the HBM)",
 			    want / 1e9, fr / 1e9, tot / 1e9);
 		}
 		cap = want;
@@ -79,15 +79,22 @@ static uint64_t index_hash(const bwt_t *bwt, const bntseq_t *bns)
 	return h;
 }
 
+// (called under index_mutex() on every mem_process_seqs call: the contig table — 10^5..10^6 names on some references — is only
+// hashed again when the caller passes other pointers than the ones that matched last time)
+static const void *g_last_ok[4] = {nullptr, nullptr, nullptr, nullptr};
+static int g_last_ok_nseqs = -1;
 bool index_matches(const bwt_t *bwt, const bntseq_t *bns, const char **what)
 {
 	const char *w = nullptr;
+	const bool same_ptrs = g_last_ok[0] == bwt && g_last_ok[1] == bns && g_last_ok[2] == bns->anns && g_last_ok[3] == bwt->bwt && g_last_ok_nseqs == bns->n_seqs;
 	if (bwt->seq_len != g_idx.id_seq_len) w = "seq_len";
 	else if (bwt->primary != g_idx.id_primary) w = "primary";
 	else if (memcmp(bwt->L2, g_idx.id_L2, sizeof g_idx.id_L2) != 0) w = "L2";
 	else if (bns->l_pac != g_idx.l_pac) w = "l_pac";
 	else if (bns->n_seqs != g_idx.id_n_seqs) w = "n_seqs";
-	else if (index_hash(bwt, bns) != g_idx.id_hash) w = "contig table or BWT";
+	else if (!same_ptrs && index_hash(bwt, bns) != g_idx.id_hash) w = "contig table or BWT";
+	if (!w) { g_last_ok[0] = bwt; g_last_ok[1] = bns; g_last_ok[2] = bns->anns; g_last_ok[3] = bwt->bwt; g_last_ok_nseqs = bns->n_seqs; }
+	else g_last_ok[0] = nullptr;
 	if (what) *what = w;
 	return w == nullptr;
 }
@@ -126,6 +133,7 @@ static void alloc_index(const bwt_t *bwt, const bntseq_t *bns)
 	g_idx.l_pac = bns->l_pac;
 	g_idx.id_primary = bwt->primary; g_idx.id_seq_len = bwt->seq_len; g_idx.id_n_seqs = bns->n_seqs;
 	g_idx.id_hash = index_hash(bwt, bns);
+	g_last_ok[0] = nullptr;   // a new resident index: the next call hashes its contig table again
 	memcpy(g_idx.id_L2, bwt->L2, sizeof g_idx.id_L2);
 	if (bwt->seq_len >= (1ull << 34))
 		die("reference of %llu symbols: this build packs SA-interval bounds into 34 bits (references up to 8.5 Gbp)", (unsigned long long)bwt->seq_len);

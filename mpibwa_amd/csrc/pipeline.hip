@@ -409,6 +409,7 @@ struct Workspace {
 	// ... and their CIGAR / SAM-text job per part, launched right behind the pairing kernel
 	DevBuf dj_hdr[2], dj_pool[2], dj_cnt[2], dj_list[2], dj_base[2], dj_arena[2], dj_used[2], dj_ooff[2], dj_olen[2];
 	PinBuf hj_hdr[2], hj_pool[2], hj_arena[2], hj_ooff[2], hj_olen[2], hj_base[2];
+	PinBuf h_small[2];   // counters coming back from the SAM stage's jobs (a pageable target would make the copy spin behind queued kernels)
 };
 static const int MAX_LANES = 4;
 // Everything one mem_process_seqs() call owns between its first and last line.  Eight of them: eight caller threads may be inside
@@ -1038,8 +1039,12 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		int *nregs = (int *)W.h_nregs.ensure((size_t)n * 4 + 8);
 		std::vector<int> reg_pos(n + 1, 0);   // where the regions of read i start in hregs
 		DevReg *hregs = nullptr;
-		if (n_slots == 0) memset(nregs, 0, (size_t)n * 4);
-		else {
+		if (n_slots == 0) {
+			memset(nregs, 0, (size_t)n * 4);
+			// no read of the sub-batch has a seed: first_reg_kernel does not run, so the pairing kernel's slice of region counts must
+			// be cleared here (it would otherwise read the previous chunk's, or whatever hipMalloc left there)
+			if (d_pr_nfirst) { HIP_OK(hipMemsetAsync(d_pr_nfirst + lo, 0, (size_t)n * 4, st)); stream_wait(st); }
+		} else {
 			int *d_chain_beg = (int *)W.chain_off.ensure((size_t)n * 4), *d_chain_cnt = (int *)W.chain_cnt.ensure((size_t)n * 4);
 			int *d_reg_beg = (int *)W.reg_off.ensure((size_t)n * 4);
 			// (device mode: already sized 2 S above, so these calls never move what chain_kernel wrote)
@@ -1512,10 +1517,10 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		HIP_OK(hipGetLastError());
 		STAT.k_aln_ms += J.ev.ms();
 		STAT.n_aln += J.n_req;
-		unsigned long long used = 0;
-		HIP_OK(hipMemcpyAsync(&used, WS.dj_used[slot].p, 8, hipMemcpyDeviceToHost, J.st));
+		unsigned long long *small = (unsigned long long *)WS.h_small[slot].ensure(256);
+		HIP_OK(hipMemcpyAsync(small, WS.dj_used[slot].p, 8, hipMemcpyDeviceToHost, J.st));
 		stream_wait(J.st);
-		used = std::min<unsigned long long>(used, J.arena_bytes);
+		const unsigned long long used = std::min<unsigned long long>(small[0], J.arena_bytes);
 		uint8_t *ha = (uint8_t *)WS.hj_arena[slot].ensure((size_t)used + 64);
 		unsigned long long *ho = (unsigned long long *)WS.hj_ooff[slot].ensure((size_t)nr * 8 + 64);
 		int *hl = (int *)WS.hj_olen[slot].ensure((size_t)nr * 4 + 64);
@@ -1529,13 +1534,15 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		for (int k = 0; k < (P.hi - P.lo) && !any_back; ++k)
 			if (pstat[P.lo + k] == 1 && (hl[2 * k] < 0 || hl[2 * k + 1] < 0)) any_back = true;
 		if (any_back) {
-			unsigned long long cnt8[8];
-			HIP_OK(hipMemcpy(cnt8, J.d_cnt, sizeof cnt8, hipMemcpyDeviceToHost));
+			unsigned long long *cnt8 = small + 8;
+			HIP_OK(hipMemcpyAsync(cnt8, J.d_cnt, 64, hipMemcpyDeviceToHost, J.st));
+			stream_wait(J.st);
 			const size_t pu = std::min<size_t>(cnt8[0], J.pool_bytes);
 			AlnHdrH *hh = (AlnHdrH *)WS.hj_hdr[slot].ensure(J.n_req * sizeof(AlnHdr) + 64);
 			uint8_t *hp = (uint8_t *)WS.hj_pool[slot].ensure(pu + 64);
-			HIP_OK(hipMemcpy(hh, J.d_hdr, J.n_req * sizeof(AlnHdr), hipMemcpyDeviceToHost));
-			if (pu) HIP_OK(hipMemcpy(hp, J.d_pool, pu, hipMemcpyDeviceToHost));
+			HIP_OK(hipMemcpyAsync(hh, J.d_hdr, J.n_req * sizeof(AlnHdr), hipMemcpyDeviceToHost, J.st));
+			if (pu) HIP_OK(hipMemcpyAsync(hp, J.d_pool, pu, hipMemcpyDeviceToHost, J.st));
+			stream_wait(J.st);
 			J.hdr = hh; J.pool = hp;
 		}
 		aln_wait_ms += now_ms() - ta;
@@ -1590,8 +1597,10 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		double ta = now_ms();
 		stream_wait(P.st);
 		HIP_OK(hipGetLastError());
-		HIP_OK(hipMemcpyAsync(P.cnt, P.d_cnt, 64, hipMemcpyDeviceToHost, P.st));
+		unsigned long long *small = (unsigned long long *)WS.h_small[P.slot].ensure(256) + 16;
+		HIP_OK(hipMemcpyAsync(small, P.d_cnt, 64, hipMemcpyDeviceToHost, P.st));
 		stream_wait(P.st);
+		memcpy(P.cnt, small, 64);
 		STAT.k_aln_ms += P.ev.ms();
 		if (s_cpusec) {
 			unsigned long long c[16];
@@ -1607,10 +1616,9 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		STAT.n_aln += n_req;
 		if (P.sam_launched) {
 			const int nr = (P.hi - P.lo) << 1;
-			unsigned long long used = 0;
-			HIP_OK(hipMemcpyAsync(&used, WS.sused[P.slot].p, 8, hipMemcpyDeviceToHost, P.st));
+			HIP_OK(hipMemcpyAsync(small + 8, WS.sused[P.slot].p, 8, hipMemcpyDeviceToHost, P.st));
 			stream_wait(P.st);
-			used = std::min<unsigned long long>(used, P.arena_bytes);
+			const unsigned long long used = std::min<unsigned long long>(small[8], P.arena_bytes);
 			uint8_t *ha = (uint8_t *)WS.h_sarena[P.slot].ensure((size_t)used + 64);
 			unsigned long long *ho = (unsigned long long *)WS.h_sooff[P.slot].ensure((size_t)nr * 8 + 64);
 			int *hl = (int *)WS.h_solen[P.slot].ensure((size_t)nr * 4 + 64);

@@ -186,7 +186,7 @@ typedef struct {
 	int paired, lockstep, trimmed, copy_comment;
 	const mem_pestat_t *pes0;    /* -I */
 	int serialize;               /* MPI_THREAD_SERIALIZED: one thread inside MPI at a time */
-	pthread_mutex_t mpi_mu, fetch_mu;
+	pthread_mutex_t mpi_mu, fetch_mu, write_mu;
 	int64_t n_fetched;           /* reads of the chunks this rank has taken so far (trimmed pairs: n_processed) */
 	double t_start;
 } loop_t;
@@ -250,6 +250,11 @@ static void *chunk_worker(void *arg)
 		const double t3 = MPI_Wtime();
 		const size_t sam_len = mi355x_collect_sam_into(seqs, n, &sam, &csam);
 		const double t4 = MPI_Wtime();
+		/* a chunk's SAM goes out in one piece per GiB: the pieces of one chunk must not be separated by another worker's text (the
+		 * shared file pointer orders the ranks' writes, this mutex the workers' of one rank).  Chunks are written as their workers
+		 * finish them: with --in-flight > 1 the records of a file are not in input order (the reference's are not across ranks either). */
+		const int many = sam_len > (1u << 30);
+		if (many) pthread_mutex_lock(&L->write_mu);
 		MPI_ENTER(L);
 		for (size_t w = 0; w < sam_len; ) {
 			int piece = sam_len - w > (1u << 30) ? (1 << 30) : (int)(sam_len - w);
@@ -258,6 +263,7 @@ static void *chunk_worker(void *arg)
 			w += (size_t)piece;
 		}
 		MPI_LEAVE(L);
+		if (many) pthread_mutex_unlock(&L->write_mu);
 		if (prof)
 			fprintf(stderr, "[mpibwa_gpu] chunk %lld done at %.3f: read %.0f  scan+fill %.0f  align %.0f  collect %.0f  write %.0f ms\n", c, MPI_Wtime() - L->t_start,
 			        (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (MPI_Wtime() - t4) * 1e3);
@@ -527,6 +533,7 @@ int main(int argc, char **argv)
 	L.t_start = t_loop;
 	pthread_mutex_init(&L.mpi_mu, 0);
 	pthread_mutex_init(&L.fetch_mu, 0);
+	pthread_mutex_init(&L.write_mu, 0);
 	pthread_t th[8];
 	for (int w = 1; w < n_workers; ++w)
 		if (pthread_create(&th[w], 0, chunk_worker, &L) != 0) DIE("cannot start worker thread %d", w);

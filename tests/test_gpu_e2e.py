@@ -346,3 +346,20 @@ def test_pe_250bp_config4_shape(both, genome):
     # config 3's shape next to it: single-end reads of 50..300 bp
     se = simulate.reads_to_ascii(simulate.simulate_reads(genome["seqs"], 1500, 150, paired=False, seed=45, var_len=(50, 300)))
     _cmp(eng, ref, se, dict(flag=0))
+
+
+@needs_ref
+def test_seedless_chunk_after_a_mapped_one(both, reads_pe):
+    """A chunk in which no read has a seed (all-N reads) right after an ordinary chunk of the same size, from the same caller
+    thread (hence the same call context and work buffers): the pairing kernel must see region counts of zero for it — not the
+    previous chunk's — and every record must be the reference's unmapped one (flags 77 / 141)."""
+    eng, ref = both
+    ra = simulate.reads_to_ascii(reads_pe[:300])
+    _cmp(eng, ref, ra, dict(flag=abi.MEM_F_PE))
+    junk = [(n, b"N" * len(a), b"N" * len(b)) for n, a, b in ra]
+    want = ref.process(ref.opt(flag=abi.MEM_F_PE), junk)
+    got = eng.process(eng.opt(flag=abi.MEM_F_PE), junk)
+    assert got == want
+    for rec in got:
+        assert rec.split(b"\t")[1] in (b"77", b"141")
+    _cmp(eng, ref, ra, dict(flag=abi.MEM_F_PE))
