@@ -34,6 +34,7 @@ def build(force=False, verbose=False):
     extra = os.environ.get("MPIBWA_CXXFLAGS", "").split()
     common = extra + ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-g1", "-Wall", "-Wno-unused-function", "-Wno-unused-result",
               "-I", CSRC, "-I", os.path.join(HERE, "..", "include")]
+    jobs = []
     for s in srcs:
         o = os.path.join(HERE, "build", os.path.basename(s) + ".o")
         objs.append(o)
@@ -42,9 +43,17 @@ def build(force=False, verbose=False):
                 cmd = [HIPCC, f"--offload-arch={ARCH}", "-x", "hip"] + common + ["-c", s, "-o", o]
             else:
                 cmd = [HIPCC, "-x", "c++"] + common + ["-c", s, "-o", o]
+            jobs.append(cmd)
+    if jobs:   # independent translation units: a few compilers side by side (MPIBWA_BUILD_JOBS, default: the CPUs at hand, at most 8)
+        from concurrent.futures import ThreadPoolExecutor
+        n_par = int(os.environ.get("MPIBWA_BUILD_JOBS", "0")) or max(1, min(8, len(os.sched_getaffinity(0))))
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)
+        with ThreadPoolExecutor(max_workers=n_par) as ex:
+            list(ex.map(run, jobs))
     if force or _stale(OUT, objs):
         cmd = [HIPCC, "-shared", "-o", OUT] + objs + ["-Wl,-Bsymbolic", "-Wl,-soname,libmpibwa_amd.so", "-lpthread", "-lm", "-ldl"]
         if verbose:

@@ -24,6 +24,11 @@ struct FmDev {
 	// (p3_k + 1)-mer, 32 B per entry {x0, x1, x2, blocks touched}; null if absent
 	const void *p3tab;
 	int p3_k;
+	// optional k-mer tables of the seeding kernel (fm_kernels.hip: kmt_build_kernel): the bi-interval of EVERY string of
+	// 1 .. kmt_k bases, 16 B per entry in the interval list's packing, the table of length L at entry (4^L - 4) / 3;
+	// an extension whose result is that short is one independent 16-byte load instead of two dependent occ fetches
+	const void *kmt;
+	int kmt_k;
 };
 
 struct DevIndex {
@@ -36,6 +41,7 @@ struct DevIndex {
 	void *d_pac = nullptr; size_t pac_bytes = 0;
 	void *d_sa_full = nullptr; size_t sa_full_bytes = 0; double sa_expand_ms = 0;
 	void *d_p3tab = nullptr;
+	void *d_kmt = nullptr; size_t kmt_bytes = 0;
 	int64_t l_pac = 0;
 	// what is resident, as the caller's host-side index describes itself (compared on every mem_process_seqs call)
 	uint64_t id_primary = 0, id_seq_len = 0, id_L2[5] = {0, 0, 0, 0, 0};
@@ -73,6 +79,8 @@ void launch_smem(void *stream, const FmDev &fm, const SmemParams &sp, int n_read
                  void *d_scratch, size_t scratch_bytes_per_quad, int n_quads,
                  bool count_blocks /* counters[1] += the reference's occ blocks of passes 1-2 (the third pass always counts) */);
 size_t occ32_bytes(uint64_t seq_len);
+size_t kmt_bytes(int k);                                         // all tables of lengths 1 .. k
+void launch_kmt_build(void *stream, const FmDev &fm, int k, void *d_tab);   // needs fm.occ32; level by level on the stream
 void launch_occ32_build(void *stream, FmDev &fm, void *d_buf);   // from fm.blk (bwa format), after upload / broadcast; sets fm.occ32 / fm.occ_sb
 int  smem_grid_quads(int max_len, size_t *scratch_per_quad);
 void launch_smem_p3(void *stream, const FmDev &fm, const SmemParams &sp, int n_reads, const uint8_t *d_seq, const int64_t *d_off,

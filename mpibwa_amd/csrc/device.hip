@@ -120,8 +120,9 @@ static void alloc_index(const bwt_t *bwt, const bntseq_t *bns)
 	HIP_OK(hipMemset(g_idx.d_pac, 0, g_idx.pac_bytes));
 	FmDev &fm = g_idx.fm;
 	fm.blk = g_idx.d_blk; fm.sa = (const uint64_t *)g_idx.d_sa; fm.sa_full = nullptr;
-	fm.p3tab = nullptr; fm.p3_k = 0; fm.occ32 = nullptr; fm.occ_sb = nullptr;
+	fm.p3tab = nullptr; fm.p3_k = 0; fm.occ32 = nullptr; fm.occ_sb = nullptr; fm.kmt = nullptr; fm.kmt_k = 0;
 	if (g_idx.d_occ32) { (void)hipFree(g_idx.d_occ32); g_idx.d_occ32 = nullptr; }
+	if (g_idx.d_kmt) { (void)hipFree(g_idx.d_kmt); g_idx.d_kmt = nullptr; g_idx.kmt_bytes = 0; }
 	if (g_idx.d_p3tab) { (void)hipFree(g_idx.d_p3tab); g_idx.d_p3tab = nullptr; }
 	if (g_idx.d_sa_full) { (void)hipFree(g_idx.d_sa_full); g_idx.d_sa_full = nullptr; g_idx.sa_full_bytes = 0; }
 	fm.primary = bwt->primary; fm.seq_len = bwt->seq_len;
@@ -163,6 +164,30 @@ static void maybe_build_p3()
 	HIP_OK(hipGetLastError());
 	g_idx.fm.p3tab = g_idx.d_p3tab;
 	g_idx.fm.p3_k = k;
+}
+
+// The seeding kernel's k-mer tables (fm_kernels.hip: kmt_build_kernel): the bi-interval of every string of up to K bases, K chosen
+// so that the longest table has about as many entries as the index has rows (beyond that a table entry is as cold as an occ block)
+// and at most 14 (5.7 GB).  MPIBWA_KMT=<K> chooses K (0 = no tables: every extension through the occ table).
+static void maybe_build_kmt()
+{
+	if (g_idx.d_kmt) { (void)hipFree(g_idx.d_kmt); g_idx.d_kmt = nullptr; g_idx.kmt_bytes = 0; }
+	g_idx.fm.kmt = nullptr; g_idx.fm.kmt_k = 0;
+	int k = 1;
+	while (k < 14 && ((uint64_t)1 << (2 * k)) < g_idx.fm.seq_len) ++k;
+	if (const char *e = getenv("MPIBWA_KMT")) k = atoi(e);
+	if (k < 1) return;
+	if (k > 15) k = 15;
+	const size_t bytes = kmt_bytes(k);
+	size_t free_b = 0, total_b = 0;
+	if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + ((size_t)16 << 30)) return;
+	HIP_OK(hipMalloc(&g_idx.d_kmt, bytes));
+	launch_kmt_build(0, g_idx.fm, k, g_idx.d_kmt);
+	HIP_OK(hipDeviceSynchronize());
+	HIP_OK(hipGetLastError());
+	g_idx.kmt_bytes = bytes;
+	g_idx.fm.kmt = g_idx.d_kmt;
+	g_idx.fm.kmt_k = k;
 }
 
 // The seeding kernel's own occ table (fm_kernels.hip: occ32_build_kernel), derived on the device from the bwa-format blocks.
@@ -240,7 +265,8 @@ extern "C" int mi355x_index_upload(int local_rank, const bwt_t *bwt, const bntse
 	maybe_expand_sa();
 	if (dbg) fprintf(stderr, "[upload] SA expanded\n");
 	maybe_build_p3();
-	if (dbg) fprintf(stderr, "[upload] jump table built\n");
+	maybe_build_kmt();
+	if (dbg) fprintf(stderr, "[upload] jump table and k-mer tables built\n");
 	g_idx.ready = true;
 	return 0;
 }
@@ -274,6 +300,7 @@ extern "C" int mi355x_index_commit(void)
 	build_occ32();
 	maybe_expand_sa();
 	maybe_build_p3();
+	maybe_build_kmt();
 	g_idx.ready = true;
 	return 0;
 }
@@ -286,6 +313,7 @@ extern "C" void mi355x_finalize(void)
 	if (g_idx.d_sa_full) (void)hipFree(g_idx.d_sa_full);
 	if (g_idx.d_p3tab) (void)hipFree(g_idx.d_p3tab);
 	if (g_idx.d_occ32) (void)hipFree(g_idx.d_occ32);
+	if (g_idx.d_kmt) (void)hipFree(g_idx.d_kmt);
 	g_idx = DevIndex();
 }
 

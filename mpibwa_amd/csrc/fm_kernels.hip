@@ -101,6 +101,62 @@ __device__ __forceinline__ int lane_extend(const FmDev &fm, const char *cbase, c
 	return (ka >> 7) == (la >> 7) ? 1 : 2;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The k-mer tables (FmDev::kmt, round 4).  The bi-interval of a string W — (first row of W, first row of its reverse
+// complement, number of occurrences) — is a function of W alone, whichever way bwt_smem1a arrives at it.  So for every
+// string of 1 .. K bases it is tabulated once per index (16 bytes: the list entry's packing; the table of length L starts
+// at entry (4^L - 4) / 3, the string's bases are the entry number, first base in the top bits), built level by level with
+// the very lane_extend the kernel uses.  An extension whose RESULT has at most K bases is then one 16-byte load whose
+// address depends on the read only: no dependent pair of occ fetches (at that depth k and l lie in different blocks: two
+// misses, and the shallow tables live in L2 / the Infinity Cache), which is where the kernel's L1 misses came from.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __host__ __forceinline__ u32 kmt_first(int L) { return 0x55555554u & ((1u << (2 * L)) - 1u); }   // (4^L - 4) / 3, L <= 15
+__device__ __forceinline__ uint4 kmt_pack(u64 x0, u64 x1, u64 x2)
+{
+	return make_uint4((u32)x0, (u32)x1, (u32)x2, (u32)(x0 >> 32) | (u32)(x1 >> 32) << 2 | (u32)(x2 >> 32) << 4);
+}
+__device__ __forceinline__ void kmt_unpack(const uint4 &v, u64 &x0, u64 &x1, u64 &x2)
+{
+	x0 = (u64)(v.w & 3) << 32 | v.x;
+	x1 = (u64)(v.w >> 2 & 3) << 32 | v.y;
+	x2 = (u64)(v.w >> 4 & 3) << 32 | v.z;
+}
+// level L from level L - 1: one lane per string, the forward extension of its prefix by its last base (src/bwt.c:299-311)
+__global__ void __launch_bounds__(256) kmt_build_kernel(FmDev fm, int L, uint4 *__restrict__ tab)
+{
+	__shared__ ulonglong2 lds_sb[SB_MAX * 4];
+	if (threadIdx.x < SB_MAX * 4) {
+		ulonglong2 v = ((const ulonglong2 *)fm.occ_sb)[threadIdx.x];
+		v.x += fm.L2[threadIdx.x & 3] + 1;
+		lds_sb[threadIdx.x] = v;
+	}
+	__syncthreads();
+	const u64 code = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (code >= (1ull << (2 * L))) return;
+	const int b = (int)(code & 3);
+	u64 x0, x1, x2;
+	if (L == 1) { x0 = fm.L2[b] + 1; x2 = fm.L2[b + 1] - fm.L2[b]; x1 = fm.L2[3 - b] + 1; }
+	else {
+		kmt_unpack(tab[kmt_first(L - 1) + (u32)(code >> 2)], x0, x1, x2);
+		if (x2 == 0) x0 = x1 = 0;   // (no sweep ever asks for a string whose prefix does not occur)
+		else {
+			const int csel = 3 - b;
+			u64 oa, omir, os;
+			lane_extend<false>(fm, (const char *)fm.occ32 + 16 * csel, lds_sb + csel, x1, x0, x2, oa, omir, os);
+			x1 = oa; x0 = omir; x2 = os;
+		}
+	}
+	tab[kmt_first(L) + (u32)code] = kmt_pack(x0, x1, x2);
+}
+size_t kmt_bytes(int k) { return ((size_t)kmt_first(k) + ((size_t)1 << (2 * k))) * 16; }
+void launch_kmt_build(void *stream, const FmDev &fm, int k, void *d_tab)
+{
+	for (int L = 1; L <= k; ++L) {
+		const u64 n = 1ull << (2 * L);
+		hipLaunchKernelGGL(kmt_build_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fm, L, (uint4 *)d_tab);
+	}
+}
+
 // One interval-list entry = 16 bytes: x0,x1,x2 (34 bits each: references up to 2^34 symbols = 8.5 Gbp) and the end
 // coordinate (16 bits); a lane reads or writes a whole entry (ds_read_b128 / ds_write_b128).
 struct QuadList {
@@ -143,7 +199,7 @@ enum { ST_PICK = 0, ST_FWD = 1, ST_BWD = 2, ST_DONE = 4 };
 // QLDS: every read of the launch fits its quad's LDS slot, so a base is always a plain LDS byte (otherwise the accessor
 // needs a generic pointer and every base costs a flat load).  COUNT: count the reference's occ blocks (counters[1]) —
 // tests and the bench's counting pass; the production launch leaves that arithmetic out.
-template <bool QLDS, int LC, int QS, bool COUNT>
+template <bool QLDS, int LC, int QS, bool COUNT, bool KMT>
 __global__ void __launch_bounds__(SMEM_BLOCK)
 smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ seq, const int64_t *__restrict__ off,
             const int *__restrict__ lens, int cap, u64 *__restrict__ out, int *__restrict__ nout_arr, u64 *counters, uint4 *scratch,
@@ -180,6 +236,11 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 	// the bi-interval to extend next as (searched side, mirrored side, size, end): going forward bwt_smem1a's `ik` with
 	// x[1] searched (the same in all four lanes), going backward the lane's list entry with x[0] searched
 	u64 cp = 1, cq = 0, cs = 0, c_end = 0;
+	// the bases from the sweep's current left end onward, first base in the top bits (going forward: from x, filled as the sweep
+	// advances; going backward: from i): the entry number of a short result in the k-mer tables is its top bits
+	u64 win = 0;
+	const uint4 *kmt = (const uint4 *)fm.kmt;
+	const int kmt_k = KMT ? fm.kmt_k : 0;
 	u64 carry_s = 0;              // backward: size of the child of the previous entry of the row, if it survived
 	bool carry_surv = false;
 	u64 *myout = out;
@@ -193,6 +254,7 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 		int b = Q(xs);
 		cq = fm.L2[b] + 1; cs = fm.L2[b + 1] - fm.L2[b]; cp = fm.L2[3 - b] + 1; c_end = xs + 1;
 		i = xs + 1; top = 0; st = ST_FWD;
+		win = (u64)b << 62;
 #ifdef SMEM_DEBUG
 		printf("begin t=%d xs=%d mi=%d pass=%d k2=%d\n", t, xs, mi, pass, k2);
 #endif
@@ -202,7 +264,10 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 		last_push_end = (int)c_end;
 		++top;
 	};
-	auto set_cb = [&]() { csel = (i < 0 || Q(i) > 3) ? -1 : (int)Q(i); };
+	auto set_cb = [&]() {   // the sweep's left end has moved to i
+		csel = (i < 0 || Q(i) > 3) ? -1 : (int)Q(i);
+		if (KMT) win = win >> 2 | (u64)(csel & 3) << 62;
+	};
 	auto fwd_done = [&]() {   // the list holds `top` entries, longest match last pushed
 		ret = last_push_end; np = top; i = x - 1; j = 0; nc = 0; last_start = -1; st = ST_BWD; carry_surv = false;
 		set_cb();
@@ -329,7 +394,16 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 		// going forward lane 0 extends for the quad, going backward every lane with an entry: the other lanes issue no loads
 		{
 			const bool mine = st == ST_FWD ? t == 0 : valid;
-			if (need && mine) nblk += lane_extend<COUNT>(fm, (const char *)fm.occ32 + 16 * csel, lds_sb + csel, cp, cq, cs, oa, omir, os);
+			if (need && mine) {
+				const int tl = st == ST_FWD ? i - x + 1 : (int)c_end - i;   // bases of the result
+				if (KMT && tl <= kmt_k) {
+					u64 w = win;
+					if (st == ST_FWD) w |= (u64)(3 - csel) << (64 - 2 * tl);
+					u64 x0, x1;
+					kmt_unpack(kmt[kmt_first(tl) + (u32)(w >> (64 - 2 * tl))], x0, x1, os);
+					oa = st == ST_FWD ? x1 : x0; omir = st == ST_FWD ? x0 : x1;
+				} else nblk += lane_extend<COUNT>(fm, (const char *)fm.occ32 + 16 * csel, lds_sb + csel, cp, cq, cs, oa, omir, os);
+			}
 		}
 		// ---- consume ----
 		const bool bwd = need && st == ST_BWD;   // (before the forward branch below may turn the quad around)
@@ -341,7 +415,10 @@ smem_kernel(FmDev fm, SmemParams sp, int n_reads, const uint8_t *__restrict__ se
 					push_fwd();
 					if (f_s < (u64)min_intv) { fwd_done(); stop = true; }
 				}
-				if (!stop) { cp = f_a; cq = f_mir; cs = f_s; c_end = i + 1; ++i; }
+				if (!stop) {
+					if (KMT && i - x < 32) win |= (u64)(3 - csel) << (62 - 2 * (i - x));
+					cp = f_a; cq = f_mir; cs = f_s; c_end = i + 1; ++i;
+				}
 			}
 		}
 		// (the ballots and the DPP reads of the backward bookkeeping stay outside lane-divergent branches)
@@ -503,14 +580,19 @@ void launch_smem(void *stream, const FmDev &fm, const SmemParams &sp, int n_read
 #define SMEM_LAUNCH(...) hipLaunchKernelGGL((smem_kernel<__VA_ARGS__>), dim3(n_blocks), dim3(SMEM_BLOCK), 0, (hipStream_t)stream, fm, sp, n_reads, d_seq, \
 	                                    d_off, d_len, cap, (u64 *)d_out, d_nout, (u64 *)d_counters, (uint4 *)d_scratch,                          \
 	                                    scratch_bytes_per_quad / sizeof(uint4))
+	// counting the reference's occ blocks means doing its extensions: the counting variant never takes a result from the k-mer tables
 	if (count_blocks) {
-		if (max_len <= QSLOT_S) SMEM_LAUNCH(true, LCAP_S, QSLOT_S, true);
-		else if (max_len <= QSLOT) SMEM_LAUNCH(true, LCAP, QSLOT, true);
-		else SMEM_LAUNCH(false, LCAP, QSLOT, true);
+		if (max_len <= QSLOT_S) SMEM_LAUNCH(true, LCAP_S, QSLOT_S, true, false);
+		else if (max_len <= QSLOT) SMEM_LAUNCH(true, LCAP, QSLOT, true, false);
+		else SMEM_LAUNCH(false, LCAP, QSLOT, true, false);
+	} else if (fm.kmt && fm.kmt_k > 0) {
+		if (max_len <= QSLOT_S) SMEM_LAUNCH(true, LCAP_S, QSLOT_S, false, true);
+		else if (max_len <= QSLOT) SMEM_LAUNCH(true, LCAP, QSLOT, false, true);
+		else SMEM_LAUNCH(false, LCAP, QSLOT, false, true);
 	} else {
-		if (max_len <= QSLOT_S) SMEM_LAUNCH(true, LCAP_S, QSLOT_S, false);
-		else if (max_len <= QSLOT) SMEM_LAUNCH(true, LCAP, QSLOT, false);
-		else SMEM_LAUNCH(false, LCAP, QSLOT, false);
+		if (max_len <= QSLOT_S) SMEM_LAUNCH(true, LCAP_S, QSLOT_S, false, false);
+		else if (max_len <= QSLOT) SMEM_LAUNCH(true, LCAP, QSLOT, false, false);
+		else SMEM_LAUNCH(false, LCAP, QSLOT, false, false);
 	}
 #undef SMEM_LAUNCH
 }

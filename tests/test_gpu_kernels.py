@@ -60,6 +60,37 @@ def test_smem_kernel_matches_oracle(engine, genome, reads_pe, reads_var):
     assert nbytes == fm.fm.n_blocks * 64 + total_in + 32 * n_intv
 
 
+@pytest.mark.parametrize("kmt", ["4", "9", "0", "default"])   # (the last one leaves the module's index as every other test expects it)
+def test_production_smem_kernel_matches_oracle(genome, reads_pe, reads_var, kmt, monkeypatch):
+    """The instantiation mem_process_seqs launches (no block counting; short results come from the k-mer tables, depth `kmt`:
+    MPIBWA_KMT, 0 = every extension through the occ table) against the oracle's mem_collect_intv: reads of all lengths, text ends,
+    the strand junction, ambiguous bases, low-complexity reads (re-seeding with min_intv > 1)."""
+    from mpibwa_amd import api
+    if kmt != "default":
+        monkeypatch.setenv("MPIBWA_KMT", kmt)
+    eng = api.Engine(genome["prefix"], device=0)   # (the tables are built at upload)
+    monkeypatch.setenv("MPIBWA_SMEM_COUNT", "0")
+    fm = po.OracleFM(genome["prefix"])
+    seqs = _flatten(reads_pe) + _flatten(reads_var)
+    g = genome["seqs"][0]
+    first, last = np.asarray(genome["seqs"][0], np.uint8), np.asarray(genome["seqs"][-1], np.uint8)
+    seqs += [np.array([0, 1, 2, 3] * 40, np.uint8), np.zeros(150, np.uint8), np.array([0, 1] * 75, np.uint8), np.full(40, 4, np.uint8),
+             np.concatenate([g[1000:1060], [4], g[1061:1150]]).astype(np.uint8), g[5000:5019].astype(np.uint8),
+             np.concatenate([g[2000:2010], [4], g[2011:2030], [4, 4], g[2032:2150]]).astype(np.uint8),
+             np.where(g[9000:9400] > 3, 0, g[9000:9400]).astype(np.uint8)]
+    if (first[:300] < 4).all() and (last[-300:] < 4).all():
+        head, tail = first[:150], last[-150:]
+        seqs += [head, _rc(head), tail, _rc(tail), first[:260], _rc(last[-260:]),
+                 np.concatenate([last[-75:], _rc(last[-75:])]), np.concatenate([_rc(first[:75]), first[:75]]),
+                 np.concatenate([last[-140:], _rc(last[-10:])]), np.concatenate([[1], head[1:]]).astype(np.uint8)]
+    got, ms, nbytes = eng.smem(eng.opt(), seqs, cap=512)
+    assert nbytes == 0   # (nothing counted in this variant)
+    for s, a in zip(seqs, got):
+        b = fm.collect_intv(s) if len(s) >= 19 else np.zeros((0, 4), np.uint64)
+        assert a.shape == b.shape, (len(s), a.shape, b.shape)
+        assert (a == b).all()
+
+
 def test_smem_kernel_overflow_is_reported(engine, reads_pe):
     opt = engine.opt()
     with pytest.raises(RuntimeError):
