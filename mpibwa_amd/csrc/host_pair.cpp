@@ -226,6 +226,92 @@ static inline void matesw_skips(const bntseq_t *bns, const mem_pestat_t pes[4], 
 	}
 }
 
+// mem_sort_dedup_patch(opt, 0, 0, 0, ...) (src/bwamem.c:437-489, as src/bwamem_pair.c:176 calls it) on "a list that is a fixed
+// point of that pass + one new hit b", without sorting: returns false when the outcome depends on how the reference's unstable
+// sort orders hits with equal end positions (the caller then runs the pass itself).
+// Why this is the same list.  Among the hits of a fixed point no two are redundant (every pair within reach of each other was
+// compared while both were alive, :451-459), and nothing is merged without the reference sequence (mem_patch_reg returns 0,
+// :408), so every event of the pass involves b.  The pass walks the hits by increasing end position; a hit p looks back over
+// the hits that end before it (same contig, p->rb < q->re + max_chain_gap: a contiguous run) and, per redundant pair, the
+// lower score dies, the earlier one on a tie (:456-459), and a hit that dies stops looking.  So: the partners R of b are found
+// in one scan; if all of them score less than b they all die and b stays, whatever the order; otherwise b first meets those that
+// end before it, nearest first (killing them until one scores more, which kills b), then those that end after it meet b in
+// turn (dying until one scores at least b's, which kills b) — an order that is only defined by the end positions when these are
+// distinct.  What is left is already sorted by (score desc, rb, qb) except for b, and two hits with equal (score, rb, qb)
+// are always redundant, so the second half of the pass (:475-487) reduces to putting b in its place.
+static bool insert_into_settled(const mem_opt_t *opt, HRegV &ma, const HReg &b)
+{
+	const int n = (int)ma.size();
+	int R_[48], nR = 0;
+	bool any_ge = false, tie = false;
+	auto redundant = [&](const HReg *q, const HReg *p) -> bool {   // q ends first; p looks back at it (src/bwamem.c:448-455)
+		if (!(p->rb < q->re + opt->max_chain_gap)) return false;
+		const int64_t orr = q->re - p->rb;
+		const int64_t oq = q->qb < p->qb ? q->qe - p->qb : p->qe - q->qb;
+		const int64_t mr = q->re - q->rb < p->re - p->rb ? q->re - q->rb : p->re - p->rb;
+		const int64_t mq = q->qe - q->qb < p->qe - p->qb ? q->qe - q->qb : p->qe - p->qb;
+		return orr > opt->mask_level_redun * mr && oq > opt->mask_level_redun * mq;
+	};
+	for (int i = 0; i < n; ++i) {
+		const HReg &e = ma[i];
+		if (e.rid != b.rid) continue;
+		// (equal end positions: either may be the one the pass visits first)
+		const bool red = e.re < b.re ? redundant(&e, &b) : e.re > b.re ? redundant(&b, &e) : (redundant(&e, &b) || redundant(&b, &e));
+		if (!red) continue;
+		if (nR == 48) return false;
+		R_[nR++] = i;
+		if (e.score >= b.score) any_ge = true;
+		if (e.re == b.re) tie = true;
+	}
+	bool b_alive = true;
+	uint64_t dead[4] = {0, 0, 0, 0};   // positions in R_
+	if (nR && !any_ge) {
+		for (int k = 0; k < nR; ++k) dead[k >> 6] |= 1ull << (k & 63);
+	} else if (nR) {
+		if (tie) return false;
+		// R by end position (insertion sort of a handful of indices); equal end positions among them: the order is the sort's
+		int o[48];
+		for (int k = 0; k < nR; ++k) o[k] = k;
+		for (int a = 1; a < nR; ++a)
+			for (int c = a; c > 0 && ma[R_[o[c]]].re < ma[R_[o[c - 1]]].re; --c) std::swap(o[c], o[c - 1]);
+		for (int a = 1; a < nR; ++a)
+			if (ma[R_[o[a]]].re == ma[R_[o[a - 1]]].re) return false;
+		int first_after = 0;
+		while (first_after < nR && ma[R_[o[first_after]]].re < b.re) ++first_after;
+		for (int a = first_after - 1; a >= 0 && b_alive; --a) {   // b looks back, nearest first
+			if (b.score < ma[R_[o[a]]].score) b_alive = false;
+			else dead[o[a] >> 6] |= 1ull << (o[a] & 63);
+		}
+		for (int a = first_after; a < nR && b_alive; ++a) {        // the hits behind b meet it in turn
+			if (ma[R_[o[a]]].score < b.score) dead[o[a] >> 6] |= 1ull << (o[a] & 63);
+			else b_alive = false;
+		}
+	}
+	// compact the survivors (they keep their order), then b into its place by (score desc, rb, qb)
+	if (dead[0] | dead[1] | dead[2] | dead[3]) {
+		int m = 0, k = 0;
+		for (int i = 0; i < n; ++i) {
+			if (k < nR && R_[k] == i) {
+				const bool d = (dead[k >> 6] >> (k & 63)) & 1;
+				++k;
+				if (d) continue;
+			}
+			if (m != i) ma[m] = ma[i];
+			++m;
+		}
+		ma.resize(m);
+	}
+	if (b_alive) {
+		size_t at = 0;
+		while (at < ma.size() && (ma[at].score > b.score || (ma[at].score == b.score && (ma[at].rb < b.rb || (ma[at].rb == b.rb && ma[at].qb < b.qb))))) ++at;
+		HReg nb = b;
+		nb.n_comp = 1;
+		ma.insert(ma.begin() + at, nb);
+	}
+	ma.settled = true;
+	return true;
+}
+
 static int matesw(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, const mem_pestat_t pes[4], const HReg *a, int l_ms,
                   const uint8_t *ms, HRegV &ma, const MswCtx *mctx, int mate_read)
 {
@@ -272,11 +358,14 @@ static int matesw(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac,
 				b.csub = aln.score2;
 				b.secondary = -1;
 				b.seedcov = (int)((b.re - b.rb < b.qe - b.qb ? b.re - b.rb : b.qe - b.qb) >> 1);
-				// keep `ma` ordered by score: insert before the first strictly lower score
-				size_t at = 0;
-				while (at < ma.size() && !(ma[at].score < b.score)) ++at;
-				ma.insert(ma.begin() + at, b);
-				ma.settled = false;
+				// A list that is a fixed point of the redundancy pass takes the new hit without the pass being run (insert_into_settled);
+				// otherwise: keep `ma` ordered by score (insert before the first strictly lower score) for the pass below
+				if (!(ma.settled && insert_into_settled(opt, ma, b))) {
+					size_t at = 0;
+					while (at < ma.size() && !(ma[at].score < b.score)) ++at;
+					ma.insert(ma.begin() + at, b);
+					ma.settled = false;
+				}
 			}
 			++n;
 		}
