@@ -75,14 +75,27 @@ __global__ void __launch_bounds__(64 * C2A_WAVES)
 c2a_kernel(C2aParams P, WxParams X, int n_reads, const uint8_t *__restrict__ seq, const int64_t *__restrict__ off,
            const int *__restrict__ lens, const int *__restrict__ chain_beg, const int *__restrict__ chain_cnt, const DevChain *__restrict__ chains,
            const DevSeed *__restrict__ seeds, unsigned int *srt, const int *__restrict__ reg_beg, DevReg *regs, int *n_regs, const int *__restrict__ tab,
-           int tab_stride, const uint8_t *__restrict__ pac, unsigned long long *counters, int max_len, const int *__restrict__ order)
+           int tab_stride, const uint8_t *__restrict__ pac, unsigned long long *counters, int max_len, const int *__restrict__ order, C2aUnits U)
 {
 	extern __shared__ int lds[];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const int slot = blockIdx.x * C2A_WAVES + wave;
-	if (slot >= n_reads) return;
-	// reads with the most seeds are started first, so that the kernel does not end on a few long-running reads
-	const int rd = uni(order ? order[slot] : slot);
+	int slot = blockIdx.x * C2A_WAVES + wave;
+	// the first U.max_units slots are the units of the reads with many chains (c2a_groups.hip): a group of their chains each,
+	// independent of the read's other groups; they go first (their reads are the long-running ones)
+	const bool unit_mode = slot < U.max_units;
+	int u_beg = 0, u_cnt = 0, u_av = 0;
+	int rd;
+	if (unit_mode) {
+		if ((unsigned)slot >= *U.n_units) return;
+		u_beg = uni(U.ustart[slot]); u_cnt = uni(U.ustart[slot + 1]) - u_beg;
+		rd = uni(U.unit_rd[slot]); u_av = uni(U.unit_av[slot]);
+	} else {
+		slot -= U.max_units;
+		if (slot >= n_reads) return;
+		// reads with the most seeds are started first, so that the kernel does not end on a few long-running reads
+		rd = uni(order ? order[slot] : slot);
+		if (U.max_units > 0 && chain_cnt[rd] > U.heavy_t) return;   // worked off as units
+	}
 	uint8_t *const lbase = (uint8_t *)lds + (size_t)wave * c2a_lds_bytes(max_len);
 	const WxLds L = wx_lds((int *)lbase, max_len);
 	uint8_t *const rdl = lbase + (((size_t)wx_lds_ints(max_len) * 4 + 15) & ~(size_t)15);   // the read
@@ -96,14 +109,20 @@ c2a_kernel(C2aParams P, WxParams X, int n_reads, const uint8_t *__restrict__ seq
 	          *thr10 = tab + 4 * tab_stride;
 	const uint8_t *qg = seq + off[rd];
 	const int lq = uni(lens[rd]);
-	DevReg *av = regs + reg_beg[rd];
-	const int ci_beg = uni(chain_beg[rd]), ci_cnt = uni(chain_cnt[rd]);
+	DevReg *av = regs + (unit_mode ? u_av : reg_beg[rd]);
+	const int ci_beg = unit_mode ? 0 : uni(chain_beg[rd]), ci_cnt = unit_mode ? u_cnt : uni(chain_cnt[rd]);
 	const int ci_end = ci_beg + (ci_cnt > 0 ? ci_cnt : 0);
+	auto CI = [&](int t) -> int { return unit_mode ? uni(U.clist[u_beg + t]) : t; };   // the chain walked at step t
 	// stage the read (slots are 16-byte aligned and padded) and the chains
 	for (int j = lane * 4; j < lq; j += 256) *(uint32_t *)(rdl + j) = *(const uint32_t *)(qg + j);
 	const bool st_c = ci_cnt > 0 && ci_cnt <= C2A_CAP_C;
-	if (st_c)
-		for (int k = lane; k < ci_cnt * (int)(sizeof(DevChain) / 4); k += 64) ((uint32_t *)chl)[k] = ((const uint32_t *)(chains + ci_beg))[k];
+	if (st_c) {
+		if (unit_mode) {
+			const int W = (int)(sizeof(DevChain) / 4);
+			for (int k = lane; k < ci_cnt * W; k += 64) ((uint32_t *)chl)[k] = ((const uint32_t *)(chains + U.clist[u_beg + k / W]))[k % W];
+		} else
+			for (int k = lane; k < ci_cnt * (int)(sizeof(DevChain) / 4); k += 64) ((uint32_t *)chl)[k] = ((const uint32_t *)(chains + ci_beg))[k];
+	}
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -200,18 +219,29 @@ c2a_kernel(C2aParams P, WxParams X, int n_reads, const uint8_t *__restrict__ seq
 		return r;
 	};
 
-	for (int ci = ci_beg; ci < ci_end; ++ci) {
-		DevChain C = st_c ? chl[ci - ci_beg] : chains[ci];
+	for (int ct = ci_beg; ct < ci_end; ++ct) {
+		const int ci = CI(ct);
+		DevChain C = st_c ? chl[ct - ci_beg] : chains[ci];
 		C.n_seeds = uni(C.n_seeds); C.seed_beg = uni(C.seed_beg); C.rid = uni(C.rid);
 		C.far_beg = uni64(C.far_beg); C.far_end = uni64(C.far_end);
 		const int n = C.n_seeds;
+		const int nav0 = nav;
+		if (unit_mode && lane == 0) { U.c_rabs[ci] = u_av + nav0; U.c_rcnt[ci] = 0; }
 		if (n == 0) continue;
 		// the chain's seeds and order: the staged copies, or the flat arrays
 		const DevSeed *sdg = seeds + C.seed_beg;
 		unsigned int *ordg = srt + C.seed_beg;
-		const int sl = C.seed_beg - s0;   // first staged seed of the chain
-		auto SD = [&](int i) -> DevSeed { return st_s ? sdl[sl + i] : sdg[i]; };
-		auto ORD = [&](int i) -> unsigned int { return st_s ? ordl[sl + i] : ordg[i]; };
+		int sl = C.seed_beg - s0;   // first staged seed of the chain
+		bool st_sc = st_s;
+		if (unit_mode && !st_s && n <= C2A_CAP_S) {   // a unit whose chains do not lie back to back stages them one at a time
+			if (lane < n) { sdl[lane] = sdg[lane]; ordl[lane] = ordg[lane]; }
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			st_sc = true; sl = 0;
+		}
+		auto SD = [&](int i) -> DevSeed { return st_sc ? sdl[sl + i] : sdg[i]; };
+		auto ORD = [&](int i) -> unsigned int { return st_sc ? ordl[sl + i] : ordg[i]; };
 		// the reference window any seed of the chain could reach (src/bwamem.c:642-661; computed with the chain) and its bases
 		const i64 rmax0 = uni64(C.rmax0), rmax1 = uni64(C.rmax1);
 		const int wlen = (int)(rmax1 - rmax0);
@@ -265,7 +295,7 @@ c2a_kernel(C2aParams P, WxParams X, int n_reads, const uint8_t *__restrict__ seq
 					other = __ballot(h) != 0;
 				}
 				if (!other) {
-					if (lane == 0) { if (st_s) ordl[sl + k] = SRT_MARK; else ordg[k] = SRT_MARK; }
+					if (lane == 0) { if (st_sc) ordl[sl + k] = SRT_MARK; else ordg[k] = SRT_MARK; }
 					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 					__builtin_amdgcn_wave_barrier();
 					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -327,9 +357,11 @@ c2a_kernel(C2aParams P, WxParams X, int n_reads, const uint8_t *__restrict__ seq
 			++nav;
 			__builtin_amdgcn_wave_barrier();
 		}
+		if (unit_mode && lane == 0) U.c_rcnt[ci] = nav - nav0;
 	}
 	if (lane == 0) {
-		n_regs[rd] = nav;
+		if (unit_mode) { if (nav) atomicAdd(&n_regs[rd], nav); }
+		else n_regs[rd] = nav;
 		// statistics only — but an atomic on ONE address costs ~10 ns of a queue the whole chip shares (MI355X_MICROARCH.md: same-
 		// address atomics), and two per read made that queue, not the DP, the length of this kernel (222 000 reads x 2 = 4.9 of
 		// 5.4 ms per launch, DP switched off or not): the counters are spread over C2A_STAT_SLOTS cache lines, the host adds them up
@@ -344,18 +376,20 @@ c2a_kernel(C2aParams P, WxParams X, int n_reads, const uint8_t *__restrict__ seq
 void launch_c2a(void *stream, const C2aParams &P, const ExtParams &ep, int n_reads, const uint8_t *d_seq, const int64_t *d_off,
                 const int *d_len, const int *d_chain_beg, const int *d_chain_cnt, const DevChain *d_chains, const DevSeed *d_seeds, unsigned int *d_srt,
                 const int *d_reg_beg, DevReg *d_regs, int *d_nregs, const int *d_tab, int tab_stride, const uint8_t *d_pac, unsigned long long *d_counters,
-                int max_len, const int *d_order)
+                int max_len, const int *d_order, const C2aUnits *units)
 {
+	C2aUnits U;
+	if (units) U = *units;
 	WxParams X;
 	for (int i = 0; i < 25; ++i) X.mat[i] = ep.mat[i];
 	X.o_del = ep.o_del; X.e_del = ep.e_del; X.o_ins = ep.o_ins; X.e_ins = ep.e_ins; X.zdrop = ep.zdrop;
 	size_t shmem = (size_t)C2A_WAVES * c2a_lds_bytes(max_len);
 	if (shmem > 64 * 1024 && hipFuncSetAttribute((const void *)c2a_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)
 		die("c2a_kernel: cannot reserve %zu bytes of LDS", shmem);
-	int n_blocks = (n_reads + C2A_WAVES - 1) / C2A_WAVES;
+	int n_blocks = (U.max_units + n_reads + C2A_WAVES - 1) / C2A_WAVES;
 	hipLaunchKernelGGL(c2a_kernel, dim3(n_blocks), dim3(64 * C2A_WAVES), shmem, (hipStream_t)stream, P, X, n_reads, d_seq, d_off,
 	                   d_len, d_chain_beg, d_chain_cnt, d_chains, d_seeds, d_srt, d_reg_beg, d_regs, d_nregs, d_tab, tab_stride, d_pac, d_counters,
-	                   max_len, d_order);
+	                   max_len, d_order, U);
 }
 
 } // namespace mbw

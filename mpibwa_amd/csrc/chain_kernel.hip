@@ -595,14 +595,25 @@ chain_general_kernel(ChainParams P, const int *__restrict__ list, const unsigned
 }
 
 // regions from their per-read slots into one dense array (reg_pos = exclusive prefix of n_regs)
+// (a read whose chains were extended as independent units, c2a_groups.hip: its regions lie per chain, and go back into the read's
+// chain order — the order the serial walk of src/bwamem.c:632-786 produces them in)
 __global__ void reg_pack_kernel(int n_reads, const int *__restrict__ reg_beg, const int *__restrict__ n_regs, const int *__restrict__ reg_pos,
-                                const DevReg *__restrict__ regs, DevReg *__restrict__ packed)
+                                const DevReg *__restrict__ regs, DevReg *__restrict__ packed, C2aUnits U, const int *__restrict__ chain_beg,
+                                const int *__restrict__ chain_cnt)
 {
 	const int r = blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= n_reads) return;
 	const int m = n_regs[r];
-	const DevReg *src = regs + reg_beg[r];
 	DevReg *dst = packed + reg_pos[r];
+	if (U.max_units > 0 && chain_cnt[r] > U.heavy_t) {
+		int k = 0;
+		for (int ci = chain_beg[r]; ci < chain_beg[r] + chain_cnt[r]; ++ci) {
+			const DevReg *src = regs + U.c_rabs[ci];
+			for (int j = 0; j < U.c_rcnt[ci]; ++j) dst[k++] = src[j];
+		}
+		return;
+	}
+	const DevReg *src = regs + reg_beg[r];
 	for (int k = 0; k < m; ++k) dst[k] = src[k];
 }
 
@@ -618,12 +629,14 @@ size_t reg_pack_tmp_bytes(int n_reads)
 // d_nregs must hold n_reads + 1 entries (the last one is ignored and may be anything); d_reg_pos gets n_reads + 1
 // entries, the last one being the total.  Everything is queued on `stream`: no host round trip between c2a and the copy.
 void launch_reg_pack(void *stream, int n_reads, const int *d_reg_beg, const int *d_nregs, int *d_reg_pos, const DevReg *d_regs, DevReg *d_packed,
-                     void *d_tmp, size_t tmp_bytes)
+                     void *d_tmp, size_t tmp_bytes, const C2aUnits *units, const int *d_chain_beg, const int *d_chain_cnt)
 {
+	C2aUnits U;
+	if (units) U = *units;
 	if (n_reads <= 0) return;
 	HIP_OK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_nregs, d_reg_pos, n_reads + 1, (hipStream_t)stream));
 	hipLaunchKernelGGL(reg_pack_kernel, dim3((n_reads + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_reads, d_reg_beg, d_nregs, d_reg_pos, d_regs,
-	                   d_packed);
+	                   d_packed, U, d_chain_beg, d_chain_cnt);
 	HIP_OK(hipGetLastError());
 }
 

@@ -123,13 +123,26 @@ struct C2aParams {
 	int a, w, pen_clip5, pen_clip3;
 	int early;    // 1: row loops end as soon as no output the kernel reads can change (wave_ext.cuh); 0: the reference's rows; 2: both, differences counted
 };
+// Reads with more than `heavy_t` chains are not walked by one wavefront: their chains are split into independent groups
+// (c2a_groups.hip) and every group is a unit of its own.  max_units = 0: no such reads in the launch.
+struct C2aUnits {
+	int max_units = 0, heavy_t = 0;
+	const unsigned int *n_units = nullptr;   // units that exist (<= max_units)
+	const int *ustart = nullptr;             // unit u: chains clist[ustart[u] .. ustart[u + 1])
+	const int *unit_rd = nullptr, *unit_av = nullptr;   // its read; first region slot of the unit
+	const int *clist = nullptr;
+	int *c_rabs = nullptr, *c_rcnt = nullptr;           // per chain (same numbering as the chain array): where its regions are, how many
+};
+size_t c2a_groups_scratch_bytes(int n_el);
+void launch_c2a_groups(void *stream, int n_el, int n_heavy, const int *d_hoff, const int *d_heavy, const int *d_chain_beg, const int *d_reg_beg,
+                       const DevChain *d_chains, void *d_scratch, int *d_clist, int *d_ustart, int *d_unit_rd, int *d_unit_av, unsigned int *d_n_units);
 // counters of c2a_kernel: C2A_STAT_SLOTS lines of 8 u64 (zeroed by the caller, summed by the caller): [0] DP cells computed, [1] extensions,
 // [2] extensions answered without DP, [3] (early = 2) extensions whose used outputs differ
 #define C2A_STAT_SLOTS 256
 void launch_c2a(void *stream, const C2aParams &P, const ExtParams &ep, int n_reads, const uint8_t *d_seq, const int64_t *d_off,
                 const int *d_len, const int *d_chain_beg, const int *d_chain_cnt, const DevChain *d_chains, const DevSeed *d_seeds, unsigned int *d_srt,
                 const int *d_reg_beg, DevReg *d_regs, int *d_nregs, const int *d_tab, int tab_stride, const uint8_t *d_pac, unsigned long long *d_counters,
-                int max_len, const int *d_order = nullptr);
+                int max_len, const int *d_order = nullptr, const C2aUnits *units = nullptr /* then d_nregs must be zeroed */);
 
 // ---- seeds -> chains -> filtered chains on the device (chain_kernel.hip) ----
 struct ChainParams {
@@ -148,7 +161,7 @@ size_t chain_general_bytes(int cap, int n_reads);   // scratch of launch_chain: 
 
 size_t reg_pack_tmp_bytes(int n_reads);
 void launch_reg_pack(void *stream, int n_reads, const int *d_reg_beg, const int *d_nregs, int *d_reg_pos, const DevReg *d_regs, DevReg *d_packed,
-                     void *d_tmp, size_t tmp_bytes);
+                     void *d_tmp, size_t tmp_bytes, const C2aUnits *units = nullptr, const int *d_chain_beg = nullptr, const int *d_chain_cnt = nullptr);
 
 // ---- final global re-alignment on the device (aln_kernel.hip) ----
 struct AlnReq {                  // one call of mem_reg2aln's DP loop (src/bwamem.c:1106-1122)

@@ -395,6 +395,9 @@ struct Workspace {
 	DevBuf nch, chain_cnt, reg_pos, regs_packed, ann_off, ann_alt, pack_tmp, order, chain_gen, c2a_stat;
 	PinBuf h_c2a_stat;
 	PinBuf h_order;
+	// reads with many chains, extended as independent groups of chains (c2a_groups.hip)
+	PinBuf h_heavy, h_hoff, h_nunits;
+	DevBuf heavy, hoff, grp_scratch, grp_clist, grp_ustart, grp_unit_rd, grp_unit_av, grp_nunits, c_rabs, c_rcnt;
 	PinBuf h_regs2;
 	PinBuf h_flat, h_sa, h_qbl, h_chains, h_seeds, h_srt, h_regs, h_nregs, h_mreq[2], h_mres[2], h_ahdr[2], h_apool[2];
 	DevBuf mreq[2], mres[2], mrows[2], alist[2];
@@ -1072,6 +1075,43 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			}
 			int *d_order = (int *)W.order.ensure((size_t)n * 4);
 			HIP_OK(hipMemcpyAsync(d_order, order, (size_t)n * 4, hipMemcpyHostToDevice, st));
+			// Reads with more than a handful of chains (high-copy repeats: hundreds of chains at hundreds of loci) are not walked by one
+			// wavefront: their chains are split into groups that cannot see each other's regions (c2a_groups.hip), a unit of c2a_kernel each.
+			// MPIBWA_C2A_HEAVY=<chains> moves the threshold (0: every read is walked by one wavefront, as before round 4).
+			static const int heavy_t = getenv("MPIBWA_C2A_HEAVY") ? atoi(getenv("MPIBWA_C2A_HEAVY")) : 8;
+			C2aUnits units;
+			if (heavy_t > 0) {
+				int n_heavy = 0;
+				int64_t n_el = 0;
+				for (int i = 0; i < n; ++i)
+					if (chain_cnt[i] > heavy_t) { ++n_heavy; n_el += chain_cnt[i]; }
+				if (n_heavy > 0 && n_el < 0x7fffffff) {
+					int *hv = (int *)W.h_heavy.ensure((size_t)n_heavy * 4 + 64), *ho = (int *)W.h_hoff.ensure((size_t)(n_heavy + 1) * 4 + 64);
+					int k = 0, tot = 0;
+					for (int i = 0; i < n; ++i)
+						if (chain_cnt[i] > heavy_t) { hv[k] = i; ho[k] = tot; tot += chain_cnt[i]; ++k; }
+					ho[k] = tot;
+					int *d_hv = (int *)W.heavy.ensure((size_t)n_heavy * 4), *d_ho = (int *)W.hoff.ensure((size_t)(n_heavy + 1) * 4);
+					void *d_gs = W.grp_scratch.ensure(c2a_groups_scratch_bytes((int)n_el));
+					int *d_clist = (int *)W.grp_clist.ensure((size_t)n_el * 4), *d_ustart = (int *)W.grp_ustart.ensure((size_t)(n_el + 1) * 4);
+					int *d_urd = (int *)W.grp_unit_rd.ensure((size_t)n_el * 4), *d_uav = (int *)W.grp_unit_av.ensure((size_t)n_el * 4);
+					unsigned int *d_nu = (unsigned int *)W.grp_nunits.ensure(64);
+					const size_t n_chain_slots = (size_t)std::max<int64_t>(base + NC, 1);
+					units.c_rabs = (int *)W.c_rabs.ensure(n_chain_slots * 4);
+					units.c_rcnt = (int *)W.c_rcnt.ensure(n_chain_slots * 4);
+					HIP_OK(hipMemcpyAsync(d_hv, hv, (size_t)n_heavy * 4, hipMemcpyHostToDevice, st));
+					HIP_OK(hipMemcpyAsync(d_ho, ho, (size_t)(n_heavy + 1) * 4, hipMemcpyHostToDevice, st));
+					launch_c2a_groups(st, (int)n_el, n_heavy, d_ho, d_hv, d_chain_beg, d_reg_beg, d_chains, d_gs, d_clist, d_ustart, d_urd, d_uav, d_nu);
+					// (the number of units sizes the launch: a grid padded to the number of chains would be millions of empty workgroups)
+					unsigned int *nu = (unsigned int *)W.h_nunits.ensure(64);
+					HIP_OK(hipMemcpyAsync(nu, d_nu, 4, hipMemcpyDeviceToHost, st));
+					stream_wait(st);
+					HIP_OK(hipGetLastError());
+					units.max_units = (int)nu[0]; units.heavy_t = heavy_t; units.n_units = d_nu; units.ustart = d_ustart;
+					units.unit_rd = d_urd; units.unit_av = d_uav; units.clist = d_clist;
+					HIP_OK(hipMemsetAsync(d_nregs, 0, (size_t)(n + 1) * 4, st));   // the units of a read add their regions up
+				}
+			}
 			C2aParams cp;
 			cp.l_pac = bns->l_pac; cp.a = opt->a; cp.w = opt->w; cp.pen_clip5 = opt->pen_clip5; cp.pen_clip3 = opt->pen_clip3;
 			cp.early = c2a_early_mode();
@@ -1085,7 +1125,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			ev_ext.start(st);
 			// one wavefront per read (any read length)
 			launch_c2a(st, cp, ep, n, d_seq, d_off_r, d_len_r, d_chain_beg, d_chain_cnt, d_chains, d_seeds, d_srt, d_reg_beg, d_regs, d_nregs,
-			           d_tab, TS, (const uint8_t *)ix.d_pac, d_c2a_stat, max_len, d_order);
+			           d_tab, TS, (const uint8_t *)ix.d_pac, d_c2a_stat, max_len, d_order, units.max_units > 0 ? &units : nullptr);
 			ev_ext.stop(st);
 			// the regions sit in sparse per-read slots: prefix-sum + pack on the device, queued behind the kernel, then one
 			// copy of what is usually enough (2 regions per read); the rare rest follows once the total is known
@@ -1094,7 +1134,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			DevReg *d_packed = (DevReg *)W.regs_packed.ensure((size_t)n_slots * sizeof(DevReg));
 			const size_t tmp_bytes = reg_pack_tmp_bytes(n);
 			void *d_tmp = W.pack_tmp.ensure(tmp_bytes);
-			launch_reg_pack(st, n, d_reg_beg, d_nregs, d_reg_pos, d_regs, d_packed, d_tmp, tmp_bytes);
+			launch_reg_pack(st, n, d_reg_beg, d_nregs, d_reg_pos, d_regs, d_packed, d_tmp, tmp_bytes, units.max_units > 0 ? &units : nullptr, d_chain_beg, d_chain_cnt);
 			if (d_pr_first) launch_first_reg(st, n, d_reg_pos, d_nregs, d_packed, d_pr_first + (size_t)lo * PR_MAXREG, d_pr_nfirst + lo);
 			hregs = (DevReg *)W.h_regs.ensure((size_t)guess * sizeof(DevReg) + 8);
 			unsigned long long *stat_h = (unsigned long long *)W.h_c2a_stat.ensure(C2A_STAT_SLOTS * 64);
