@@ -21,6 +21,8 @@
 // Latency-bound integer work: ~1.5 k instructions per ordinary read, a few hundred bytes of HBM per read.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <algorithm>
+#include <cstdlib>
 #include "device.h"
 
 namespace mbw {
@@ -590,8 +592,478 @@ chain_general_kernel(ChainParams P, const int *__restrict__ list, const unsigned
 	L.cid_ = base + (size_t)F_NFIELDS_GEN * CK_MAXCH_GEN * 4;
 	L.ord_ = L.cid_ + 256; L.tmp_ = L.ord_ + 256; L.next_ = L.tmp_ + 256;
 	L.nodes = (GenNode *)(L.next_ + 256);
-	n_chains[rd] = chain_read<StoreGen, MapBtree>(L, P, rd, n_seeds[rd], lens[rd], seed_off[rd], l_rep, sa, qbl, ann_off, ann_alt, n_seqs, tab, chains,
-	                                               seeds, srt);
+	const int r = chain_read<StoreGen, MapBtree>(L, P, rd, n_seeds[rd], lens[rd], seed_off[rd], l_rep, sa, qbl, ann_off, ann_alt, n_seqs, tab, chains,
+	                                              seeds, srt);
+	n_chains[rd] = r < 0 ? -2 : r;   // (-2: declined for good — the next round of this kernel must not pick the read again)
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// chain_heavy_kernel (round 4): the reads with MORE than 255 seeds — reads of high-copy repeats: max_occ (500) occurrences
+// of each of several intervals, hundreds to a few thousand seeds and nearly as many chains — one WAVEFRONT per read.
+//   * mem_chain (src/bwamem.c:251-315) is sequential in the seeds (every seed meets the ordered map as the earlier ones left it):
+//     lane 0 walks them, with the B-tree (kb_intervalp / kb_putp, t = 5, the same rules as MapBtree above with 16-bit chain
+//     numbers) and the chains' positions in LDS, the other per-chain fields in a slice of HBM scratch the wave keeps;
+//   * mem_chain_weight (:213-237) runs a chain per lane;
+//   * mem_chain_flt's unstable sort (:341) is ks_introsort on (weight, chain) words in LDS, lane 0;
+//   * its pairwise pass (:346-367) — every chain against every chain kept so far, n^2 / 2 tests for a repeat whose chains all
+//     overlap and all survive: the host spent 300 k cycles per such read here — runs 64 kept chains per step, the columns of the
+//     kept chains (query span, weight, ALT flag, first shadowed chain) in the LDS the tree no longer needs, a break found by ballot;
+//   * emission as chain_read above, a kept chain per lane, output positions by a wave prefix sum.
+// Persistent waves take reads from a list (chain_pick_kernel) through a counter.  CAP = seeds (hence chains) a read may have in
+// the instantiation: 1024 (21 KB of LDS per wave) and 4096 (84 KB); more seeds than that, or reads long enough for
+// mem_flt_chained_seeds to act, stay with the host.
+// ---------------------------------------------------------------------------------------------------------------------
+struct HvNode { uint8_t internal, n; uint16_t key[9]; uint16_t child[10]; };   // 40 bytes
+#define HV_NONE 0xFFFFu
+__host__ __device__ constexpr int hv_nodes(int cap) { return cap * 5 / 16 + 16; }   // every node but the root holds >= 4 keys: leaves <= n / 4, their parents <= a quarter of that
+__host__ __device__ constexpr size_t hv_lds_bytes(int cap) { return (size_t)cap * 8 + (size_t)hv_nodes(cap) * sizeof(HvNode); }
+__host__ __device__ constexpr size_t hv_scratch_bytes(int cap) { return (size_t)cap * (8 + 4 + 10 * 2) + 256; }
+struct HvStore {   // per-chain fields and per-seed links of the read in hand (HBM, the wave's slice)
+	i64 *last_r; uint32_t *rid;
+	uint16_t *first_q, *last_q, *last_len, *nmem, *head, *tail, *w, *cid, *next, *ord;
+};
+struct HvTree {
+	HvNode *nodes; i64 *pos;   // LDS
+	int n, n_nodes, root, max_nodes;
+	bool full;
+	__device__ __forceinline__ int make()
+	{
+		if (n_nodes == max_nodes) { full = true; return 0; }
+		nodes[n_nodes].internal = 0; nodes[n_nodes].n = 0;
+		return n_nodes++;
+	}
+	__device__ __forceinline__ int locate(const HvNode &x, i64 p, int *r) const
+	{
+		int begin = 0, end = x.n;
+		if (x.n == 0) return -1;
+		while (begin < end) {
+			const int mid = (begin + end) >> 1;
+			if (pos[x.key[mid]] < p) begin = mid + 1;
+			else end = mid;
+		}
+		if (begin == x.n) { *r = 1; return x.n - 1; }
+		const i64 kp = pos[x.key[begin]];
+		*r = (kp < p) - (p < kp);
+		if (*r < 0) --begin;
+		return begin;
+	}
+	__device__ __forceinline__ int lower(i64 p) const
+	{
+		if (n == 0) return -1;
+		int low = -1, r = 0, xi = root;
+		for (;;) {
+			const HvNode &x = nodes[xi];
+			const int i = locate(x, p, &r);
+			if (i >= 0 && r == 0) return x.key[i];
+			if (i >= 0) low = x.key[i];
+			if (!x.internal) return low;
+			xi = x.child[i + 1];
+		}
+	}
+	__device__ __forceinline__ void split(int xi, int i, int yi)
+	{
+		const int zi = make();
+		if (full) return;
+		HvNode &x = nodes[xi], &y = nodes[yi], &z = nodes[zi];
+		z.internal = y.internal;
+		z.n = 4;
+		for (int k = 0; k < 4; ++k) z.key[k] = y.key[5 + k];
+		if (y.internal) for (int k = 0; k < 5; ++k) z.child[k] = y.child[5 + k];
+		y.n = 4;
+		for (int k = x.n; k > i; --k) x.child[k + 1] = x.child[k];
+		x.child[i + 1] = (uint16_t)zi;
+		for (int k = x.n - 1; k >= i; --k) x.key[k + 1] = x.key[k];
+		x.key[i] = y.key[4];
+		++x.n;
+	}
+	__device__ __forceinline__ bool put(int id, i64 p)
+	{
+		if (n_nodes == 0) root = make();
+		int r = root, rr = 0;
+		if (nodes[r].n == 9) {
+			const int si = make();
+			if (full) return false;
+			root = si; nodes[si].internal = 1; nodes[si].n = 0;
+			nodes[si].child[0] = (uint16_t)r;
+			split(si, 0, r);
+			if (full) return false;
+			r = si;
+		}
+		int xi = r;
+		while (nodes[xi].internal) {
+			int i = locate(nodes[xi], p, &rr) + 1;
+			if (nodes[nodes[xi].child[i]].n == 9) {
+				split(xi, i, nodes[xi].child[i]);
+				if (full) return false;
+				if (pos[nodes[xi].key[i]] < p) ++i;
+			}
+			xi = nodes[xi].child[i];
+		}
+		HvNode &x = nodes[xi];
+		const int i = locate(x, p, &rr);
+		for (int k = x.n - 1; k > i; --k) x.key[k + 1] = x.key[k];
+		x.key[i + 1] = (uint16_t)id;
+		++x.n;
+		++n;
+		return true;
+	}
+	__device__ __forceinline__ void in_order(uint16_t *ord) const
+	{
+		if (n == 0) return;
+		int sn[10], si[10], sp = 0, out = 0;
+		sn[0] = root; si[0] = 0;
+		while (sp >= 0) {
+			const HvNode &x = nodes[sn[sp]];
+			if (!x.internal) {
+				for (int k = 0; k < x.n; ++k) ord[out++] = x.key[k];
+				--sp;
+				continue;
+			}
+			const int i = si[sp];
+			if (i > 0 && i <= x.n) ord[out++] = x.key[i - 1];
+			if (i <= x.n) { si[sp] = i + 1; ++sp; sn[sp] = x.child[i]; si[sp] = 0; }
+			else --sp;
+		}
+	}
+};
+// ks_introsort (src/ksort.h:176-226) of n words, "less" = the heavier chain first (the weight is the word's upper half)
+__device__ __forceinline__ bool hv_lt(uint32_t a, uint32_t b) { return (a >> 16) > (b >> 16); }
+__device__ __forceinline__ void hv_insertion(uint32_t *a, int s, int t)
+{
+	for (int i = s + 1; i < t; ++i)
+		for (int j = i; j > s && hv_lt(a[j], a[j - 1]); --j) { const uint32_t x = a[j]; a[j] = a[j - 1]; a[j - 1] = x; }
+}
+__device__ __forceinline__ void hv_comb(uint32_t *a, int s0, int n)
+{
+	const double shrink = 1.2473309501039786540366528676643;
+	int gap = n;
+	bool swapped;
+	do {
+		if (gap > 2) {
+			gap = (int)((double)gap / shrink);
+			if (gap == 9 || gap == 10) gap = 11;
+		}
+		swapped = false;
+		for (int i = s0; i < s0 + n - gap; ++i) {
+			const int j = i + gap;
+			if (hv_lt(a[j], a[i])) { const uint32_t x = a[i]; a[i] = a[j]; a[j] = x; swapped = true; }
+		}
+	} while (swapped || gap > 2);
+	if (gap != 1) hv_insertion(a, s0, s0 + n);
+}
+__device__ __forceinline__ void hv_introsort(uint32_t *a, int n)
+{
+	if (n < 2) return;
+	if (n == 2) {
+		if (hv_lt(a[1], a[0])) { const uint32_t x = a[0]; a[0] = a[1]; a[1] = x; }
+		return;
+	}
+	int d = 2;
+	while ((1 << d) < n) ++d;
+	int fs[32], ft[32], fd[32], sp = 0;
+	int s = 0, t = n - 1;
+	d <<= 1;
+	for (;;) {
+		if (s < t) {
+			if (--d == 0) {
+				hv_comb(a, s, t - s + 1);
+				t = s;
+				continue;
+			}
+			int i = s, j = t, k = i + ((j - i) >> 1) + 1;
+			if (hv_lt(a[k], a[i])) { if (hv_lt(a[k], a[j])) k = j; }
+			else k = hv_lt(a[j], a[i]) ? i : j;
+			const uint32_t pivot = a[k];
+			if (k != t) { const uint32_t x = a[k]; a[k] = a[t]; a[t] = x; }
+			for (;;) {
+				do ++i; while (hv_lt(a[i], pivot));
+				do --j; while (i <= j && hv_lt(pivot, a[j]));
+				if (j <= i) break;
+				const uint32_t x = a[i]; a[i] = a[j]; a[j] = x;
+			}
+			{ const uint32_t x = a[i]; a[i] = a[t]; a[t] = x; }
+			if (i - s > t - i) {
+				if (i - s > 16) { fs[sp] = s; ft[sp] = i - 1; fd[sp] = d; ++sp; }
+				s = t - i > 16 ? i + 1 : t;
+			} else {
+				if (t - i > 16) { fs[sp] = i + 1; ft[sp] = t; fd[sp] = d; ++sp; }
+				t = i - s > 16 ? i - 1 : s;
+			}
+		} else {
+			if (sp == 0) { hv_insertion(a, 0, n); return; }
+			--sp;
+			s = fs[sp]; t = ft[sp]; d = fd[sp];
+		}
+	}
+}
+__device__ __forceinline__ void hv_sync()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ int hv_bcast(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+template <int CAP>
+__global__ void __launch_bounds__(64)
+chain_heavy_kernel(ChainParams P, const int *__restrict__ list, const unsigned int *__restrict__ list_n, unsigned int *work, int list_cap,
+                   const int *__restrict__ lens, const int *__restrict__ n_seeds, const int *__restrict__ l_rep, const i64 *__restrict__ seed_off,
+                   const unsigned long long *__restrict__ sa, const int32_t *__restrict__ qbl, const i64 *__restrict__ ann_off,
+                   const uint8_t *__restrict__ ann_alt, int n_seqs, const int *__restrict__ gap, uint8_t *__restrict__ scratch,
+                   DevChain *__restrict__ chains, DevSeed *__restrict__ seeds, unsigned int *__restrict__ srt, int *__restrict__ n_chains)
+{
+	extern __shared__ uint8_t hv_lds[];
+	const int lane = threadIdx.x;
+	// phase A: the tree
+	i64 *pos = (i64 *)hv_lds;
+	HvNode *nodes = (HvNode *)(hv_lds + (size_t)CAP * 8);
+	// phases C-D (the tree is dead by then): sort words, then the columns of the chains in sorted order and of the kept list
+	uint32_t *skey = (uint32_t *)hv_lds;                 // [CAP]
+	uint16_t *cbeg = (uint16_t *)(skey + CAP);           // [CAP] each
+	uint16_t *cend = cbeg + CAP, *kidx = cend + CAP, *kfirst = kidx + CAP;
+	uint8_t *calt = (uint8_t *)(kfirst + CAP), *ckept = calt + CAP;   // [CAP] each: 4 + 8 + 2 = 14 bytes per chain <= the 20.5 of the tree
+	uint8_t *sb = scratch + (size_t)blockIdx.x * hv_scratch_bytes(CAP);
+	HvStore S;
+	S.last_r = (i64 *)sb; S.rid = (uint32_t *)(S.last_r + CAP);
+	S.first_q = (uint16_t *)(S.rid + CAP); S.last_q = S.first_q + CAP; S.last_len = S.last_q + CAP; S.nmem = S.last_len + CAP;
+	S.head = S.nmem + CAP; S.tail = S.head + CAP; S.w = S.tail + CAP; S.cid = S.w + CAP; S.next = S.cid + CAP; S.ord = S.next + CAP;
+	const i64 l_pac = P.l_pac;
+	const int n_list = (int)(*list_n < (unsigned int)list_cap ? *list_n : (unsigned int)list_cap);
+	for (;;) {
+		int t = 0;
+		if (lane == 0) t = (int)atomicAdd(work, 1u);
+		t = hv_bcast(t);
+		if (t >= n_list) break;
+		const int rd = hv_bcast(list[t]);
+		const int ns = hv_bcast(n_seeds[rd]), lq = hv_bcast(lens[rd]);
+		const i64 so = seed_off[rd];
+		auto S_R = [&](int k) -> i64 { return (i64)sa[so + k]; };
+		auto S_Q = [&](int k) -> int { return qbl[2 * (so + k)]; };
+		auto S_L = [&](int k) -> int { return qbl[2 * (so + k) + 1]; };
+		if (ns > CAP) continue;   // (the list only holds reads that fit; n_chains stays -1: host)
+		// ---------------- mem_chain: lane 0 ----------------
+		int n_ch = 0, ok = 1;
+		if (lane == 0) {
+			HvTree T;
+			T.nodes = nodes; T.pos = pos; T.n = 0; T.n_nodes = 0; T.root = 0; T.max_nodes = hv_nodes(CAP); T.full = false;
+			i64 c_lo = 0, c_hi = -1;
+			int c_rid = -1;
+			for (int k = 0; k < ns; ++k) {
+				const i64 rb = S_R(k);
+				const int qb = S_Q(k), len = S_L(k);
+				S.cid[k] = HV_NONE;
+				int rid;
+				if (rb >= c_lo && rb + len <= c_hi && len > 0) rid = c_rid;
+				else {   // bns_intv2rid, src/bntseq.c:365-376
+					if (rb < l_pac && rb + len > l_pac) rid = -2;
+					else {
+						const int rid_b = ck_pos2rid(ann_off, n_seqs, l_pac, ck_depos(l_pac, rb));
+						const int rid_e = len > 0 ? ck_pos2rid(ann_off, n_seqs, l_pac, ck_depos(l_pac, rb + len - 1)) : rid_b;
+						rid = rid_b == rid_e ? rid_b : -1;
+					}
+					if (rid >= 0) {
+						const i64 o = ann_off[rid], l = ann_off[rid + 1] - o;
+						if (rb < l_pac) { c_lo = o; c_hi = o + l; }
+						else { c_lo = (l_pac << 1) - o - l; c_hi = (l_pac << 1) - o; }
+						c_rid = rid;
+					}
+				}
+				if (rid < 0) continue;
+				const int id0 = T.lower(rb);
+				bool merged = false;
+				if (id0 >= 0 && (int)S.rid[id0] == rid) {   // test_and_merge, src/bwamem.c:190-211
+					const i64 first_r = pos[id0], last_r = S.last_r[id0];
+					const int first_q = S.first_q[id0], last_q = S.last_q[id0], last_len = S.last_len[id0];
+					const int qend = last_q + last_len;
+					const i64 rend = last_r + last_len;
+					if (qb >= first_q && qb + len <= qend && rb >= first_r && rb + len <= rend) merged = true;
+					else if (!((last_r < l_pac || first_r < l_pac) && rb >= l_pac)) {
+						const i64 x = qb - last_q, y = rb - last_r;
+						if (y >= 0 && x - y <= P.w && y - x <= P.w && x - last_len < P.max_chain_gap && y - last_len < P.max_chain_gap) {
+							S.last_r[id0] = rb; S.last_q[id0] = (uint16_t)qb; S.last_len[id0] = (uint16_t)len;
+							S.nmem[id0] += 1;
+							S.cid[k] = (uint16_t)id0;
+							S.next[S.tail[id0]] = (uint16_t)k; S.next[k] = HV_NONE; S.tail[id0] = (uint16_t)k;
+							merged = true;
+						}
+					}
+				}
+				if (merged) continue;
+				const int id = n_ch;
+				pos[id] = rb;
+				S.last_r[id] = rb; S.rid[id] = (uint32_t)rid;
+				S.first_q[id] = (uint16_t)qb; S.last_q[id] = (uint16_t)qb; S.last_len[id] = (uint16_t)len; S.nmem[id] = 1;
+				S.head[id] = S.tail[id] = (uint16_t)k; S.next[k] = HV_NONE;
+				if (!T.put(id, rb)) { ok = 0; break; }
+				S.cid[k] = (uint16_t)id;
+				++n_ch;
+			}
+			if (ok) T.in_order(S.ord);
+		}
+		ok = hv_bcast(ok); n_ch = hv_bcast(n_ch);
+		hv_sync();
+		if (!ok) { if (lane == 0) n_chains[rd] = -2; continue; }
+		// ---------------- mem_chain_weight: a chain per lane; the chains that weigh enough, in tree order, as sort words ----------------
+		int n = 0;
+		for (int t0 = 0; t0 < n_ch; t0 += 64) {
+			const int tt = t0 + lane;
+			int w = 0, id = 0;
+			if (tt < n_ch) {
+				id = S.ord[tt];
+				i64 end = 0;
+				int wq;
+				for (int k = S.head[id]; k != HV_NONE; k = S.next[k]) {
+					const int qb = S_Q(k), len = S_L(k);
+					if (qb >= end) w += len;
+					else if (qb + len > end) w += (int)(qb + len - end);
+					end = end > qb + len ? end : qb + len;
+				}
+				wq = w; w = 0; end = 0;
+				for (int k = S.head[id]; k != HV_NONE; k = S.next[k]) {
+					const i64 rb = S_R(k);
+					const int len = S_L(k);
+					if (rb >= end) w += len;
+					else if (rb + len > end) w += (int)(rb + len - end);
+					end = end > rb + len ? end : rb + len;
+				}
+				w = w < wq ? w : wq;
+			}
+			const bool pass = tt < n_ch && w >= P.min_chain_weight && w < 65536;
+			if (__ballot(tt < n_ch && w >= 65536)) ok = 0;   // (a weight beyond the sort word: reads of more than 65 kbp never come here)
+			const unsigned long long m = __ballot(pass);
+			if (pass) skey[n + __popcll(m & ((1ull << lane) - 1))] = (uint32_t)w << 16 | (uint32_t)id;
+			n += __popcll(m);
+		}
+		hv_sync();
+		if (!ok) { if (lane == 0) n_chains[rd] = -2; continue; }
+		if (n == 0) { if (lane == 0) n_chains[rd] = 0; continue; }
+		if (lane == 0) hv_introsort(skey, n);
+		hv_sync();
+		// ---------------- mem_chain_flt's pairwise pass: 64 kept chains per step ----------------
+		for (int t0 = 0; t0 < n; t0 += 64) {
+			const int tt = t0 + lane;
+			if (tt < n) {
+				const int id = skey[tt] & 0xffff;
+				cbeg[tt] = S.first_q[id];
+				cend[tt] = (uint16_t)(S.last_q[id] + S.last_len[id]);
+				calt[tt] = ann_alt[S.rid[id]];
+				ckept[tt] = 0;
+			}
+		}
+		if (lane == 0) { ckept[0] = 3; kidx[0] = 0; kfirst[0] = HV_NONE; }
+		hv_sync();
+		int nk = 1;
+		for (int i = 1; i < n; ++i) {
+			const int bi = cbeg[i], ei = cend[i], li = ei - bi, wi = (int)(skey[i] >> 16), alt_i = calt[i];
+			bool large = false, broke = false;
+			for (int k0 = 0; k0 < nk && !broke; k0 += 64) {
+				const int kk = k0 + lane;
+				bool sig = false, brk = false;
+				if (kk < nk) {
+					const int j = kidx[kk];
+					const int bj = cbeg[j], ej = cend[j];
+					const int b_max = bj > bi ? bj : bi, e_min = ej < ei ? ej : ei;
+					if (e_min > b_max && (!calt[j] || alt_i)) {
+						const int lj = ej - bj, min_l = li < lj ? li : lj;
+						if ((float)(e_min - b_max) >= (float)min_l * P.mask_level && min_l < P.max_chain_gap) {
+							sig = true;
+							const int wj = (int)(skey[j] >> 16);
+							brk = (float)wi < (float)wj * P.drop_ratio && wj - wi >= P.min_seed_len << 1;
+						}
+					}
+				}
+				unsigned long long sm = __ballot(sig);
+				const unsigned long long bm = __ballot(brk);
+				if (bm) {   // the reference stops at the first such chain: what lies behind it is not looked at
+					const int fb = __ffsll((long long)bm) - 1;
+					sm &= fb == 63 ? ~0ull : ((2ull << fb) - 1);
+					broke = true;
+				}
+				if (sm) {
+					large = true;
+					if ((sm >> lane) & 1) { if (kfirst[kk] == HV_NONE) kfirst[kk] = (uint16_t)i; }
+				}
+			}
+			if (!broke) {
+				if (lane == 0) { kidx[nk] = (uint16_t)i; kfirst[nk] = HV_NONE; ckept[i] = large ? 2 : 3; }
+				++nk;
+			}
+			hv_sync();
+		}
+		for (int k0 = 0; k0 < nk; k0 += 64) {
+			const int kk = k0 + lane;
+			if (kk < nk && kfirst[kk] != HV_NONE) ckept[kfirst[kk]] = 1;
+		}
+		hv_sync();
+		if (P.max_chain_extend < n) {   // at most max_chain_extend chains with kept = 1 or 2 are extended (src/bwamem.c:372-379)
+			if (lane == 0) {
+				int i = 0, cnt = 0;
+				for (; i < n; ++i) {
+					if (ckept[i] == 0 || ckept[i] == 3) continue;
+					if (++cnt >= P.max_chain_extend) break;
+				}
+				for (; i < n; ++i)
+					if (ckept[i] < 3) ckept[i] = 0;
+			}
+			hv_sync();
+		}
+		// ---------------- emission: a kept chain per lane, where it goes by prefix sums ----------------
+		const float frac_rep = (float)l_rep[rd] / (float)lq;
+		int n_out = 0;
+		i64 cursor = so;
+		for (int t0 = 0; t0 < n; t0 += 64) {
+			const int tt = t0 + lane;
+			const bool kept = tt < n && ckept[tt] != 0;
+			const int id = kept ? (int)(skey[tt] & 0xffff) : 0;
+			const int cs = kept ? (int)S.nmem[id] : 0;
+			int pre = cs;   // inclusive prefix sum over the lanes
+			for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(pre, o); if (lane >= o) pre += v; }
+			const unsigned long long km = __ballot(kept);
+			const i64 my_cur = cursor + (pre - cs);
+			const int my_out = n_out + __popcll(km & ((1ull << lane) - 1));
+			if (kept) {
+				// members in arrival order, then (stable) by length: the order mem_chain2aln visits them backwards in (src/bwamem.c:662-667)
+				int a = 0;
+				for (int k = S.head[id]; k != HV_NONE; k = S.next[k], ++a) {
+					DevSeed ds;
+					ds.rbeg = S_R(k); ds.qbeg = S_Q(k); ds.len = S_L(k);
+					int b = a;
+					while (b > 0 && seeds[my_cur + b - 1].len > ds.len) { seeds[my_cur + b] = seeds[my_cur + b - 1]; --b; }
+					seeds[my_cur + b] = ds;
+				}
+				i64 lo = l_pac << 1, hi = 0;
+				for (a = 0; a < cs; ++a) {
+					const DevSeed ds = seeds[my_cur + a];
+					srt[my_cur + a] = (unsigned int)a;
+					const i64 b = ds.rbeg - (ds.qbeg + gap[ds.qbeg]);
+					const int tail = lq - ds.qbeg - ds.len;
+					const i64 e = ds.rbeg + ds.len + (tail + gap[tail]);
+					lo = b < lo ? b : lo;
+					hi = e > hi ? e : hi;
+				}
+				const int rid = (int)S.rid[id];
+				const i64 first_r = S_R(S.head[id]);
+				DevChain d;
+				i64 fb = ann_off[rid], fe = ann_off[rid + 1];
+				if (first_r >= l_pac) { const i64 x = fb; fb = (l_pac << 1) - fe; fe = (l_pac << 1) - x; }
+				d.far_beg = fb; d.far_end = fe;
+				d.seed_beg = (int)my_cur; d.n_seeds = cs; d.rid = rid; d.frac_rep = frac_rep;
+				d.rmax0 = lo > 0 ? lo : 0;
+				d.rmax1 = hi < l_pac << 1 ? hi : l_pac << 1;
+				if (d.rmax0 < l_pac && l_pac < d.rmax1) {
+					if (first_r < l_pac) d.rmax1 = l_pac;
+					else d.rmax0 = l_pac;
+				}
+				d.rmax0 = d.rmax0 > fb ? d.rmax0 : fb;
+				d.rmax1 = d.rmax1 < fe ? d.rmax1 : fe;
+				chains[so + my_out] = d;
+			}
+			cursor += __shfl(pre, 63);
+			n_out += __popcll(km);
+		}
+		if (lane == 0) n_chains[rd] = n_out;
+		hv_sync();   // (the next read reuses the LDS)
+	}
 }
 
 // regions from their per-read slots into one dense array (reg_pos = exclusive prefix of n_regs)
@@ -642,7 +1114,15 @@ void launch_reg_pack(void *stream, int n_reads, const int *d_reg_beg, const int 
 
 static size_t chain_lds_bytes(int maxs, int maxch) { return (size_t)F_NFIELDS * maxch * 64 * 4 + (size_t)(2 * (maxs + 1) + 16) * 64; }
 
-size_t chain_general_bytes(int cap, int n_reads) { return (size_t)cap * CK_GEN_BYTES + (size_t)cap * 4 + (size_t)n_reads * 8 + 512; }
+// scratch of launch_chain: [the B-tree kernel's slices for `cap` reads][its list][two retry lists][counters][two lists of reads with more
+// than 255 seeds][the slices of chain_heavy_kernel's persistent waves]
+#define HV_WAVES_S 1024   // waves of the 1024-seed instantiation (21 KB of LDS each: 7 per CU)
+#define HV_WAVES_L 256    // ... of the 4096-seed one (84 KB: one per CU)
+static size_t heavy_scratch_bytes() { return HV_WAVES_S * hv_scratch_bytes(1024) + HV_WAVES_L * hv_scratch_bytes(4096); }
+size_t chain_general_bytes(int cap, int n_reads)
+{
+	return (size_t)cap * CK_GEN_BYTES + (size_t)cap * 4 + (size_t)n_reads * 8 + 512 + (size_t)n_reads * 8 + 256 + heavy_scratch_bytes();
+}
 
 // d_gen / gen_cap: scratch of chain_general_bytes(gen_cap) for the third launch (reads with more than 9 chains, up to 255
 // seeds and chains, at most gen_cap of them per call); null / 0: those reads keep n_chains = -1 (host path).
@@ -673,8 +1153,10 @@ void launch_chain(void *stream, const ChainParams &P, int n_reads, const int *d_
 		uint8_t *scratch = (uint8_t *)d_gen;
 		int *list_g = (int *)(scratch + (size_t)gen_cap * CK_GEN_BYTES);
 		int *list_a = list_g + gen_cap, *list_b = list_a + n_reads;
-		unsigned int *count = (unsigned int *)(list_b + n_reads);   // [0] general, [1] 64-seed retry, [2] 255-seed retry
-		HIP_OK(hipMemsetAsync(count, 0, 16, st));
+		unsigned int *count = (unsigned int *)(list_b + n_reads);   // [0] general, [1] 64-seed retry, [2] 255-seed retry, [4..7] heavy: list sizes and work counters
+		int *list_h1 = (int *)((uint8_t *)count + 512), *list_h2 = list_h1 + n_reads;
+		uint8_t *hv_scr = (uint8_t *)(((uintptr_t)(list_h2 + n_reads) + 255) & ~(uintptr_t)255);
+		HIP_OK(hipMemsetAsync(count, 0, 64, st));
 		const dim3 pgrid((n_reads + 255) / 256), pblock(256);
 		hipLaunchKernelGGL(chain_pick_kernel, pgrid, pblock, 0, st, n_reads, d_len, d_nseeds, (const int *)d_nchains, noflt, 0, CK_MAXSEEDS, n_reads, list_a, count + 1);
 		hipLaunchKernelGGL((chain_kernel<CK_MAXSEEDS, CK_MAXCH, 0>), grid, block, lds, st, CHAIN_ARGS, (const int *)list_a, (const unsigned int *)(count + 1));
@@ -684,10 +1166,32 @@ void launch_chain(void *stream, const ChainParams &P, int n_reads, const int *d_
 			hipLaunchKernelGGL((chain_kernel<CK_MAXSEEDS_BIG, CK_MAXCH, CK_MAXSEEDS>), grid, block, lds_big, st, CHAIN_ARGS, (const int *)list_b, (const unsigned int *)(count + 2));
 		}
 		if (big >= 2) {
-			hipLaunchKernelGGL(chain_pick_kernel, pgrid, pblock, 0, st, n_reads, d_len, d_nseeds, (const int *)d_nchains, noflt, 0, CK_MAXSEEDS_BIG, gen_cap, list_g, count);
-			hipLaunchKernelGGL(chain_general_kernel, dim3((gen_cap + 63) / 64), dim3(64), 0, st, P, (const int *)list_g, (const unsigned int *)count, gen_cap, d_len,
-			                   d_nseeds, d_lrep, (const i64 *)d_seed_off, (const unsigned long long *)d_sa, d_qbl, (const i64 *)d_ann_off, d_ann_alt, n_seqs,
-			                   d_tab, scratch, d_chains, d_seeds, d_srt, d_nchains);
+			// the scratch holds gen_cap reads at a time: several rounds over it (on a low-complexity reference a third of the reads have
+			// more than 9 chains; a round that finds nothing left is two empty launches)
+			static const int rounds = getenv("MPIBWA_CHAIN_ROUNDS") ? std::max(1, atoi(getenv("MPIBWA_CHAIN_ROUNDS"))) : 4;
+			for (int r = 0; r < rounds; ++r) {
+				if (r) HIP_OK(hipMemsetAsync(count, 0, 4, st));
+				hipLaunchKernelGGL(chain_pick_kernel, pgrid, pblock, 0, st, n_reads, d_len, d_nseeds, (const int *)d_nchains, noflt, 0, CK_MAXSEEDS_BIG, gen_cap, list_g, count);
+				hipLaunchKernelGGL(chain_general_kernel, dim3((gen_cap + 63) / 64), dim3(64), 0, st, P, (const int *)list_g, (const unsigned int *)count, gen_cap, d_len,
+				                   d_nseeds, d_lrep, (const i64 *)d_seed_off, (const unsigned long long *)d_sa, d_qbl, (const i64 *)d_ann_off, d_ann_alt, n_seqs,
+				                   d_tab, scratch, d_chains, d_seeds, d_srt, d_nchains);
+			}
+		}
+		if (big >= 2 && !(getenv("MPIBWA_CHAIN_HEAVY") && atoi(getenv("MPIBWA_CHAIN_HEAVY")) == 0)) {
+			// reads with more than 255 seeds (high-copy repeats): a wavefront per read, two LDS footprints
+			static bool s_attr2 = false;
+			if (!s_attr2) {
+				HIP_OK(hipFuncSetAttribute((const void *)chain_heavy_kernel<4096>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hv_lds_bytes(4096)));
+				s_attr2 = true;
+			}
+			hipLaunchKernelGGL(chain_pick_kernel, pgrid, pblock, 0, st, n_reads, d_len, d_nseeds, (const int *)d_nchains, noflt, CK_MAXSEEDS_BIG, 1024, n_reads, list_h1, count + 4);
+			hipLaunchKernelGGL(chain_pick_kernel, pgrid, pblock, 0, st, n_reads, d_len, d_nseeds, (const int *)d_nchains, noflt, 1024, 4096, n_reads, list_h2, count + 6);
+			hipLaunchKernelGGL((chain_heavy_kernel<4096>), dim3(HV_WAVES_L), dim3(64), hv_lds_bytes(4096), st, P, (const int *)list_h2, (const unsigned int *)(count + 6), count + 7,
+			                   n_reads, d_len, d_nseeds, d_lrep, (const i64 *)d_seed_off, (const unsigned long long *)d_sa, d_qbl, (const i64 *)d_ann_off, d_ann_alt, n_seqs, d_tab,
+			                   hv_scr + HV_WAVES_S * hv_scratch_bytes(1024), d_chains, d_seeds, d_srt, d_nchains);
+			hipLaunchKernelGGL((chain_heavy_kernel<1024>), dim3(HV_WAVES_S), dim3(64), hv_lds_bytes(1024), st, P, (const int *)list_h1, (const unsigned int *)(count + 4), count + 5,
+			                   n_reads, d_len, d_nseeds, d_lrep, (const i64 *)d_seed_off, (const unsigned long long *)d_sa, d_qbl, (const i64 *)d_ann_off, d_ann_alt, n_seqs, d_tab,
+			                   hv_scr, d_chains, d_seeds, d_srt, d_nchains);
 		}
 	}
 #undef CHAIN_ARGS

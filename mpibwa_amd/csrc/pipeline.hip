@@ -1003,6 +1003,20 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 				        t[0] * 1e-6, t[1] * 1e-6, t[2] * 1e-6, t[3] * 1e-6, t[4] * 1e-6, t[5], t[6], n);
 			}
 		}
+		if (getenv("MPIBWA_CHAIN_HIST")) {   // which reads the host chained: seeds in, chains out (log2 buckets)
+			unsigned long long hs[20] = {0}, hc[20] = {0}, ss[20] = {0};
+			for (int t = 0; t < n_todo; ++t) {
+				int b = 0, c = 0;
+				while ((1 << (b + 1)) <= nseeds[todo[t]] && b < 19) ++b;
+				while ((1 << (c + 1)) <= chain_off[t + 1] && c < 19) ++c;
+				++hs[b]; ss[b] += nseeds[todo[t]]; ++hc[c];
+			}
+			fprintf(stderr, "[chain hist] %d host-chained reads; by seeds (2^b..): ", n_todo);
+			for (int b = 0; b < 20; ++b) if (hs[b]) fprintf(stderr, " %d:%llu(%llu)", b, hs[b], ss[b]);
+			fprintf(stderr, "; by kept chains: ");
+			for (int b = 0; b < 20; ++b) if (hc[b]) fprintf(stderr, " %d:%llu", b, hc[b]);
+			fprintf(stderr, "\n");
+		}
 		chain_off[0] = reg_off[0] = 0;
 		for (int t = 0; t < n_todo; ++t) { chain_off[t + 1] += chain_off[t]; reg_off[t + 1] += reg_off[t]; }
 		const int NC = chain_off[n_todo], NS = reg_off[n_todo];   // chains / kept seeds of the host-chained reads

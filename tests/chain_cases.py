@@ -47,14 +47,14 @@ def adversarial_interval_sets(rng, n_cases, l_pac, offs, n_seqs):
 
 
 
-def repeat_like_interval_sets(rng, n_cases, l_pac, offs, n_seqs):
+def repeat_like_interval_sets(rng, n_cases, l_pac, offs, n_seqs, n_copies=(100, 400), n_ivs=(2, 4)):
     """Reads of a high-copy repeat: two or three intervals with 100 to 400 hits each at unrelated positions, so mem_chain_flt
     sees hundreds of chains of (nearly) equal weight that overlap completely on the query and mostly all survive — the quadratic
     case of its kept-list scan."""
     cases = []
     for it in range(n_cases):
         lq = int(rng.choice([100, 150, 250]))
-        n_copy = int(rng.integers(100, 400))
+        n_copy = int(rng.integers(n_copies[0], n_copies[1]))
         copies = []
         for _ in range(n_copy):
             k = int(rng.integers(0, n_seqs))
@@ -63,7 +63,7 @@ def repeat_like_interval_sets(rng, n_cases, l_pac, offs, n_seqs):
                 p = max(2 * l_pac - 1 - p - lq, l_pac)
             copies.append(p)
         ivs = {}
-        for j in range(int(rng.integers(2, 4))):
+        for j in range(int(rng.integers(n_ivs[0], n_ivs[1]))):
             qb = int(rng.integers(0, lq - 40))
             ln = int(rng.integers(19, min(lq - qb, 60) + 1))
             # most copies carry the interval at its place, some a little off (a gap in the copy), some not at all
