@@ -72,10 +72,14 @@ def main():
     ap.add_argument("--chunks", type=int, default=int(os.environ.get("MPIBWA_BENCH_CHUNKS", "3")),
                     help="distinct chunks per rank the steps cycle through (config 1: 1 M pairs = 3 chunks of 333 334)")
     ap.add_argument("--repeat-frac", type=float, default=float(os.environ.get("MPIBWA_BENCH_REPEAT_FRAC", "0.05")),
-                    help="share of the synthetic genome covered by planted repeat families (real GRCh38 is ~0.5: see README)")
-    ap.add_argument("--genome-model", default=os.environ.get("MPIBWA_BENCH_GENOME_MODEL", "uniform"), choices=["uniform", "grch38like"],
-                    help="uniform: i.i.d. bases + planted repeats of 2-40 copies (the headline workload since round 1); grch38like: SURVEY §8d's "
-                         "generator (order-3 Markov, GC 41 %, repeat families of up to 10^4 copies, 0-5 % divergence), use with --repeat-frac 0.5")
+                    help="share of the synthetic genome covered by planted repeat families (SURVEY §8d config 1: 0.05; real GRCh38 is ~0.5: see README)")
+    ap.add_argument("--genome-model", default=os.environ.get("MPIBWA_BENCH_GENOME_MODEL", "grch38like"), choices=["uniform", "grch38like"],
+                    help="grch38like (default since round 4): SURVEY §8d's generator — order-3 Markov base composition, GC 41 %, repeat families of "
+                         "up to 10^4 copies, 0-5 % divergence; uniform: i.i.d. bases + planted repeats of 2-40 copies (the headline workload of rounds 1-3)")
+    ap.add_argument("--alt-legs", default=os.environ.get("MPIBWA_BENCH_ALT_LEGS", "grch38like:0.5,uniform:0.05"),
+                    help="after the headline (N = 1 only): the same bench, shortened, on these other references (model:repeat_frac,...), each in a "
+                         "child process of its own so that the headline line survives whatever happens there; '' = none")
+    ap.add_argument("--quick", action="store_true", help="no one-call-in-flight leg and no counting pass (the alt legs run this way: no roofline figures)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check-parity", action="store_true",
                     help="every rank also aligns its chunks with the reference (oracle/_ref) and compares the SAM: `parity_all_ranks` "
@@ -272,26 +276,31 @@ def main():
     # the latency mode next to it, outside the timed region: one call in flight, every chunk once (the kernels' durations when
     # they have the GPU to themselves; inside the timed region a launch shares the chip with the kernels of the other calls)
     alone = {}
-    time.sleep(2.2)   # the library treats a caller as a busy one for two seconds after it last had three calls in flight
-    run_steps(1, {}, fly=1)   # (the lone caller's mode has work buffers of its own: first touch outside the figure)
-    drain()
-    ta = time.perf_counter()
-    run_steps(n_chunks, alone, fly=1)
-    torch.cuda.synchronize()
-    alone_s = time.perf_counter() - ta
-    drain()
+    alone_s = None
+    if not args.quick:
+        time.sleep(2.2)   # the library treats a caller as a busy one for two seconds after it last had three calls in flight
+        run_steps(1, {}, fly=1)   # (the lone caller's mode has work buffers of its own: first touch outside the figure)
+        drain()
+        ta = time.perf_counter()
+        run_steps(n_chunks, alone, fly=1)
+        torch.cuda.synchronize()
+        alone_s = time.perf_counter() - ta
+        drain()
     # the algorithmic bytes of the seeding kernel are a property of the reads (64 B per occ block the reference
     # touches + read + output): counted on the device by the counting variant of the kernel, every chunk once, outside the
     # timed region (the production variant leaves the per-extension block arithmetic out); a timed step on chunk c moved
     # exactly those bytes
-    os.environ["MPIBWA_SMEM_COUNT"] = "1"
-    counted = {}
-    run_steps(n_chunks, {}, fly=1, by_chunk=counted)
-    os.environ["MPIBWA_SMEM_COUNT"] = "0"
-    drain()
-    first_timed = step_no[0] - 2 * n_chunks - args.steps
-    acc["smem_bytes"] = sum(counted[s_ % n_chunks]["smem_bytes"] for s_ in range(first_timed, first_timed + args.steps))
-    alone["smem_bytes"] = sum(counted[c]["smem_bytes"] for c in range(n_chunks))
+    if not args.quick:
+        os.environ["MPIBWA_SMEM_COUNT"] = "1"
+        counted = {}
+        run_steps(n_chunks, {}, fly=1, by_chunk=counted)
+        os.environ["MPIBWA_SMEM_COUNT"] = "0"
+        drain()
+        first_timed = step_no[0] - 2 * n_chunks - args.steps
+        acc["smem_bytes"] = sum(counted[s_ % n_chunks]["smem_bytes"] for s_ in range(first_timed, first_timed + args.steps))
+        alone["smem_bytes"] = sum(counted[c]["smem_bytes"] for c in range(n_chunks))
+    else:
+        acc["smem_bytes"] = 0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -348,7 +357,7 @@ def main():
         "sam_bytes_per_step": int(sam_bytes / args.steps),
         "sam_records_written_by_device_frac": round(acc.get("n_sam_dev", 0) / max(1, acc.get("n_reads", 1)), 4),
         "one_call_in_flight": {"value": round(2 * args.pairs * n_chunks * world / alone_s / 1e6, 4), "unit": "Mreads/s",
-                               "ms_per_step": round(alone_s / n_chunks * 1e3, 2), "steps": n_chunks},
+                               "ms_per_step": round(alone_s / n_chunks * 1e3, 2), "steps": n_chunks} if alone_s else None,
         "host_cpu_s_per_step": round(host_cpu_s / args.steps, 3), "host_sys_s_per_step": round(host_sys_s / args.steps, 3),
         "timed_region_disturbances": {"work_buffer_reallocations": grown, "cgroup_cpu_throttle_events": thr1[0] - thr0[0], "cgroup_cpu_throttled_ms": round((thr1[1] - thr0[1]) / 1e3, 1)}, "host_cpu_busy_frac": round(host_cpu_s / (elapsed * max(cores, 1)), 3),
         "roofline": roofline,
@@ -392,10 +401,11 @@ def main():
                     else:
                         same = None
                 out["cpu_baseline"] = {"value": round(n_ref / t_ref / 1e6, 5), "unit": "Mreads/s", "cores": cores, "kind": "reference",
-                                       "sample": "the %d chunks of the run (%d reads), one reference mem_process_seqs -t %d call each (%.1f s in all)" %
-                                                 (n_chunks, n_ref, cores, t_ref)}
+                                       "sample": "%s of the %d chunks of the run (%d reads), one reference mem_process_seqs -t %d call each (%.1f s in all)" %
+                                                 ("all reads" if not args.cpu_sample_pairs else "the first %d pairs of each" % args.cpu_sample_pairs,
+                                                  n_chunks, n_ref, cores, t_ref)}
                 # the per-core anchor: the reference at -t 1 on a bounded slice of the first chunk
-                n1 = min(len(chunk_reads[0]), int(os.environ.get("MPIBWA_BENCH_T1_PAIRS", "30000")))
+                n1 = min(len(chunk_reads[0]), int(os.environ.get("MPIBWA_BENCH_T1_PAIRS", "30000" if not args.quick else "2000")))
                 rb1 = abi.SeqBatch(po.libc, chunk_reads[0][:n1])
                 ropt1 = ref.opt(flag=abi.MEM_F_PE, n_threads=1)
                 t0 = time.perf_counter()
@@ -435,14 +445,38 @@ def main():
         out["parity_all_ranks"] = bool(ok_here)
     out["index_residency"] = {"rank0": "host upload", "other_ranks": "broadcast from rank 0 (torch.distributed, in place on the index arrays)" if world > 1 else None,
                               "broadcast_s": round(eng.bcast_seconds, 3) if eng.bcast_seconds is not None else None}
-    # the same bench on harder references (more repeats; SURVEY §8d's generator), measured in runs of their own with this very
-    # script and committed under profiles/: attached for the reader, not part of `value`
-    try:
-        alt = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_alt_workloads.json")))
-        if args.genome_model == "uniform" and args.repeat_frac == 0.05:
-            out["alt_workloads"] = alt
-    except Exception:
-        pass
+    # ---- the same bench, shortened, on other references: measured here, by this run, each in a child process of its own (so the
+    # headline survives whatever happens there, e.g. a work buffer that does not fit); not part of `value` ----
+    if rank == 0 and world == 1 and args.alt_legs and not args.quick:
+        import subprocess
+        del batches, chunk_reads
+        lib.mi355x_finalize()          # the child uploads its own index: this process gives the 70 GB of tables back first
+        out["alt_workloads"] = []
+        for spec in args.alt_legs.split(","):
+            model, frac = spec.split(":")
+            if model == args.genome_model and float(frac) == args.repeat_frac:
+                continue
+            cmd = [sys.executable, os.path.abspath(__file__), "--quick", "--alt-legs", "", "--genome-model", model, "--repeat-frac", frac, "--chunks", "2",
+                   "--steps", "8", "--warmup", "1", "--in-flight", str(n_fly), "--cpu-sample-pairs", "30000", "--genome-mbp", str(args.genome_mbp),
+                   "--pairs", str(args.pairs), "--read-len", str(args.read_len), "--workdir", args.workdir]
+            t_leg = time.perf_counter()
+            leg = {"workload": spec, "command": " ".join(cmd[1:])}
+            try:
+                r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=float(os.environ.get("MPIBWA_BENCH_LEG_TIMEOUT", "420")))
+                lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+                if lines:
+                    d = json.loads(lines[-1])
+                    leg.update({k: d.get(k) for k in ("value", "unit", "ms_per_step", "steps", "host_cpu_s_per_step", "host_cpu_busy_frac", "timed_region_disturbances",
+                                                      "parity_on_sample", "sam_records_written_by_device_frac", "work_per_step")})
+                    leg["workload"] = d["config"]["workload"]
+                    leg["calls_in_flight"] = d["config"]["calls_in_flight"]
+                    leg["cpu_baseline"] = {k: d["cpu_baseline"].get(k) for k in ("value", "unit", "cores", "kind", "sample")} if isinstance(d.get("cpu_baseline"), dict) else None
+                else:
+                    leg["error"] = "exit code %d: %s" % (r.returncode, r.stderr.decode()[-400:])
+            except Exception as e:
+                leg["error"] = repr(e)
+            leg["wall_s"] = round(time.perf_counter() - t_leg, 1)
+            out["alt_workloads"].append(leg)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -3,6 +3,7 @@
 #define MBW_DEVICE_H
 #include "internal.h"
 #include <mutex>
+#include <vector>
 
 namespace mbw {
 
@@ -63,11 +64,24 @@ struct SmemParams {
 };
 
 // ---- device buffers reused across calls ----
+struct DevBuf;
+// A DevBuf that is constructed while an owner list is open (pipeline.hip: the work buffers of a call context) enters it, so that
+// the context's buffers can be given back as a whole: when the index is released, or when another call's buffer does not fit.
+extern std::vector<DevBuf *> *g_devbuf_owner;
 struct DevBuf {
 	void *p = nullptr; size_t cap = 0;
-	void *ensure(size_t bytes);   // grow-only hipMalloc
+	DevBuf() { if (g_devbuf_owner) g_devbuf_owner->push_back(this); }
+	DevBuf(const DevBuf &) = delete;
+	DevBuf &operator=(const DevBuf &) = delete;
+	// grow-only hipMalloc.  A buffer that does not fit asks the pipeline to make room (device_memory_pressure: the buffers of idle
+	// call contexts are given back; with other calls in flight the caller waits for one of them to end and fewer calls are admitted
+	// from then on) and only a lone call whose buffer still does not fit ends the process.
+	void *ensure(size_t bytes);
 	void release();
 };
+// pipeline.hip: called when a device allocation has failed; true = something was freed or a call has ended: try again
+bool device_memory_pressure(size_t wanted);
+void release_idle_work_buffers();   // all call contexts that are not inside a call (mi355x_finalize)
 
 // Launchers (all asynchronous on `stream`; kernel time measured by the caller with HIP events)
 // SMEM seeding: two launches on the stream — the third pass (smem_kernels.hip, a read per lane) first, then passes 1-2

@@ -30,17 +30,31 @@ void note_buffer_growth(size_t from, size_t to, const char *kind)
 // (re)allocations of device and page-locked work buffers so far: hipFree / hipMalloc / hipHostMalloc stall every stream of the
 // device, so a caller that sees this number move in steady state knows where a slow chunk came from
 extern "C" unsigned long long mi355x_buffer_growths(void) { return g_buf_growths.load(); }
+std::vector<DevBuf *> *g_devbuf_owner = nullptr;
 void *DevBuf::ensure(size_t bytes)
 {
 	if (bytes > cap) {
 		size_t want = bytes + bytes / 4 + 256;
 		note_buffer_growth(cap, want, "device");
 		if (p) HIP_OK(hipFree(p));
-		if (hipMalloc(&p, want) != hipSuccess) {
+		p = nullptr; cap = 0;
+		// (what the runtime itself needs later — kernel scratch, queues, events — comes out of the same HBM, and it aborts the process
+		// when it finds none: an allocation that leaves less than a reserve free counts as one that did not fit)
+		static const size_t reserve = (size_t)(getenv("MPIBWA_HBM_RESERVE_GB") ? atof(getenv("MPIBWA_HBM_RESERVE_GB")) : 6.0) << 30;
+		for (int attempt = 0;; ++attempt) {
+			if (hipMalloc(&p, want) == hipSuccess) {
+				size_t fr = 0, tot = 0;
+				if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr >= reserve) break;
+				(void)hipFree(p);
+			}
+			(void)hipGetLastError();
+			p = nullptr;
+			if (attempt == 0 && want > bytes + 256) { want = bytes + 256; continue; }   // without the head room first
+			if (device_memory_pressure(want)) continue;
 			size_t fr = 0, tot = 0;
 			(void)hipMemGetInfo(&fr, &tot);
-			die("device work buffer of %.2f GB does not fit: %.1f of %.1f GB free (index, dense SA and the work buffers of the calls in flight share the HBM)",
-			    want / 1e9, fr / 1e9, tot / 1e9);
+			die("device work buffer of %.2f GB does not fit: %.1f of %.1f GB free (index, dense SA and the work buffers of this call share the HBM; no other "
+			    "call is in flight and no idle buffer is left to give back)", want / 1e9, fr / 1e9, tot / 1e9);
 		}
 		cap = want;
 	}
@@ -315,6 +329,7 @@ extern "C" void mi355x_finalize(void)
 	if (g_idx.d_occ32) (void)hipFree(g_idx.d_occ32);
 	if (g_idx.d_kmt) (void)hipFree(g_idx.d_kmt);
 	g_idx = DevIndex();
+	release_idle_work_buffers();   // a process that is done with this index gives the HBM of its call contexts back too
 }
 
 namespace mbw {

@@ -419,6 +419,9 @@ static const int MAX_LANES = 4;
 // the function at once (chunk i+1 seeding and extending on the GPU while the host pairs and prints chunk i — the stage that
 // keeps the GPU busy and the stage that keeps the host busy belong to different halves of a call).  A ninth caller waits.
 struct CallCtx {
+	// (first and last members: every DevBuf constructed in between enters `bufs`)
+	std::vector<DevBuf *> bufs;
+	struct Open { Open(std::vector<DevBuf *> *l) { g_devbuf_owner = l; } } open_{&bufs};
 	// ws[lane] / reg_arena[k]: a call with neighbours in flight runs its chunk in one piece through ws[0], a lone call its two
 	// sub-batches through ws[0] and ws[1].  The buffers only grow, so a context that has served a lone call regrows ws[0] ONCE,
 	// at its first whole chunk (65 buffers: hipFree + hipMalloc stall every stream) — a caller that wants that out of its
@@ -431,6 +434,9 @@ struct CallCtx {
 	hipStream_t p_streams[MAX_LANES] = {nullptr}, a_streams[2] = {nullptr, nullptr}, d_streams[2] = {nullptr, nullptr};
 	bool busy = false;
 	const bseq1_t *seq_lo = nullptr, *seq_hi = nullptr;   // the caller's array while the call runs
+	struct Close { Close() { g_devbuf_owner = nullptr; } } close_;
+	size_t device_bytes() const { size_t b = 0; for (const DevBuf *d : bufs) b += d->cap; return b; }
+	void release_device() { for (DevBuf *d : bufs) d->release(); }
 };
 static const int MAX_CALLS = 12;
 static CallCtx g_ctx[MAX_CALLS];
@@ -438,6 +444,11 @@ static std::mutex g_ctx_mu;
 static std::recursive_mutex g_init_mu;
 std::recursive_mutex &index_mutex() { return g_init_mu; }
 static std::condition_variable g_ctx_cv;
+// Calls admitted at once: MAX_CALLS until a work buffer has failed to fit, then what was in flight at that moment minus one (never
+// fewer than one): the callers beyond that wait at the door instead of in the middle of a call.
+static int g_admit = MAX_CALLS;             // (under g_ctx_mu)
+static int g_waiting_for_memory = 0;        // calls stuck in device_memory_pressure (under g_ctx_mu)
+static std::condition_variable g_mem_cv;    // a call has ended
 struct CtxLease {
 	CallCtx *c = nullptr;
 	int others = 0;   // calls that were in flight when this one started
@@ -448,8 +459,14 @@ struct CtxLease {
 	{
 		std::unique_lock<std::mutex> lk(g_ctx_mu);
 		for (;;) {
-			for (int i = 0; i < MAX_CALLS && !c; ++i)
-				if (!g_ctx[i].busy) { c = &g_ctx[i]; c->busy = true; }
+			int n_busy = 0;
+			for (int i = 0; i < MAX_CALLS; ++i) n_busy += g_ctx[i].busy ? 1 : 0;
+			if (n_busy < g_admit) {
+				// a context that already holds buffers first (an idle one with buffers next to a busy fresh one would be HBM nobody uses)
+				for (int pass = 0; pass < 2 && !c; ++pass)
+					for (int i = 0; i < MAX_CALLS && !c; ++i)
+						if (!g_ctx[i].busy && (pass == 1 || g_ctx[i].device_bytes() > 0)) { c = &g_ctx[i]; c->busy = true; }
+			}
 			if (c) break;
 			g_ctx_cv.wait(lk);
 		}
@@ -461,17 +478,83 @@ struct CtxLease {
 				die("mem_process_seqs: called on seqs[] that another call in flight is still working on");
 		}
 		c->seq_lo = seqs; c->seq_hi = seqs + n;
-		static double last_crowded_ms = -1e30;   // (under g_ctx_mu)
 		const double now = now_ms();
-		if (others >= 2) last_crowded_ms = now;
-		crowded = now - last_crowded_ms < 2000.0;
+		if (others >= 2) last_crowded_ms() = now;
+		crowded = now - last_crowded_ms() < 2000.0;
 	}
+	static double &last_crowded_ms() { static double t = -1e30; return t; }   // (under g_ctx_mu)
 	~CtxLease()
 	{
-		{ std::lock_guard<std::mutex> lk(g_ctx_mu); c->busy = false; c->seq_lo = c->seq_hi = nullptr; }
-		g_ctx_cv.notify_one();
+		{
+			std::lock_guard<std::mutex> lk(g_ctx_mu);
+			// (also when a call ENDS among two others: a caller whose calls take longer than the two seconds — first use of its contexts,
+			// a hard reference — would otherwise start its next round as a lone caller)
+			int n_busy = 0;
+			for (int i = 0; i < MAX_CALLS; ++i) n_busy += g_ctx[i].busy ? 1 : 0;
+			if (n_busy >= 3) last_crowded_ms() = now_ms();
+			c->busy = false; c->seq_lo = c->seq_hi = nullptr;
+		}
+		g_ctx_cv.notify_all();
+		g_mem_cv.notify_all();
 	}
 };
+// give back the device buffers of every context that is not inside a call; returns the bytes freed
+static size_t release_idle_locked(std::unique_lock<std::mutex> &lk)
+{
+	size_t freed = 0;
+	for (int i = 0; i < MAX_CALLS; ++i) {
+		CallCtx &x = g_ctx[i];
+		if (x.busy || x.device_bytes() == 0) continue;
+		x.busy = true;              // nobody leases it while its buffers go
+		lk.unlock();
+		freed += x.device_bytes();
+		x.release_device();
+		lk.lock();
+		x.busy = false;
+	}
+	return freed;
+}
+void release_idle_work_buffers()
+{
+	std::unique_lock<std::mutex> lk(g_ctx_mu);
+	release_idle_locked(lk);
+}
+bool device_memory_pressure(size_t wanted)
+{
+	std::unique_lock<std::mutex> lk(g_ctx_mu);
+	if (const size_t freed = release_idle_locked(lk)) {
+		fprintf(stderr, "[mpibwa_amd] a device work buffer of %.2f GB did not fit: %.2f GB of idle call contexts' buffers given back\n", wanted / 1e9, freed / 1e9);
+		return true;
+	}
+	int n_busy = 0;
+	for (int i = 0; i < MAX_CALLS; ++i) n_busy += g_ctx[i].busy ? 1 : 0;
+	if (n_busy <= 1) return false;   // a lone call: nothing to wait for
+	if (g_admit > n_busy - 1) {
+		g_admit = std::max(1, n_busy - 1);
+		fprintf(stderr, "[mpibwa_amd] a device work buffer of %.2f GB does not fit with %d calls in flight: %d calls are admitted at once from now on\n",
+		        wanted / 1e9, n_busy, g_admit);
+	}
+	// wait for another call to end (its context then is idle: its buffers are given back above on the next attempt) — unless every
+	// call in flight is waiting here, in which case nobody will ever end
+	++g_waiting_for_memory;
+	bool ok = true;
+	for (;;) {
+		if (g_waiting_for_memory >= n_busy) { ok = false; break; }
+		g_mem_cv.wait_for(lk, std::chrono::milliseconds(50));
+		int now_busy = 0;
+		for (int i = 0; i < MAX_CALLS; ++i) now_busy += g_ctx[i].busy ? 1 : 0;
+		if (now_busy < n_busy) break;
+		n_busy = now_busy;
+	}
+	--g_waiting_for_memory;
+	if (!ok) {
+		// everybody waits: the call that holds the least gives up its turn?  It cannot — its buffers are in use.  The last resort is
+		// the one the library always had; report what is held so that the caller can lower its number of calls in flight.
+		return false;
+	}
+	release_idle_locked(lk);
+	return true;
+}
 static thread_local mi355x_stats_t t_stats;   // of the last call made by this thread
 static thread_local bool t_stats_set = false;
 static std::atomic<int> g_in_flight(0);
