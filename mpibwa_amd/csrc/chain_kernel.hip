@@ -1116,9 +1116,10 @@ static size_t chain_lds_bytes(int maxs, int maxch) { return (size_t)F_NFIELDS * 
 
 // scratch of launch_chain: [the B-tree kernel's slices for `cap` reads][its list][two retry lists][counters][two lists of reads with more
 // than 255 seeds][the slices of chain_heavy_kernel's persistent waves]
-#define HV_WAVES_S 1024   // waves of the 1024-seed instantiation (21 KB of LDS each: 7 per CU)
+#define HV_WAVES_T 4096   // waves of the 256-seed instantiation (5.3 KB of LDS each): the reads with more than 9 chains
+#define HV_WAVES_S 1024   // ... of the 1024-seed instantiation (21 KB: 7 per CU)
 #define HV_WAVES_L 256    // ... of the 4096-seed one (84 KB: one per CU)
-static size_t heavy_scratch_bytes() { return HV_WAVES_S * hv_scratch_bytes(1024) + HV_WAVES_L * hv_scratch_bytes(4096); }
+static size_t heavy_scratch_bytes() { return HV_WAVES_T * hv_scratch_bytes(256) + HV_WAVES_S * hv_scratch_bytes(1024) + HV_WAVES_L * hv_scratch_bytes(4096); }
 size_t chain_general_bytes(int cap, int n_reads)
 {
 	return (size_t)cap * CK_GEN_BYTES + (size_t)cap * 4 + (size_t)n_reads * 8 + 512 + (size_t)n_reads * 8 + 256 + heavy_scratch_bytes();
@@ -1165,7 +1166,18 @@ void launch_chain(void *stream, const ChainParams &P, int n_reads, const int *d_
 			                   count + 2);
 			hipLaunchKernelGGL((chain_kernel<CK_MAXSEEDS_BIG, CK_MAXCH, CK_MAXSEEDS>), grid, block, lds_big, st, CHAIN_ARGS, (const int *)list_b, (const unsigned int *)(count + 2));
 		}
-		if (big >= 2) {
+		static const bool use_general = getenv("MPIBWA_CHAIN_GENERAL") && atoi(getenv("MPIBWA_CHAIN_GENERAL")) != 0;
+		if (big >= 2 && !use_general) {
+			// the reads with more than 9 chains (up to 255 seeds): a wavefront per read with the B-tree in LDS (on a low-complexity
+			// reference a third of the reads are of this kind; a lane per read with the tree in HBM — chain_general_kernel, rounds 2-3 —
+			// took 51 ms per chunk there)
+			int *list_t = list_a;   // (the 64-seed retry is done with it)
+			hipLaunchKernelGGL(chain_pick_kernel, pgrid, pblock, 0, st, n_reads, d_len, d_nseeds, (const int *)d_nchains, noflt, 0, CK_MAXSEEDS_BIG, n_reads, list_t, count);
+			hipLaunchKernelGGL((chain_heavy_kernel<256>), dim3(HV_WAVES_T), dim3(64), hv_lds_bytes(256), st, P, (const int *)list_t, (const unsigned int *)count, count + 3,
+			                   n_reads, d_len, d_nseeds, d_lrep, (const i64 *)d_seed_off, (const unsigned long long *)d_sa, d_qbl, (const i64 *)d_ann_off, d_ann_alt, n_seqs, d_tab,
+			                   hv_scr, d_chains, d_seeds, d_srt, d_nchains);
+		}
+		if (big >= 2 && use_general) {
 			// the scratch holds gen_cap reads at a time: several rounds over it (on a low-complexity reference a third of the reads have
 			// more than 9 chains; a round that finds nothing left is two empty launches)
 			static const int rounds = getenv("MPIBWA_CHAIN_ROUNDS") ? std::max(1, atoi(getenv("MPIBWA_CHAIN_ROUNDS"))) : 4;
@@ -1184,14 +1196,15 @@ void launch_chain(void *stream, const ChainParams &P, int n_reads, const int *d_
 				HIP_OK(hipFuncSetAttribute((const void *)chain_heavy_kernel<4096>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hv_lds_bytes(4096)));
 				s_attr2 = true;
 			}
+			uint8_t *scr_s = hv_scr + HV_WAVES_T * hv_scratch_bytes(256);
 			hipLaunchKernelGGL(chain_pick_kernel, pgrid, pblock, 0, st, n_reads, d_len, d_nseeds, (const int *)d_nchains, noflt, CK_MAXSEEDS_BIG, 1024, n_reads, list_h1, count + 4);
 			hipLaunchKernelGGL(chain_pick_kernel, pgrid, pblock, 0, st, n_reads, d_len, d_nseeds, (const int *)d_nchains, noflt, 1024, 4096, n_reads, list_h2, count + 6);
 			hipLaunchKernelGGL((chain_heavy_kernel<4096>), dim3(HV_WAVES_L), dim3(64), hv_lds_bytes(4096), st, P, (const int *)list_h2, (const unsigned int *)(count + 6), count + 7,
 			                   n_reads, d_len, d_nseeds, d_lrep, (const i64 *)d_seed_off, (const unsigned long long *)d_sa, d_qbl, (const i64 *)d_ann_off, d_ann_alt, n_seqs, d_tab,
-			                   hv_scr + HV_WAVES_S * hv_scratch_bytes(1024), d_chains, d_seeds, d_srt, d_nchains);
+			                   scr_s + HV_WAVES_S * hv_scratch_bytes(1024), d_chains, d_seeds, d_srt, d_nchains);
 			hipLaunchKernelGGL((chain_heavy_kernel<1024>), dim3(HV_WAVES_S), dim3(64), hv_lds_bytes(1024), st, P, (const int *)list_h1, (const unsigned int *)(count + 4), count + 5,
 			                   n_reads, d_len, d_nseeds, d_lrep, (const i64 *)d_seed_off, (const unsigned long long *)d_sa, d_qbl, (const i64 *)d_ann_off, d_ann_alt, n_seqs, d_tab,
-			                   hv_scr, d_chains, d_seeds, d_srt, d_nchains);
+			                   scr_s, d_chains, d_seeds, d_srt, d_nchains);
 		}
 	}
 #undef CHAIN_ARGS

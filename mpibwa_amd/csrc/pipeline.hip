@@ -968,7 +968,10 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 				kp.min_seed_len = opt->min_seed_len; kp.max_chain_extend = opt->max_chain_extend;
 				kp.mask_level = opt->mask_level; kp.drop_ratio = opt->drop_ratio;
 				// third launch (reads with more than 9 chains): room for a sixth of the reads, the rest of them stays with the host
-				const int gen_cap = std::min(n, std::max(4096, n / 6));
+				// (MPIBWA_CHAIN_GENERAL=1: the reads with more than 9 chains through the lane-per-read B-tree kernel of rounds 2-3, which needs
+				// 18 KB of scratch per read: room for a sixth of the reads at a time)
+				static const bool use_general = getenv("MPIBWA_CHAIN_GENERAL") && atoi(getenv("MPIBWA_CHAIN_GENERAL")) != 0;
+				const int gen_cap = use_general ? std::min(n, std::max(4096, n / 6)) : std::min(n, 64);
 				void *d_gen = W.chain_gen.ensure(chain_general_bytes(gen_cap, n));
 				launch_chain(st, kp, n, d_len_r, d_nseeds, d_lrep, d_seed_off, d_sa, d_qbl, d_ann_off, d_ann_alt, bns->n_seqs, d_tab, TS, d_chains, d_seeds,
 				             d_srt, d_nch, d_gen, gen_cap);

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/prof_bench
-timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_bench --output-format csv -- python3 $R/bench.py --steps ${STEPS:-12} --warmup 2 > $R/gpurun_out/prof_bench.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_bench --output-format csv -- python3 $R/bench.py --steps ${STEPS:-16} --warmup 2 --no-cpu-baseline --alt-legs "" ${BENCH_ARGS:-} > $R/gpurun_out/prof_bench.log 2>&1
 echo "rc=$?"
 tail -1 $R/gpurun_out/prof_bench.log | cut -c1-400
 f=$(ls $R/gpurun_out/prof_bench/*/*kernel_stats.csv | head -1)
