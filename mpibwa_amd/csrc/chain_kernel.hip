@@ -600,9 +600,10 @@ chain_general_kernel(ChainParams P, const int *__restrict__ list, const unsigned
 // ---------------------------------------------------------------------------------------------------------------------
 // chain_heavy_kernel (round 4): the reads with MORE than 255 seeds — reads of high-copy repeats: max_occ (500) occurrences
 // of each of several intervals, hundreds to a few thousand seeds and nearly as many chains — one WAVEFRONT per read.
-//   * mem_chain (src/bwamem.c:251-315) is sequential in the seeds (every seed meets the ordered map as the earlier ones left it):
-//     lane 0 walks them, with the B-tree (kb_intervalp / kb_putp, t = 5, the same rules as MapBtree above with 16-bit chain
-//     numbers) and the chains' positions in LDS, the other per-chain fields in a slice of HBM scratch the wave keeps;
+//   * mem_chain (src/bwamem.c:251-315) is sequential in the seeds (every seed meets the ordered map as the earlier ones left it), but
+//     what a seed does to the map is a job for 64 lanes: the map is a sorted array in LDS, the closest chain at or before the seed
+//     is one or two ballots, a new chain makes room with all lanes (while the chain positions of a read are distinct this is the
+//     reference's B-tree to the letter; a read with two chains at one position goes to the host's restatement of the tree);
 //   * mem_chain_weight (:213-237) runs a chain per lane;
 //   * mem_chain_flt's unstable sort (:341) is ks_introsort on (weight, chain) words in LDS, lane 0;
 //   * its pairwise pass (:346-367) — every chain against every chain kept so far, n^2 / 2 tests for a repeat whose chains all
@@ -610,121 +611,21 @@ chain_general_kernel(ChainParams P, const int *__restrict__ list, const unsigned
 //     kept chains (query span, weight, ALT flag, first shadowed chain) in the LDS the tree no longer needs, a break found by ballot;
 //   * emission as chain_read above, a kept chain per lane, output positions by a wave prefix sum.
 // Persistent waves take reads from a list (chain_pick_kernel) through a counter.  CAP = seeds (hence chains) a read may have in
-// the instantiation: 1024 (21 KB of LDS per wave) and 4096 (84 KB); more seeds than that, or reads long enough for
-// mem_flt_chained_seeds to act, stay with the host.
+// the instantiation: 256 (7.5 KB of LDS per wave: the reads of up to 255 seeds with more than 9 chains), 1024 (26 KB) and 4096 (98 KB);
+// more seeds than that, or reads long enough for mem_flt_chained_seeds to act, stay with the host.
 // ---------------------------------------------------------------------------------------------------------------------
-struct HvNode { uint8_t internal, n; uint16_t key[9]; uint16_t child[10]; };   // 40 bytes
 #define HV_NONE 0xFFFFu
-__host__ __device__ constexpr int hv_nodes(int cap) { return cap * 5 / 16 + 16; }   // every node but the root holds >= 4 keys: leaves <= n / 4, their parents <= a quarter of that
-__host__ __device__ constexpr size_t hv_lds_bytes(int cap) { return (size_t)cap * 8 + (size_t)hv_nodes(cap) * sizeof(HvNode); }
-__host__ __device__ constexpr size_t hv_scratch_bytes(int cap) { return (size_t)cap * (8 + 4 + 10 * 2) + 256; }
-struct HvStore {   // per-chain fields and per-seed links of the read in hand (HBM, the wave's slice)
-	i64 *last_r; uint32_t *rid;
-	uint16_t *first_q, *last_q, *last_len, *nmem, *head, *tail, *w, *cid, *next, *ord;
-};
-struct HvTree {
-	HvNode *nodes; i64 *pos;   // LDS
-	int n, n_nodes, root, max_nodes;
-	bool full;
-	__device__ __forceinline__ int make()
-	{
-		if (n_nodes == max_nodes) { full = true; return 0; }
-		nodes[n_nodes].internal = 0; nodes[n_nodes].n = 0;
-		return n_nodes++;
-	}
-	__device__ __forceinline__ int locate(const HvNode &x, i64 p, int *r) const
-	{
-		int begin = 0, end = x.n;
-		if (x.n == 0) return -1;
-		while (begin < end) {
-			const int mid = (begin + end) >> 1;
-			if (pos[x.key[mid]] < p) begin = mid + 1;
-			else end = mid;
-		}
-		if (begin == x.n) { *r = 1; return x.n - 1; }
-		const i64 kp = pos[x.key[begin]];
-		*r = (kp < p) - (p < kp);
-		if (*r < 0) --begin;
-		return begin;
-	}
-	__device__ __forceinline__ int lower(i64 p) const
-	{
-		if (n == 0) return -1;
-		int low = -1, r = 0, xi = root;
-		for (;;) {
-			const HvNode &x = nodes[xi];
-			const int i = locate(x, p, &r);
-			if (i >= 0 && r == 0) return x.key[i];
-			if (i >= 0) low = x.key[i];
-			if (!x.internal) return low;
-			xi = x.child[i + 1];
-		}
-	}
-	__device__ __forceinline__ void split(int xi, int i, int yi)
-	{
-		const int zi = make();
-		if (full) return;
-		HvNode &x = nodes[xi], &y = nodes[yi], &z = nodes[zi];
-		z.internal = y.internal;
-		z.n = 4;
-		for (int k = 0; k < 4; ++k) z.key[k] = y.key[5 + k];
-		if (y.internal) for (int k = 0; k < 5; ++k) z.child[k] = y.child[5 + k];
-		y.n = 4;
-		for (int k = x.n; k > i; --k) x.child[k + 1] = x.child[k];
-		x.child[i + 1] = (uint16_t)zi;
-		for (int k = x.n - 1; k >= i; --k) x.key[k + 1] = x.key[k];
-		x.key[i] = y.key[4];
-		++x.n;
-	}
-	__device__ __forceinline__ bool put(int id, i64 p)
-	{
-		if (n_nodes == 0) root = make();
-		int r = root, rr = 0;
-		if (nodes[r].n == 9) {
-			const int si = make();
-			if (full) return false;
-			root = si; nodes[si].internal = 1; nodes[si].n = 0;
-			nodes[si].child[0] = (uint16_t)r;
-			split(si, 0, r);
-			if (full) return false;
-			r = si;
-		}
-		int xi = r;
-		while (nodes[xi].internal) {
-			int i = locate(nodes[xi], p, &rr) + 1;
-			if (nodes[nodes[xi].child[i]].n == 9) {
-				split(xi, i, nodes[xi].child[i]);
-				if (full) return false;
-				if (pos[nodes[xi].key[i]] < p) ++i;
-			}
-			xi = nodes[xi].child[i];
-		}
-		HvNode &x = nodes[xi];
-		const int i = locate(x, p, &rr);
-		for (int k = x.n - 1; k > i; --k) x.key[k + 1] = x.key[k];
-		x.key[i + 1] = (uint16_t)id;
-		++x.n;
-		++n;
-		return true;
-	}
-	__device__ __forceinline__ void in_order(uint16_t *ord) const
-	{
-		if (n == 0) return;
-		int sn[10], si[10], sp = 0, out = 0;
-		sn[0] = root; si[0] = 0;
-		while (sp >= 0) {
-			const HvNode &x = nodes[sn[sp]];
-			if (!x.internal) {
-				for (int k = 0; k < x.n; ++k) ord[out++] = x.key[k];
-				--sp;
-				continue;
-			}
-			const int i = si[sp];
-			if (i > 0 && i <= x.n) ord[out++] = x.key[i - 1];
-			if (i <= x.n) { si[sp] = i + 1; ++sp; sn[sp] = x.child[i]; si[sp] = 0; }
-			else --sp;
-		}
-	}
+// LDS while the seeds are walked: the ordered map (chain positions in ascending order, 8 bytes, and whose they are, 2) and per chain
+// the last seed's offset from its position (4), first_q / last_q / last_len / tail / nmem (5 x 2) — everything test_and_merge reads;
+// afterwards the same bytes hold the filter's columns
+__host__ __device__ constexpr size_t hv_lds_bytes(int cap) { return (size_t)(cap + 64) * 24; }   // (+ 64: the map's shifts write one entry past its end)
+__host__ __device__ constexpr size_t hv_scratch_bytes(int cap) { return (size_t)cap * (4 + 7 * 2 + 8 + 4) + 512; }
+struct HvStore {   // what only the later phases read (HBM, the wave's slice): contig and first seed of every chain, the seeds' links, the tree order
+	uint32_t *rid;
+	uint16_t *head, *cid, *next, *ord;
+	// LDS
+	uint32_t *last_off;
+	uint16_t *first_q, *last_q, *last_len, *tail, *nmem;
 };
 // ks_introsort (src/ksort.h:176-226) of n words, "less" = the heavier chain first (the weight is the word's upper half)
 __device__ __forceinline__ bool hv_lt(uint32_t a, uint32_t b) { return (a >> 16) > (b >> 16); }
@@ -815,8 +716,8 @@ chain_heavy_kernel(ChainParams P, const int *__restrict__ list, const unsigned i
 	extern __shared__ uint8_t hv_lds[];
 	const int lane = threadIdx.x;
 	// phase A: the tree
-	i64 *pos = (i64 *)hv_lds;
-	HvNode *nodes = (HvNode *)(hv_lds + (size_t)CAP * 8);
+	i64 *spos = (i64 *)hv_lds;                                    // [CAP + 64] chain positions in ascending order
+	uint16_t *sid = (uint16_t *)(hv_lds + (size_t)(CAP + 64) * 22);   // [CAP + 64] ... and whose they are
 	// phases C-D (the tree is dead by then): sort words, then the columns of the chains in sorted order and of the kept list
 	uint32_t *skey = (uint32_t *)hv_lds;                 // [CAP]
 	uint16_t *cbeg = (uint16_t *)(skey + CAP);           // [CAP] each
@@ -824,9 +725,15 @@ chain_heavy_kernel(ChainParams P, const int *__restrict__ list, const unsigned i
 	uint8_t *calt = (uint8_t *)(kfirst + CAP), *ckept = calt + CAP;   // [CAP] each: 4 + 8 + 2 = 14 bytes per chain <= the 20.5 of the tree
 	uint8_t *sb = scratch + (size_t)blockIdx.x * hv_scratch_bytes(CAP);
 	HvStore S;
-	S.last_r = (i64 *)sb; S.rid = (uint32_t *)(S.last_r + CAP);
-	S.first_q = (uint16_t *)(S.rid + CAP); S.last_q = S.first_q + CAP; S.last_len = S.last_q + CAP; S.nmem = S.last_len + CAP;
-	S.head = S.nmem + CAP; S.tail = S.head + CAP; S.w = S.tail + CAP; S.cid = S.w + CAP; S.next = S.cid + CAP; S.ord = S.next + CAP;
+	S.rid = (uint32_t *)sb;
+	S.head = (uint16_t *)(S.rid + CAP); S.cid = S.head + CAP; S.next = S.cid + CAP; S.ord = S.next + CAP;
+	S.last_off = (uint32_t *)(hv_lds + (size_t)(CAP + 64) * 8);
+	S.first_q = (uint16_t *)(S.last_off + CAP); S.last_q = S.first_q + CAP; S.last_len = S.last_q + CAP; S.tail = S.last_len + CAP; S.nmem = S.tail + CAP;
+	// (the filter reads first_q / last_q / last_len / nmem of the chains after the tree is gone: they are copied to the wave's HBM slice
+	// before the LDS is reused — hv_spill below)
+	uint16_t *g_first_q = S.ord + CAP, *g_end_q = g_first_q + CAP, *g_nmem = g_end_q + CAP;
+	i64 *g_clo = (i64 *)(sb + (((size_t)CAP * 18 + 15) & ~(size_t)15));   // per seed: start of its contig on its strand (-1: no contig), its contig
+	int *g_rid = (int *)(g_clo + CAP);
 	const i64 l_pac = P.l_pac;
 	const int n_list = (int)(*list_n < (unsigned int)list_cap ? *list_n : (unsigned int)list_cap);
 	for (;;) {
@@ -841,68 +748,112 @@ chain_heavy_kernel(ChainParams P, const int *__restrict__ list, const unsigned i
 		auto S_Q = [&](int k) -> int { return qbl[2 * (so + k)]; };
 		auto S_L = [&](int k) -> int { return qbl[2 * (so + k) + 1]; };
 		if (ns > CAP) continue;   // (the list only holds reads that fit; n_chains stays -1: host)
-		// ---------------- mem_chain: lane 0 ----------------
+		// ---------------- mem_chain: the whole wave per seed ----------------
+		// The ordered map of src/bwamem.c:263 is only ever asked for the closest chain at or before a position and walked in order at
+		// the end; while all chain positions of the read are DISTINCT, a sorted array answers both exactly like the reference's B-tree
+		// (whose shape only shows when keys are equal).  The array lives in LDS; the wave finds the predecessor with one or two ballots
+		// and makes room for a new chain with all lanes.  A new chain at the position of an existing one ends the attempt: such a read
+		// (rare: two seeds at one reference position more than w apart on the read) is chained by the host's restatement of the tree.
 		int n_ch = 0, ok = 1;
-		if (lane == 0) {
-			HvTree T;
-			T.nodes = nodes; T.pos = pos; T.n = 0; T.n_nodes = 0; T.root = 0; T.max_nodes = hv_nodes(CAP); T.full = false;
-			i64 c_lo = 0, c_hi = -1;
-			int c_rid = -1;
-			for (int k = 0; k < ns; ++k) {
+		{
+			// the contig of every seed first (bns_intv2rid, src/bntseq.c:365-376: two binary searches over the contig table in HBM), a
+			// seed per lane — the seeds of a repeat hop from contig to contig, and ten dependent loads per seed in the walk below were
+			// most of its time: the walk gets each seed's contig and where that contig starts on the seed's strand along with the seed
+			for (int k = lane; k < ns; k += 64) {
 				const i64 rb = S_R(k);
-				const int qb = S_Q(k), len = S_L(k);
-				S.cid[k] = HV_NONE;
+				const int len = S_L(k);
 				int rid;
-				if (rb >= c_lo && rb + len <= c_hi && len > 0) rid = c_rid;
-				else {   // bns_intv2rid, src/bntseq.c:365-376
-					if (rb < l_pac && rb + len > l_pac) rid = -2;
+				if (rb < l_pac && rb + len > l_pac) rid = -2;
+				else {
+					const int rid_b = ck_pos2rid(ann_off, n_seqs, l_pac, ck_depos(l_pac, rb));
+					const int rid_e = len > 0 ? ck_pos2rid(ann_off, n_seqs, l_pac, ck_depos(l_pac, rb + len - 1)) : rid_b;
+					rid = rid_b == rid_e ? rid_b : -1;
+				}
+				i64 lo = -1;
+				if (rid >= 0) lo = rb < l_pac ? ann_off[rid] : (l_pac << 1) - ann_off[rid + 1];
+				g_rid[k] = rid; g_clo[k] = lo;
+			}
+			hv_sync();
+			i64 nx_rb = S_R(0), nx_clo = g_clo[0];   // (the next seed is fetched while this one meets the map: the walk itself only touches LDS)
+			int nx_qb = S_Q(0), nx_len = S_L(0), nx_rid = g_rid[0];
+			for (int k = 0; k < ns; ++k) {
+				const i64 rb = nx_rb, c_lo = nx_clo;
+				const int qb = nx_qb, len = nx_len, rid = nx_rid;
+				if (k + 1 < ns) { nx_rb = S_R(k + 1); nx_qb = S_Q(k + 1); nx_len = S_L(k + 1); nx_rid = g_rid[k + 1]; nx_clo = g_clo[k + 1]; }
+				if (rid < 0) { if (lane == 0) S.cid[k] = HV_NONE; continue; }
+				// chains at or before rb: a prefix of the sorted array -> its length
+				int cnt;
+				if (n_ch <= 64) cnt = __popcll(__ballot(lane < n_ch && spos[lane] <= rb));
+				else {
+					const int stride = (n_ch + 63) >> 6;
+					const int at = lane * stride;
+					const int blk = __popcll(__ballot(at < n_ch && spos[at] <= rb));   // samples 0, stride, 2 stride, ... at or before rb
+					if (blk == 0) cnt = 0;
 					else {
-						const int rid_b = ck_pos2rid(ann_off, n_seqs, l_pac, ck_depos(l_pac, rb));
-						const int rid_e = len > 0 ? ck_pos2rid(ann_off, n_seqs, l_pac, ck_depos(l_pac, rb + len - 1)) : rid_b;
-						rid = rid_b == rid_e ? rid_b : -1;
-					}
-					if (rid >= 0) {
-						const i64 o = ann_off[rid], l = ann_off[rid + 1] - o;
-						if (rb < l_pac) { c_lo = o; c_hi = o + l; }
-						else { c_lo = (l_pac << 1) - o - l; c_hi = (l_pac << 1) - o; }
-						c_rid = rid;
+						const int base = (blk - 1) * stride, e = base + lane;       // the answer lies in [base, base + stride)
+						cnt = base + __popcll(__ballot(lane < stride && e < n_ch && spos[e] <= rb));
 					}
 				}
-				if (rid < 0) continue;
-				const int id0 = T.lower(rb);
 				bool merged = false;
-				if (id0 >= 0 && (int)S.rid[id0] == rid) {   // test_and_merge, src/bwamem.c:190-211
-					const i64 first_r = pos[id0], last_r = S.last_r[id0];
-					const int first_q = S.first_q[id0], last_q = S.last_q[id0], last_len = S.last_len[id0];
-					const int qend = last_q + last_len;
-					const i64 rend = last_r + last_len;
-					if (qb >= first_q && qb + len <= qend && rb >= first_r && rb + len <= rend) merged = true;
-					else if (!((last_r < l_pac || first_r < l_pac) && rb >= l_pac)) {
-						const i64 x = qb - last_q, y = rb - last_r;
-						if (y >= 0 && x - y <= P.w && y - x <= P.w && x - last_len < P.max_chain_gap && y - last_len < P.max_chain_gap) {
-							S.last_r[id0] = rb; S.last_q[id0] = (uint16_t)qb; S.last_len[id0] = (uint16_t)len;
-							S.nmem[id0] += 1;
-							S.cid[k] = (uint16_t)id0;
-							S.next[S.tail[id0]] = (uint16_t)k; S.next[k] = HV_NONE; S.tail[id0] = (uint16_t)k;
-							merged = true;
+				int id0 = -1;
+				if (cnt > 0) {
+					id0 = sid[cnt - 1];
+					const i64 first_r = spos[cnt - 1];
+					// (a chain lies in the contig of its first seed, hence of its position: the chain found is in this seed's contig — and on its
+					// strand — exactly when its position is not before the contig's start)
+					if (first_r >= c_lo) {   // test_and_merge, src/bwamem.c:190-211
+						const i64 last_r = first_r + (i64)S.last_off[id0];
+						const int first_q = S.first_q[id0], last_q = S.last_q[id0], last_len = S.last_len[id0];
+						const int qend = last_q + last_len;
+						const i64 rend = last_r + last_len;
+						if (qb >= first_q && qb + len <= qend && rb >= first_r && rb + len <= rend) { merged = true; if (lane == 0) S.cid[k] = HV_NONE; }
+						else if (!((last_r < l_pac || first_r < l_pac) && rb >= l_pac)) {
+							const i64 x = qb - last_q, y = rb - last_r;
+							if (y >= 0 && x - y <= P.w && y - x <= P.w && x - last_len < P.max_chain_gap && y - last_len < P.max_chain_gap) {
+								if (lane == 0) {
+									S.last_off[id0] = (uint32_t)(rb - first_r); S.last_q[id0] = (uint16_t)qb; S.last_len[id0] = (uint16_t)len;
+									S.nmem[id0] += 1;
+									S.cid[k] = (uint16_t)id0;
+									S.next[S.tail[id0]] = (uint16_t)k; S.next[k] = HV_NONE; S.tail[id0] = (uint16_t)k;
+								}
+								merged = true;
+							}
 						}
 					}
 				}
-				if (merged) continue;
-				const int id = n_ch;
-				pos[id] = rb;
-				S.last_r[id] = rb; S.rid[id] = (uint32_t)rid;
-				S.first_q[id] = (uint16_t)qb; S.last_q[id] = (uint16_t)qb; S.last_len[id] = (uint16_t)len; S.nmem[id] = 1;
-				S.head[id] = S.tail[id] = (uint16_t)k; S.next[k] = HV_NONE;
-				if (!T.put(id, rb)) { ok = 0; break; }
-				S.cid[k] = (uint16_t)id;
-				++n_ch;
+				if (!merged) {
+					if (cnt > 0 && spos[cnt - 1] == rb) { ok = 0; break; }   // equal keys: the reference's tree decides, on the host
+					const int id = n_ch;
+					// room at position cnt: the entries behind it move up by one, the top 64 first
+					for (int hi = n_ch; hi > cnt; hi -= 64) {
+						const int e = hi - 1 - lane;
+						i64 v = 0; uint16_t w = 0;
+						if (e >= cnt) { v = spos[e]; w = sid[e]; }
+						hv_sync();
+						if (e >= cnt) { spos[e + 1] = v; sid[e + 1] = w; }
+						hv_sync();
+					}
+					if (lane == 0) {
+						spos[cnt] = rb; sid[cnt] = (uint16_t)id;
+						S.last_off[id] = 0; S.rid[id] = (uint32_t)rid;
+						S.first_q[id] = (uint16_t)qb; S.last_q[id] = (uint16_t)qb; S.last_len[id] = (uint16_t)len; S.nmem[id] = 1;
+						S.head[id] = (uint16_t)k; S.tail[id] = (uint16_t)k; S.next[k] = HV_NONE;
+						S.cid[k] = (uint16_t)id;
+					}
+					++n_ch;
+				}
+				hv_sync();
 			}
-			if (ok) T.in_order(S.ord);
+			if (ok)
+				for (int t0 = lane; t0 < n_ch; t0 += 64) S.ord[t0] = sid[t0];   // the chains in position order (kb_itr of src/bwamem.c:304)
 		}
 		ok = hv_bcast(ok); n_ch = hv_bcast(n_ch);
 		hv_sync();
 		if (!ok) { if (lane == 0) n_chains[rd] = -2; continue; }
+		for (int id = lane; id < n_ch; id += 64) {   // hv_spill: query span and size of every chain, out of the LDS that is about to be reused
+			g_first_q[id] = S.first_q[id]; g_end_q[id] = (uint16_t)(S.last_q[id] + S.last_len[id]); g_nmem[id] = S.nmem[id];
+		}
+		hv_sync();
 		// ---------------- mem_chain_weight: a chain per lane; the chains that weigh enough, in tree order, as sort words ----------------
 		int n = 0;
 		for (int t0 = 0; t0 < n_ch; t0 += 64) {
@@ -944,8 +895,8 @@ chain_heavy_kernel(ChainParams P, const int *__restrict__ list, const unsigned i
 			const int tt = t0 + lane;
 			if (tt < n) {
 				const int id = skey[tt] & 0xffff;
-				cbeg[tt] = S.first_q[id];
-				cend[tt] = (uint16_t)(S.last_q[id] + S.last_len[id]);
+				cbeg[tt] = g_first_q[id];
+				cend[tt] = g_end_q[id];
 				calt[tt] = ann_alt[S.rid[id]];
 				ckept[tt] = 0;
 			}
@@ -1015,7 +966,7 @@ chain_heavy_kernel(ChainParams P, const int *__restrict__ list, const unsigned i
 			const int tt = t0 + lane;
 			const bool kept = tt < n && ckept[tt] != 0;
 			const int id = kept ? (int)(skey[tt] & 0xffff) : 0;
-			const int cs = kept ? (int)S.nmem[id] : 0;
+			const int cs = kept ? (int)g_nmem[id] : 0;
 			int pre = cs;   // inclusive prefix sum over the lanes
 			for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(pre, o); if (lane >= o) pre += v; }
 			const unsigned long long km = __ballot(kept);

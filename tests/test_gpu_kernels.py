@@ -322,7 +322,8 @@ def test_chain_kernel_matches_host_chaining(engine, genome):
     for d, h, sd in zip(dev, host, seedsets):
         if d is None:
             n_declined += 1
-            assert len(sd) > 4096, (len(sd), "declined without reason")
+            # (more than 4096 seeds, or — beyond one tree node — two chains anchored at one reference position: the host's B-tree)
+            assert len(sd) > 4096 or len({x[0] for x in sd}) < len(sd), (len(sd), "declined without reason")
             continue
         assert d == h, (sd, d, h)
         n_dev += 1
@@ -358,7 +359,7 @@ def test_chain_kernel_matches_the_reference_mem_chain(engine, genome):
         assert hh == w, ("host path", len(sd), hh[:3], w[:3])
         if d is None:
             n_declined += 1
-            assert len(sd) > 4096, (len(sd), "declined without reason")
+            assert len(sd) > 4096 or len({x[0] for x in sd}) < len(sd), (len(sd), "declined without reason")
             continue
         dd = [(c[0], c[5], c[6]) for c in d]
         assert dd == w, ("chain_kernel", len(sd), dd[:3], w[:3])
