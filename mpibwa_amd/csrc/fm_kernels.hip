@@ -43,10 +43,17 @@ typedef unsigned int u32;
 //   short reads (<= 160 bp): 20 entries + 160 B = 480 B per quad -> 30 KB per workgroup, 5 workgroups per CU (the VGPR limit)
 //   otherwise:               23 entries + 256 B = 624 B per quad -> 39.5 KB per workgroup (with the superblock records), 4 workgroups per CU
 // (measured on 2x150 bp: 24.9 ms -> 22.7-23.5 ms for the whole chunk; 16 entries spill too often, 32 cost a workgroup)
+#ifndef LCAP_S
 #define LCAP_S 20
+#endif
 #define QSLOT_S 160
+#ifndef LCAP
 #define LCAP 23
+#endif
 #define QSLOT 256
+#ifndef SMEM_WG_S
+#define SMEM_WG_S 5       // workgroups per CU with the short-read footprint
+#endif
 #define SMEM_BLOCK 256     // 4 waves = 64 quads per workgroup
 #define SMEM_FETCH 16      // reads a wave takes from the work counter at a time (>= the 16 quads of a wave)
 
@@ -558,7 +565,7 @@ int smem_grid_quads(int max_len, size_t *scratch_per_quad)
 	// They fill the LDS of the CU: nothing else that needs LDS starts next to a running SMEM launch (leaving room was
 	// measured to cost more than it gives back).  MPIBWA_SMEM_WG_PER_CU overrides.
 	const bool small = max_len <= QSLOT_S;
-	int per_cu = small ? 5 : 4;
+	int per_cu = small ? SMEM_WG_S : 4;
 	if (const char *e = getenv("MPIBWA_SMEM_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= per_cu) per_cu = v; }
 	int n_blocks = 256 * per_cu;
 	const int lc = small ? LCAP_S : LCAP;
