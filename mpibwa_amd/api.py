@@ -17,7 +17,7 @@ EXPORTS = [
     "mem_process_seqs", "mem_opt_init", "bwa_fill_scmat", "bwa_idx_load_from_disk", "bwa_mem2idx", "bwa_idx_destroy",
     "mi355x_index_upload", "mi355x_index_alloc", "mi355x_index_buffers", "mi355x_index_d2d", "mi355x_index_commit",
     "mi355x_finalize", "mi355x_index_build", "mi355x_index_build_gpu",
-    "mi355x_smem_batch", "mi355x_sa_batch", "mi355x_sa_batch2", "mi355x_sa_dense_info", "mi355x_extend_batch", "mi355x_matesw_batch", "mi355x_chain_batch", "mi355x_fastq_scan", "mi355x_fastq_chunks", "mi355x_fastq_fill", "mi355x_last_stats", "mi355x_host_cpus", "mi355x_collect_sam", "mi355x_collect_sam_into", "mi355x_host_ksw_align2",
+    "mi355x_smem_batch", "mi355x_sa_batch", "mi355x_sa_batch2", "mi355x_sa_dense_info", "mi355x_extend_batch", "mi355x_matesw_batch", "mi355x_chain_batch", "mi355x_pair_batch", "mi355x_fastq_scan", "mi355x_fastq_chunks", "mi355x_fastq_fill", "mi355x_last_stats", "mi355x_host_cpus", "mi355x_collect_sam", "mi355x_collect_sam_into", "mi355x_host_ksw_align2",
     "bwa_set_rg", "bwa_insert_header", "bwa_idx2mem", "mi355x_write_map", "mi355x_init", "mi355x_init_bcast_seconds", "mi355x_global_batch", "mi355x_device_count", "mi355x_device_memory", "mi355x_buffer_growths",
 ]
 
@@ -86,6 +86,7 @@ def load_library(build_if_missing=True):
     sig("mi355x_device_count", C.c_int, [])
     sig("mi355x_device_memory", C.c_int, [P(C.c_size_t), P(C.c_size_t)])
     sig("mi355x_buffer_growths", C.c_ulonglong, [])
+    sig("mi355x_pair_batch", C.c_int, [P(abi.mem_opt_t), C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p])
     sig("mi355x_global_batch", C.c_int, [P(abi.mem_opt_t), C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 7 +
         [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, P(C.c_double)])
     _LIB = lib
@@ -280,6 +281,27 @@ class Engine:
                 chs.append((rid, fb, fe, r0, r1, fr, sd))
             res.append(chs)
         return res
+
+    REG_DT = np.dtype([("rb", "<i8"), ("re", "<i8"), ("qb", "<i4"), ("qe", "<i4"), ("rid", "<i4"), ("score", "<i4"), ("truesc", "<i4"), ("w", "<i4"),
+                       ("seedcov", "<i4"), ("seedlen0", "<i4"), ("frac_rep", "<f4"), ("pad", "<i4")])
+    DESC_DT = np.dtype([("rb", "<i8"), ("re", "<i8"), ("qb", "<i4"), ("qe", "<i4"), ("req", "<i4"), ("rid", "<i4"), ("flag", "<i4"), ("mapq", "<i4"),
+                        ("score", "<i4"), ("sub", "<i4")])
+    AREQ_DT = np.dtype([("rb", "<i8"), ("re", "<i8"), ("read", "<i4"), ("qb", "<i4"), ("qe", "<i4"), ("w2", "<i4"), ("truesc", "<i4"), ("pad", "<i4")])
+
+    def pairs(self, opt, pes, regs, n_regs, max_len=150, n_processed=0):
+        """pair_simple_kernel on pairs given by their regions: regs (2 n_pairs, 4) of REG_DT, n_regs (2 n_pairs).
+        -> status (n_pairs,) uint8, desc (2 n_pairs,) DESC_DT, req (2 n_pairs,) AREQ_DT"""
+        regs = np.ascontiguousarray(regs, dtype=self.REG_DT)
+        n_regs = np.ascontiguousarray(n_regs, dtype=np.int32)
+        n_pairs = len(n_regs) // 2
+        status = np.zeros(n_pairs, dtype=np.uint8)
+        desc = np.zeros(2 * n_pairs, dtype=self.DESC_DT)
+        req = np.zeros(2 * n_pairs, dtype=self.AREQ_DT)
+        rc = self.lib.mi355x_pair_batch(opt, C.cast(self.bns, C.c_void_p), C.cast(pes, C.c_void_p), n_processed, n_pairs, regs.ctypes.data, n_regs.ctypes.data,
+                                        max_len, status.ctypes.data, desc.ctypes.data, req.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("mi355x_pair_batch: the kernel cannot use these insert-size statistics")
+        return status, desc, req
 
     def matesw(self, opt, l_pac, pac, reads, rb, re, read, is_rev):
         """mem_matesw's ksw_align2 for windows of `pac`; returns (n_req x 8 int32, kernel ms)."""

@@ -226,6 +226,10 @@ struct PairParams {
 	int tab_off[4];           // start of each orientation's run in the pair-score table: entry [dist - low]
 	int ltab_n;               // entries of the per-length table
 };
+// PairParams from the options and the insert-size statistics; false when the kernel cannot take this chunk (a degenerate
+// distribution); *n_tab = entries of the pair-score table.  pair_tables fills tab[n_tab + P.ltab_n] (scores, then the per-length table).
+bool pair_params(const mem_opt_t *opt, int64_t l_pac, const mem_pestat_t pes[4], int64_t n_processed, int max_len, PairParams &P, size_t *n_tab);
+void pair_tables(const mem_opt_t *opt, const mem_pestat_t pes[4], const PairParams &P, size_t n_tab, double *tab);
 // per read of a sub-batch: its first PR_MAXREG regions and its number of regions, into chunk-wide arrays (d_first: PR_MAXREG records per read)
 void launch_first_reg(void *stream, int n, const int *d_reg_pos, const int *d_nregs, const DevReg *d_packed, DevReg *d_first, int *d_nfirst);
 // status[k] = 1: pair k is decided; reqs[2k .. 2k+1] and desc[2k .. 2k+1] are what the host's COLLECT pass would have listed

@@ -379,6 +379,84 @@ int clamp_band(const mem_opt_t *opt, int qlen, int w, int end_bonus)
 
 } // namespace mbw
 
+namespace mbw {
+bool pair_params(const mem_opt_t *opt, int64_t l_pac, const mem_pestat_t pes[4], int64_t n_processed, int max_len, PairParams &pp, size_t *n_tab_)
+{
+	memset(&pp, 0, sizeof pp);
+	pp.l_pac = l_pac; pp.a = opt->a; pp.b = opt->b; pp.pen_unpaired = opt->pen_unpaired; pp.min_seed_len = opt->min_seed_len; pp.w = opt->w;
+	pp.o_del = opt->o_del; pp.e_del = opt->e_del; pp.o_ins = opt->o_ins; pp.e_ins = opt->e_ins;
+	pp.max_chain_gap = opt->max_chain_gap; pp.mask_level_redun = opt->mask_level_redun; pp.mask_level = opt->mask_level;
+	pp.XA_drop_ratio = opt->XA_drop_ratio; pp.T = opt->T; pp.max_matesw = opt->max_matesw; pp.id0 = (uint64_t)(n_processed >> 1);
+	for (int v = 0; v < 40; ++v) pp.lnq[v] = (int)(4.343 * log(v + 1) + .499);
+	pp.no_rescue = ((opt->flag & MEM_F_NO_RESCUE) || opt->max_matesw <= 0) ? 1 : 0;
+	bool usable = true;
+	size_t n_tab = 0;
+	for (int d = 0; d < 4; ++d) {
+		pp.low[d] = pes[d].low; pp.high[d] = pes[d].high; pp.failed[d] = pes[d].failed ? 1 : 0;
+		pp.tab_off[d] = (int)n_tab;
+		if (!pes[d].failed) {
+			// (a degenerate distribution — std 0, as a user's -I can give — makes the pair score NaN / infinite for some distances,
+			// and the conversion of those to int is the one place where the host's and the device's arithmetic differ: host path)
+			if (!(pes[d].std > 0) || !std::isfinite(pes[d].avg) || !std::isfinite(pes[d].std)) usable = false;
+			if (pes[d].high < pes[d].low || (int64_t)pes[d].high - pes[d].low > (1 << 20)) usable = false;
+			else n_tab += (size_t)(pes[d].high - pes[d].low + 1);
+		}
+	}
+	pp.ltab_n = 4 * max_len + 256;
+	*n_tab_ = n_tab;
+	return usable;
+}
+void pair_tables(const mem_opt_t *opt, const mem_pestat_t pes[4], const PairParams &pp, size_t n_tab, double *tab)
+{
+	for (int d = 0; d < 4; ++d)
+		if (!pes[d].failed)
+			for (int64_t dist = pes[d].low; dist <= pes[d].high; ++dist) {   // src/bwamem_pair.c:218-219, the double part of q
+				const double ns = (dist - pes[d].avg) / pes[d].std;
+				tab[pp.tab_off[d] + (dist - pes[d].low)] = .721 * log(2. * erfc(fabs(ns) * M_SQRT1_2)) * opt->a;
+			}
+	double *ltab = tab + n_tab;
+	ltab[0] = 1.;
+	for (int l = 1; l < pp.ltab_n; ++l) ltab[l] = l < opt->mapQ_coef_len ? 1. : opt->mapQ_coef_fac / log(l);   // src/bwamem.c:964
+}
+} // namespace mbw
+
+// Stage entry of pair_simple_kernel (pair_kernel.hip) for parity tests: n_pairs pairs given by the regions of their two ends
+// (regs: PR_MAXREG DevReg records per read, n_regs per read) as they stand after phase 1; status[k] = 1: decided — desc[2k], desc[2k+1]
+// (SamDesc) and req[2k], req[2k+1] (AlnReq) are what mem_sam_pe's paired branch reports; else the code of the test that sent the pair to
+// the host.  Returns 0, or -1 when the insert-size statistics are not usable by the kernel.
+extern "C" int mi355x_pair_batch(const mem_opt_t *opt, const bntseq_t *bns, const mem_pestat_t pes[4], int64_t n_processed, int n_pairs,
+                                 const void *regs, const int *n_regs, int max_len, uint8_t *status, void *desc, void *req)
+{
+	int nd = 0;
+	if (hipGetDeviceCount(&nd) != hipSuccess || nd == 0) die("no HIP device visible (no CPU fallback)");
+	if (n_pairs <= 0) return 0;
+	PairParams pp;
+	size_t n_tab = 0;
+	if (!pair_params(opt, bns->l_pac, pes, n_processed, max_len, pp, &n_tab)) return -1;
+	std::vector<double> tab(n_tab + (size_t)pp.ltab_n);
+	pair_tables(opt, pes, pp, n_tab, tab.data());
+	std::vector<int64_t> ann_off(bns->n_seqs + 1);
+	std::vector<uint8_t> ann_alt(bns->n_seqs + 1, 0), ok((size_t)n_pairs, 1);
+	for (int k = 0; k < bns->n_seqs; ++k) { ann_off[k] = bns->anns[k].offset; ann_alt[k] = bns->anns[k].is_alt ? 1 : 0; }
+	ann_off[bns->n_seqs] = bns->l_pac;
+	const size_t n = (size_t)2 * n_pairs;
+	DevReg *d_first; int *d_nf; uint8_t *d_ok, *d_aa, *d_st; int64_t *d_ao; double *d_tab; AlnReq *d_rq; SamDesc *d_ds;
+	HIP_OK(hipMalloc(&d_first, n * PR_MAXREG * sizeof(DevReg))); HIP_OK(hipMalloc(&d_nf, n * 4)); HIP_OK(hipMalloc(&d_ok, n_pairs));
+	HIP_OK(hipMalloc(&d_aa, ann_alt.size())); HIP_OK(hipMalloc(&d_st, n_pairs)); HIP_OK(hipMalloc(&d_ao, ann_off.size() * 8));
+	HIP_OK(hipMalloc(&d_tab, tab.size() * 8)); HIP_OK(hipMalloc(&d_rq, n * sizeof(AlnReq))); HIP_OK(hipMalloc(&d_ds, n * sizeof(SamDesc)));
+	HIP_OK(hipMemcpy(d_first, regs, n * PR_MAXREG * sizeof(DevReg), hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(d_nf, n_regs, n * 4, hipMemcpyHostToDevice));
+	HIP_OK(hipMemcpy(d_ok, ok.data(), n_pairs, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(d_aa, ann_alt.data(), ann_alt.size(), hipMemcpyHostToDevice));
+	HIP_OK(hipMemcpy(d_ao, ann_off.data(), ann_off.size() * 8, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(d_tab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
+	launch_pair_simple(0, pp, n_pairs, d_first, d_nf, d_ok, d_ao, d_aa, d_tab, d_tab + n_tab, d_st, d_rq, d_ds);
+	HIP_OK(hipDeviceSynchronize());
+	HIP_OK(hipGetLastError());
+	HIP_OK(hipMemcpy(status, d_st, n_pairs, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(desc, d_ds, n * sizeof(SamDesc), hipMemcpyDeviceToHost));
+	HIP_OK(hipMemcpy(req, d_rq, n * sizeof(AlnReq), hipMemcpyDeviceToHost));
+	(void)hipFree(d_first); (void)hipFree(d_nf); (void)hipFree(d_ok); (void)hipFree(d_aa); (void)hipFree(d_st); (void)hipFree(d_ao); (void)hipFree(d_tab);
+	(void)hipFree(d_rq); (void)hipFree(d_ds);
+	return 0;
+}
+
 extern "C" int mi355x_smem_batch(const mem_opt_t *opt, int n, const uint8_t *seqs, const int64_t *off, int cap,
                                  uint64_t *intv_out, int *n_out, double *kernel_ms, uint64_t *algo_bytes)
 {

@@ -1429,38 +1429,11 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		const double tp0 = now_ms();
 		stage(9);
 		PairParams pp;
-		memset(&pp, 0, sizeof pp);
-		pp.l_pac = bns->l_pac; pp.a = opt->a; pp.b = opt->b; pp.pen_unpaired = opt->pen_unpaired; pp.min_seed_len = opt->min_seed_len; pp.w = opt->w;
-		pp.o_del = opt->o_del; pp.e_del = opt->e_del; pp.o_ins = opt->o_ins; pp.e_ins = opt->e_ins;
-		pp.max_chain_gap = opt->max_chain_gap; pp.mask_level_redun = opt->mask_level_redun; pp.mask_level = opt->mask_level;
-		pp.XA_drop_ratio = opt->XA_drop_ratio; pp.T = opt->T; pp.max_matesw = opt->max_matesw; pp.id0 = (uint64_t)(n_processed >> 1);
-		for (int v = 0; v < 40; ++v) pp.lnq[v] = (int)(4.343 * log(v + 1) + .499);
-		pp.no_rescue = ((opt->flag & MEM_F_NO_RESCUE) || opt->max_matesw <= 0) ? 1 : 0;
-		bool usable = true;
 		size_t n_tab = 0;
-		for (int d = 0; d < 4; ++d) {
-			pp.low[d] = pes[d].low; pp.high[d] = pes[d].high; pp.failed[d] = pes[d].failed ? 1 : 0;
-			pp.tab_off[d] = (int)n_tab;
-			if (!pes[d].failed) {
-				// (a degenerate distribution — std 0, as a user's -I can give — makes the pair score NaN / infinite for some distances,
-				// and the conversion of those to int is the one place where the host's and the device's arithmetic differ: host path)
-				if (!(pes[d].std > 0) || !std::isfinite(pes[d].avg) || !std::isfinite(pes[d].std)) usable = false;
-				if (pes[d].high < pes[d].low || (int64_t)pes[d].high - pes[d].low > (1 << 20)) usable = false;
-				else n_tab += (size_t)(pes[d].high - pes[d].low + 1);
-			}
-		}
+		const bool usable = pair_params(opt, bns->l_pac, pes, n_processed, max_len, pp, &n_tab);
 		if (usable) {
-			pp.ltab_n = 4 * max_len + 256;
 			double *tab = (double *)W.h_pr_tab.ensure((n_tab + (size_t)pp.ltab_n) * 8 + 64);
-			for (int d = 0; d < 4; ++d)
-				if (!pes[d].failed)
-					for (int64_t dist = pes[d].low; dist <= pes[d].high; ++dist) {   // src/bwamem_pair.c:218-219, the double part of q
-						const double ns = (dist - pes[d].avg) / pes[d].std;
-						tab[pp.tab_off[d] + (dist - pes[d].low)] = .721 * log(2. * erfc(fabs(ns) * M_SQRT1_2)) * opt->a;
-					}
-			double *ltab = tab + n_tab;
-			ltab[0] = 1.;
-			for (int l = 1; l < pp.ltab_n; ++l) ltab[l] = l < opt->mapQ_coef_len ? 1. : opt->mapQ_coef_fac / log(l);   // src/bwamem.c:964
+			pair_tables(opt, pes, pp, n_tab, tab);
 			stage(28);
 			uint8_t *ok = (uint8_t *)W.h_pr_ok.ensure((size_t)n_units + 64);
 			parallel_for(n_thr, n_units, 8192, [&](int k) {

@@ -287,6 +287,41 @@ def chain_inject_lib():
     return _inj
 
 
+_pinj = None
+
+# mem_alnreg_t (src/bwamem.h:59-77), 88 bytes
+ALNREG_DT = np.dtype([("rb", "<i8"), ("re", "<i8"), ("qb", "<i4"), ("qe", "<i4"), ("rid", "<i4"), ("score", "<i4"), ("truesc", "<i4"), ("sub", "<i4"),
+                      ("alt_sc", "<i4"), ("csub", "<i4"), ("sub_n", "<i4"), ("w", "<i4"), ("seedcov", "<i4"), ("secondary", "<i4"),
+                      ("secondary_all", "<i4"), ("seedlen0", "<i4"), ("n_comp_is_alt", "<i4"), ("frac_rep", "<f4"), ("hash", "<u8")])
+assert ALNREG_DT.itemsize == 88
+
+
+def pair_inject_available():
+    return os.path.exists(os.path.join(HERE, "_ref", "libpairinj.so"))
+
+
+def ref_pair(opt, bns, pac, pes, pair_id, l_seq, regs0, regs1):
+    """The reference's own mem_sam_pe (oracle/pair_inject.c) on the two region lists (arrays of ALNREG_DT, as mem_chain2aln leaves them:
+    its mem_sort_dedup_patch runs first).  -> dict: paired (its paired branch wrote the records), n_align (alignments mem_matesw asked
+    for), n_xa per end (hits that got an XA entry), and per reported line the region, flag and MAPQ."""
+    global _pinj
+    if _pinj is None:
+        ref_lib()
+        _pinj = C.CDLL(os.path.join(HERE, "_ref", "libpairinj.so"))
+        _pinj.inj_sam_pe.restype = C.c_int
+        _pinj.inj_sam_pe.argtypes = [C.POINTER(abi.mem_opt_t), C.POINTER(abi.bntseq_t), C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_int, C.c_void_p]
+    regs = np.concatenate([np.ascontiguousarray(regs0, dtype=ALNREG_DT), np.ascontiguousarray(regs1, dtype=ALNREG_DT)])
+    out = np.zeros(64, dtype=np.int64)
+    _pinj.inj_sam_pe(opt, bns, C.cast(pac, C.c_void_p), C.cast(pes, C.c_void_p), int(pair_id), int(l_seq), len(regs0), len(regs1), regs.ctypes.data, 1, out.ctypes.data)
+    r = {"n_reg2aln": int(out[0]), "n_lines": int(out[1]), "n_align": int(out[2]), "paired": int(out[3]) == 0, "n_xa": (int(out[4]), int(out[5])), "lines": []}
+    for k in range(min(int(out[0]), 4)):
+        v = out[6 + 11 * k:6 + 11 * (k + 1)]
+        r["lines"].append(dict(rb=int(v[0]), re=int(v[1]), qb=int(v[2]), qe=int(v[3]), score=int(v[4]), sub=int(v[5]), secondary=int(v[6]), truesc=int(v[7]),
+                               w=int(v[8]), flag=int(v[9]), mapq=int(v[10])))
+    return r
+
+
 def chain_inject_available():
     return os.path.exists(os.path.join(HERE, "_ref", "libchaininj.so"))
 
