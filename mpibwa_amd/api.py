@@ -18,7 +18,7 @@ EXPORTS = [
     "mi355x_index_upload", "mi355x_index_alloc", "mi355x_index_buffers", "mi355x_index_d2d", "mi355x_index_commit",
     "mi355x_finalize", "mi355x_index_build", "mi355x_index_build_gpu",
     "mi355x_smem_batch", "mi355x_sa_batch", "mi355x_sa_batch2", "mi355x_sa_dense_info", "mi355x_extend_batch", "mi355x_matesw_batch", "mi355x_chain_batch", "mi355x_pair_batch", "mi355x_fastq_scan", "mi355x_fastq_chunks", "mi355x_fastq_fill", "mi355x_last_stats", "mi355x_host_cpus", "mi355x_collect_sam", "mi355x_collect_sam_into", "mi355x_host_ksw_align2",
-    "bwa_set_rg", "bwa_insert_header", "bwa_idx2mem", "mi355x_write_map", "mi355x_init", "mi355x_init_bcast_seconds", "mi355x_global_batch", "mi355x_device_count", "mi355x_device_memory", "mi355x_buffer_growths",
+    "bwa_set_rg", "bwa_insert_header", "bwa_idx2mem", "mi355x_write_map", "mi355x_init", "mi355x_index_checksums", "mi355x_init_bcast_seconds", "mi355x_global_batch", "mi355x_device_count", "mi355x_device_memory", "mi355x_buffer_growths",
 ]
 
 
@@ -83,6 +83,7 @@ def load_library(build_if_missing=True):
     sig("mi355x_write_map", C.c_int, [C.c_char_p, C.c_char_p])
     sig("mi355x_init", C.c_int, [C.c_int, P(abi.bwaidx_t), P(mi355x_comm_t)])
     sig("mi355x_init_bcast_seconds", C.c_double, [])
+    sig("mi355x_index_checksums", C.c_int, [C.c_void_p])
     sig("mi355x_device_count", C.c_int, [])
     sig("mi355x_device_memory", C.c_int, [P(C.c_size_t), P(C.c_size_t)])
     sig("mi355x_buffer_growths", C.c_ulonglong, [])
@@ -181,6 +182,15 @@ class Engine:
         torch.cuda.synchronize(device)
         self.bcast_seconds = time.time() - t0
         del views
+        # every rank hashes what it now holds on its device; rank 0's numbers go round; a rank that differs stops the run here
+        mine = (C.c_uint64 * 3)()
+        if self.lib.mi355x_index_checksums(mine) != 0:
+            raise RuntimeError("mi355x_index_checksums failed")
+        self.index_checksums = [int(x) for x in mine]
+        objs = [self.index_checksums if rank == 0 else None]
+        dist.broadcast_object_list(objs, src=0)
+        if objs[0] != self.index_checksums:
+            raise RuntimeError("rank %d received a damaged index by broadcast: checksums %s, rank 0 sent %s" % (rank, self.index_checksums, objs[0]))
         if self.lib.mi355x_index_commit() != 0:
             raise RuntimeError("mi355x_index_commit failed")
         self.uploaded = True

@@ -67,7 +67,36 @@ static Rccl &rccl()
 
 static double g_bcast_seconds = 0;
 
+// position-sensitive sum of the 64-bit words of a device array (order-independent: any grid computes the same number)
+__global__ void __launch_bounds__(256) checksum_kernel(const unsigned long long *__restrict__ w, size_t n_words, unsigned long long *out)
+{
+	unsigned long long h = 0;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x)
+		h += (w[i] ^ (i * 0x9E3779B97F4A7C15ull)) * (2 * i + 1);
+	for (int o = 32; o; o >>= 1) h += __shfl_xor(h, o);
+	if ((threadIdx.x & 63) == 0 && h) atomicAdd(out, h);
+}
+
 } // namespace mbw
+using namespace mbw;
+
+// checksums of the three resident index arrays (occ blocks, sampled SA, pac), computed on the device: what a rank received by
+// broadcast must hash to what rank 0 sent
+extern "C" int mi355x_index_checksums(uint64_t out[3])
+{
+	void *d[3]; size_t cap[3];
+	if (mi355x_index_buffers(&d[0], &cap[0], &d[1], &cap[1], &d[2], &cap[2]) != 0) return -1;
+	unsigned long long *d_sum;
+	HIP_OK(hipMalloc(&d_sum, 3 * 8));
+	HIP_OK(hipMemset(d_sum, 0, 3 * 8));
+	for (int w = 0; w < 3; ++w)
+		hipLaunchKernelGGL(checksum_kernel, dim3(2048), dim3(256), 0, 0, (const unsigned long long *)d[w], cap[w] / 8, d_sum + w);
+	HIP_OK(hipDeviceSynchronize());
+	HIP_OK(hipGetLastError());
+	HIP_OK(hipMemcpy(out, d_sum, 3 * 8, hipMemcpyDeviceToHost));
+	(void)hipFree(d_sum);
+	return 0;
+}
 
 using namespace mbw;
 
@@ -117,6 +146,21 @@ extern "C" int mi355x_init(int local_rank, const bwaidx_t *idx, const mi355x_com
 	g_bcast_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 	HIP_OK(hipStreamDestroy(st));
 	RCCL_OK(R.CommDestroy(nc));
+	// Did every rank get what rank 0 sent?  Each rank hashes its three arrays on its device, rank 0's numbers travel through the
+	// caller's host broadcast, and a rank that differs ends the run here instead of aligning against a damaged index.
+	{
+		uint64_t mine[3] = {0, 0, 0}, root[3];
+		if (mi355x_index_checksums(mine) != 0) die("mi355x_init: no resident index to verify");
+		memcpy(root, mine, sizeof root);
+		comm->bcast(root, sizeof root, 0, comm->user);
+		for (int w = 0; w < 3; ++w)
+			if (root[w] != mine[w])
+				die("mi355x_init: rank %d of %d received a damaged index: array %d (%s) hashes to %016llx, rank 0 sent %016llx", comm->rank, comm->size, w,
+				    w == 0 ? "occ blocks" : w == 1 ? "sampled SA" : "pac", (unsigned long long)mine[w], (unsigned long long)root[w]);
+		if (const char *e = getenv("MPIBWA_VERBOSE_INIT"))
+			if (atoi(e)) fprintf(stderr, "[mpibwa_amd] rank %d of %d: index verified against rank 0 (%016llx %016llx %016llx), broadcast %.3f s\n", comm->rank, comm->size,
+			                     (unsigned long long)mine[0], (unsigned long long)mine[1], (unsigned long long)mine[2], g_bcast_seconds);
+	}
 	// every rank expands its own dense SA and jump table from what it now holds (device-local, no further traffic)
 	return mi355x_index_commit();
 }

@@ -24,6 +24,8 @@ if rank == 0:
 dist.barrier()
 eng = api.Engine(os.path.join(d, "gold.fa"), device=dev, dist=dist, rank=rank)
 assert eng.bcast_seconds is not None
+assert len(eng.index_checksums) == 3 and any(eng.index_checksums)   # (compared with rank 0's inside; a difference raises)
+print("CHECKSUMS rank=%d %s" % (rank, " ".join("%016x" % x for x in eng.index_checksums)), flush=True)
 kw = sam_cases()["pe_default"]
 out = b"".join(eng.process(eng.opt(**kw), load_reads("reads_pe150.tsv.gz")))
 ok = out == load_sam("pe_default")

@@ -25,3 +25,6 @@ def test_index_broadcast_two_ranks(tmp_path, built):
         sys.stderr.write(r.stdout[-3000:] + "\n" + "\n".join(l for l in r.stderr.splitlines() if not l.startswith("[M::"))[-6000:])
     assert r.returncode == 0
     assert "rank=0 ok=1" in r.stdout and "rank=1 ok=1" in r.stdout
+    # both ranks hashed their device copies and hold the same three numbers
+    sums = sorted(l.split(None, 2) for l in r.stdout.splitlines() if l.startswith("CHECKSUMS"))
+    assert len(sums) == 2 and sums[0][2] == sums[1][2], r.stdout[-1000:]

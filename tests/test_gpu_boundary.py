@@ -55,7 +55,7 @@ def bcast(buf, nbytes, root, user):
 cb = api.mi355x_comm_t.BCAST(bcast)
 comm = api.mi355x_comm_t(0, 1, cb, None)
 eng = api.Engine(%r, device=0, comm=comm)
-assert seen == [(128, 0)], seen
+assert seen == [(128, 0), (24, 0)], seen      # the RCCL bootstrap id, then rank 0's checksums of the three index arrays
 assert eng.bcast_seconds is not None and eng.bcast_seconds > 0
 kw = sam_cases()["pe_default"]
 assert b"".join(eng.process(eng.opt(**kw), load_reads("reads_pe150.tsv.gz"))) == load_sam("pe_default")
@@ -63,6 +63,26 @@ print("RCCL_PATH_OK")
 """ % (ROOT, os.path.join(ROOT, "tests"), gold)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL_PATH_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_mi355x_init_refuses_an_index_that_differs_from_rank_0s(gold):
+    """After its broadcast every rank hashes the three index arrays on its device and compares with rank 0's numbers, which travel
+    through the caller's host broadcast: numbers that differ (here: bent on the way, as a rank with a damaged copy would see them)
+    end the process with a message instead of letting it align against a damaged index."""
+    code = r"""
+import sys, ctypes as C
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from mpibwa_amd import api
+def bcast(buf, nbytes, root, user):
+    if int(nbytes) == 24:
+        C.cast(buf, C.POINTER(C.c_uint64))[1] ^= 1
+cb = api.mi355x_comm_t.BCAST(bcast)
+comm = api.mi355x_comm_t(0, 1, cb, None)
+eng = api.Engine(%r, device=0, comm=comm)
+print("NOT_REACHED")
+""" % (ROOT, os.path.join(ROOT, "tests"), gold)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "NOT_REACHED" not in r.stdout and "damaged index" in r.stderr and "sampled SA" in r.stderr, (r.stdout[-500:], r.stderr[-2000:])
 
 
 def test_a_call_with_another_index_than_the_resident_one_aborts(gold, genome):
