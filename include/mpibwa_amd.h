@@ -213,6 +213,9 @@ int  mi355x_device_memory(size_t *free_bytes, size_t *total_bytes);
 /* (re)allocations of device / page-locked work buffers since the library was loaded: they stall every stream of the device, so
  * the number should stand still once every call context has seen its largest chunk */
 unsigned long long mi355x_buffer_growths(void);
+/* host threads the library uses for this rank's calls (its share of the node's usable CPUs; *ranks_on_node: the ranks it believes
+ * share the node, from the launcher's environment).  mi355x_init prints it and refuses to start with fewer than 2. */
+int  mi355x_rank_host_threads(int *ranks_on_node);
 /* device-computed checksums of the three resident index arrays (occ blocks, sampled SA, pac): mi355x_init compares every rank's
  * with rank 0's after its broadcast and ends the run on a difference; a host that broadcasts by other means does the same with this */
 int  mi355x_index_checksums(uint64_t out[3]);

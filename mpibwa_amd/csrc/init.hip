@@ -102,10 +102,29 @@ using namespace mbw;
 
 extern "C" double mi355x_init_bcast_seconds(void) { return g_bcast_seconds; }
 
+extern "C" int mi355x_rank_host_threads(int *ranks_on_node);
+// One line per rank about what it runs on, and a refusal to start on a share of the host that cannot feed a GPU: the host stages
+// of a call (encoding, region clean-up, the pairs the pairing kernel leaves, SAM text of the records the device does not write)
+// take 1.3 CPU-s per 667 k reads on SURVEY 8d's workload — about nine busy cores at the rate one MI355X sustains; below two
+// threads per rank the calls in flight only queue behind each other (MPIBWA_ALLOW_FEW_CORES=1 starts anyway).
+static void report_rank(int local_rank, const mi355x_comm_t *comm)
+{
+	int ranks = 1;
+	const int thr = mi355x_rank_host_threads(&ranks);
+	if (bwa_verbose >= 3)
+		fprintf(stderr, "[M::mi355x_init] rank %d of %d: GPU %d of %d visible, %d host threads (this rank's share of the node: %d ranks on it)%s\n",
+		        comm ? comm->rank : 0, comm ? comm->size : 1, local_rank, mi355x_device_count(), thr, ranks,
+		        thr < 8 ? " - fewer than 8: the host stages will bound the throughput of this rank" : "");
+	if (thr < 2 && !(getenv("MPIBWA_ALLOW_FEW_CORES") && atoi(getenv("MPIBWA_ALLOW_FEW_CORES"))))
+		die("mi355x_init: %d host thread for this rank (%d ranks share the node's usable CPUs): a rank needs at least 2, about 9 to keep its GPU busy; "
+		    "start fewer ranks per node, give the job more cores, or set MPIBWA_ALLOW_FEW_CORES=1", thr, ranks);
+}
+
 extern "C" int mi355x_init(int local_rank, const bwaidx_t *idx, const mi355x_comm_t *comm)
 {
 	if (!idx || !idx->bwt || !idx->bns || !idx->pac) die("mi355x_init: the index handle is not attached");
 	g_bcast_seconds = 0;
+	report_rank(local_rank, comm);
 	if (!comm) return mi355x_index_upload(local_rank, idx->bwt, idx->bns, idx->pac);   // (a communicator of one rank still goes through RCCL)
 	if (comm->size < 1 || comm->rank < 0 || comm->rank >= comm->size || !comm->bcast) die("mi355x_init: bad communicator description");
 

@@ -571,6 +571,15 @@ extern "C" void mi355x_last_stats(mi355x_stats_t *st)
 	*st = g_stats;
 }
 extern "C" int mi355x_host_cpus(void) { return usable_cpus(); }
+// host threads the library will use for this rank's calls: its share of the node's usable CPUs (the launcher's local size), and
+// how many ranks it believes share the node
+extern "C" int mi355x_rank_host_threads(int *ranks_on_node)
+{
+	int ranks = env_local_size();
+	if (ranks < 1) ranks = 1;
+	if (ranks_on_node) *ranks_on_node = ranks;
+	return host_threads(nullptr);
+}
 
 // Caller-side helper mirroring mpiBWA's copy_buffer_thr (src/mainParallel.c:103-127): concatenate all
 // seqs[i].sam into one malloc'ed buffer and free the per-read strings.
