@@ -106,6 +106,41 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(dev)
 
+    # ---- the same bench, shortened, on other references: measured by this run, each in a child process of its own, BEFORE this
+    # process touches the GPU (a child has the whole device, and the headline survives whatever happens there, e.g. a timeout);
+    # attached to the line as alt_workloads, not part of `value` ----
+    alt_workloads = None
+    if rank == 0 and world == 1 and args.alt_legs and not args.quick:
+        import subprocess
+        alt_workloads = []
+        n_fly_legs = max(1, min(args.in_flight, 12))
+        for spec in args.alt_legs.split(","):
+            model, frac = spec.split(":")
+            if model == args.genome_model and float(frac) == args.repeat_frac:
+                continue
+            cmd = [sys.executable, os.path.abspath(__file__), "--quick", "--alt-legs", "", "--genome-model", model, "--repeat-frac", frac, "--chunks", "2",
+                   "--steps", "8", "--warmup", "2", "--in-flight", str(n_fly_legs), "--cpu-sample-pairs", "30000", "--genome-mbp", str(args.genome_mbp),
+                   "--pairs", str(args.pairs), "--read-len", str(args.read_len), "--workdir", args.workdir]
+            t_leg = time.perf_counter()
+            leg = {"workload": spec, "command": " ".join(cmd[1:])}
+            try:
+                r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=float(os.environ.get("MPIBWA_BENCH_LEG_TIMEOUT", "420")))
+                lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+                if lines:
+                    d = json.loads(lines[-1])
+                    leg.update({k: d.get(k) for k in ("value", "unit", "ms_per_step", "steps", "host_cpu_s_per_step", "host_cpu_busy_frac", "timed_region_disturbances",
+                                                      "parity_on_sample", "sam_records_written_by_device_frac", "work_per_step")})
+                    leg["workload"] = d["config"]["workload"]
+                    leg["calls_in_flight"] = d["config"]["calls_in_flight"]
+                    leg["cpu_baseline"] = {k: d["cpu_baseline"].get(k) for k in ("value", "unit", "cores", "kind", "sample")} if isinstance(d.get("cpu_baseline"), dict) else None
+                else:
+                    leg["error"] = "exit code %d: %s" % (r.returncode, r.stderr.decode()[-400:])
+            except Exception as e:
+                leg["error"] = repr(e)[:600]
+            leg["wall_s"] = round(time.perf_counter() - t_leg, 1)
+            alt_workloads.append(leg)
+            log("alt leg %s: %s" % (spec, {k: leg.get(k) for k in ("value", "parity_on_sample", "error", "wall_s")}))
+
     from mpibwa_amd import abi, api, bigindex, simulate
     from mpibwa_amd.build import build
     if rank == 0:
@@ -445,38 +480,8 @@ def main():
         out["parity_all_ranks"] = bool(ok_here)
     out["index_residency"] = {"rank0": "host upload", "other_ranks": "broadcast from rank 0 (torch.distributed, in place on the index arrays)" if world > 1 else None,
                               "broadcast_s": round(eng.bcast_seconds, 3) if eng.bcast_seconds is not None else None}
-    # ---- the same bench, shortened, on other references: measured here, by this run, each in a child process of its own (so the
-    # headline survives whatever happens there, e.g. a work buffer that does not fit); not part of `value` ----
-    if rank == 0 and world == 1 and args.alt_legs and not args.quick:
-        import subprocess
-        del batches, chunk_reads
-        lib.mi355x_finalize()          # the child uploads its own index: this process gives the 70 GB of tables back first
-        out["alt_workloads"] = []
-        for spec in args.alt_legs.split(","):
-            model, frac = spec.split(":")
-            if model == args.genome_model and float(frac) == args.repeat_frac:
-                continue
-            cmd = [sys.executable, os.path.abspath(__file__), "--quick", "--alt-legs", "", "--genome-model", model, "--repeat-frac", frac, "--chunks", "2",
-                   "--steps", "8", "--warmup", "1", "--in-flight", str(n_fly), "--cpu-sample-pairs", "30000", "--genome-mbp", str(args.genome_mbp),
-                   "--pairs", str(args.pairs), "--read-len", str(args.read_len), "--workdir", args.workdir]
-            t_leg = time.perf_counter()
-            leg = {"workload": spec, "command": " ".join(cmd[1:])}
-            try:
-                r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=float(os.environ.get("MPIBWA_BENCH_LEG_TIMEOUT", "420")))
-                lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
-                if lines:
-                    d = json.loads(lines[-1])
-                    leg.update({k: d.get(k) for k in ("value", "unit", "ms_per_step", "steps", "host_cpu_s_per_step", "host_cpu_busy_frac", "timed_region_disturbances",
-                                                      "parity_on_sample", "sam_records_written_by_device_frac", "work_per_step")})
-                    leg["workload"] = d["config"]["workload"]
-                    leg["calls_in_flight"] = d["config"]["calls_in_flight"]
-                    leg["cpu_baseline"] = {k: d["cpu_baseline"].get(k) for k in ("value", "unit", "cores", "kind", "sample")} if isinstance(d.get("cpu_baseline"), dict) else None
-                else:
-                    leg["error"] = "exit code %d: %s" % (r.returncode, r.stderr.decode()[-400:])
-            except Exception as e:
-                leg["error"] = repr(e)
-            leg["wall_s"] = round(time.perf_counter() - t_leg, 1)
-            out["alt_workloads"].append(leg)
+    if alt_workloads is not None:
+        out["alt_workloads"] = alt_workloads
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
