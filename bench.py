@@ -354,14 +354,14 @@ def main():
     traffic, traffic_src = None, None
     try:
         here = os.path.dirname(os.path.abspath(__file__))
-        pj = json.load(open(os.path.join(here, "profiles", "r03_pmc_smem.json")))
+        pj = json.load(open(os.path.join(here, "profiles", "r04_pmc_smem.json")))
         now = kernel_sources_sha256(here)
         if pj.get("kernel_sources_sha256") != now:
-            log("WARNING: profiles/r03_pmc_smem.json was measured on other kernel sources (%s..., now %s...): roofline.traffic = null; "
+            log("WARNING: profiles/r04_pmc_smem.json was measured on other kernel sources (%s..., now %s...): roofline.traffic = null; "
                 "re-run tools/pmc_smem.sh" % (str(pj.get("kernel_sources_sha256"))[:12], now[:12]))
         elif args.genome_mbp >= 3000 and args.read_len == 150:
             traffic = int(pj["smem_kernel"]["traffic_bytes_per_read"] * 2 * args.pairs * args.steps / n_launch)
-            traffic_src = "profiles/r03_pmc_smem.json (FETCH_SIZE pass of the same workload, per read) x reads per launch"
+            traffic_src = "profiles/r04_pmc_smem.json (FETCH_SIZE pass of the same workload, per read) x reads per launch"
     except Exception as e:
         log("WARNING: no usable PMC summary for roofline.traffic: %r" % (e,))
     tab = acc.get("smem_tab_bytes", 0)

@@ -447,6 +447,24 @@ static std::condition_variable g_ctx_cv;
 // Calls admitted at once: MAX_CALLS until a work buffer has failed to fit, then what was in flight at that moment minus one (never
 // fewer than one): the callers beyond that wait at the door instead of in the middle of a call.
 static int g_admit = MAX_CALLS;             // (under g_ctx_mu)
+// What a call context holds in HBM once it has seen a chunk (the largest seen so far) — what a call that starts on a fresh context
+// will come to hold.  A call is only let in next to others when the HBM that is free, less what the calls in flight may still grow
+// by, covers that (+ the runtime's reserve); until a first call has ended nobody knows, and at most two run at once.  On references
+// whose chunks need tens of GB per context (half the genome in repeats) this is what keeps eight callers from filling the HBM
+// together and then all waiting for each other.
+static size_t g_footprint = 0;              // (under g_ctx_mu)
+static bool room_for_another_call(const CallCtx *cand, int n_busy)
+{
+	if (n_busy == 0) return true;
+	if (g_footprint == 0) return n_busy < 2;
+	size_t fr = 0, tot = 0;
+	if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return true; }
+	size_t promised = 0;
+	for (int i = 0; i < MAX_CALLS; ++i)
+		if (g_ctx[i].busy && g_ctx[i].device_bytes() < g_footprint) promised += g_footprint - g_ctx[i].device_bytes();
+	const size_t have = cand->device_bytes(), need = (have < g_footprint ? g_footprint - have : 0) + ((size_t)8 << 30);
+	return fr >= promised + need;
+}
 static int g_waiting_for_memory = 0;        // calls stuck in device_memory_pressure (under g_ctx_mu)
 static std::condition_variable g_mem_cv;    // a call has ended
 struct CtxLease {
@@ -463,12 +481,14 @@ struct CtxLease {
 			for (int i = 0; i < MAX_CALLS; ++i) n_busy += g_ctx[i].busy ? 1 : 0;
 			if (n_busy < g_admit) {
 				// a context that already holds buffers first (an idle one with buffers next to a busy fresh one would be HBM nobody uses)
-				for (int pass = 0; pass < 2 && !c; ++pass)
-					for (int i = 0; i < MAX_CALLS && !c; ++i)
-						if (!g_ctx[i].busy && (pass == 1 || g_ctx[i].device_bytes() > 0)) { c = &g_ctx[i]; c->busy = true; }
+				CallCtx *cand = nullptr;
+				for (int pass = 0; pass < 2 && !cand; ++pass)
+					for (int i = 0; i < MAX_CALLS && !cand; ++i)
+						if (!g_ctx[i].busy && (pass == 1 || g_ctx[i].device_bytes() > 0)) cand = &g_ctx[i];
+				if (cand && room_for_another_call(cand, n_busy)) { c = cand; c->busy = true; }
 			}
 			if (c) break;
-			g_ctx_cv.wait(lk);
+			g_ctx_cv.wait_for(lk, std::chrono::milliseconds(20));   // (a call that ends wakes the waiters; so does memory given back without one ending)
 		}
 		for (int i = 0; i < MAX_CALLS; ++i) {
 			if (!g_ctx[i].busy || &g_ctx[i] == c) continue;
@@ -492,6 +512,7 @@ struct CtxLease {
 			int n_busy = 0;
 			for (int i = 0; i < MAX_CALLS; ++i) n_busy += g_ctx[i].busy ? 1 : 0;
 			if (n_busy >= 3) last_crowded_ms() = now_ms();
+			if (c->device_bytes() > g_footprint) g_footprint = c->device_bytes();
 			c->busy = false; c->seq_lo = c->seq_hi = nullptr;
 		}
 		g_ctx_cv.notify_all();
