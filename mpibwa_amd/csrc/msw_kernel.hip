@@ -151,38 +151,23 @@ __device__ __forceinline__ MswPassOut msw_pass(uint32_t *cell, const MswParams &
 	return o;
 }
 
-__global__ __launch_bounds__(64) void msw_kernel(MswParams P, int n_req, const MswReq *__restrict__ req, const uint8_t *__restrict__ seq,
-                                                 const int64_t *__restrict__ off, const int *__restrict__ lens, const uint8_t *__restrict__ pac,
-                                                 MswRes *__restrict__ res, uint16_t *__restrict__ rows)
+// What follows the forward pass of one request: score2 / te2 from the row maxima (the b[] list of src/ksw.c:196-226 rebuilt), the
+// reverse pass that finds where the best local alignment starts (KSW_XSTART, src/ksw.c:344-352), the result record.  `cell` is
+// re-initialised for the reverse pass (layout of msw_pass).  All four lanes of the quad call it with the same arguments.
+__device__ __forceinline__ void msw_tail(uint32_t *cell, const MswParams &P, const uint8_t *__restrict__ pac, bool live, const MswReq &rq, int qlen,
+                                         const uint8_t *__restrict__ ms, int r, int n_req, MswPassOut f, int sat, uint16_t *__restrict__ rows,
+                                         MswRes *__restrict__ res)
 {
-	extern __shared__ uint32_t cell[];   // [positions of a quarter][64 lanes]
 	const int lane = threadIdx.x, j = lane & 3;
-	const int r = blockIdx.x * 16 + (lane >> 2);
-	const bool live = r < n_req;
-	MswReq rq;
-	rq.rb = rq.re = 0; rq.read = 0; rq.is_rev = 0;
-	if (live) rq = req[r];
-	const int qlen = live ? lens[rq.read] : 0;
 	const int tlen = (int)(rq.re - rq.rb);
-	const bool byte_flavour = qlen * P.a < 250;          // KSW_XBYTE as mem_matesw sets it
+	const bool byte_flavour = qlen * P.a < 250;
 	const int PP = byte_flavour ? 16 : 8;
-	const int slen = (qlen + PP - 1) / PP;
-	const int npos = slen * PP, S = npos >> 2;           // positions per lane (npos is a multiple of 8)
-	const uint8_t *ms = seq + (live ? off[rq.read] : 0);
-	// query codes -> LDS (reverse-complemented for the orientations that need it), H = E = 0
-	if (live)
-		for (int kk = 0; kk < S; ++kk) {
-			const int k = j * S + kk;
-			cell[kk * 64 + lane] = msw_code(ms, qlen, rq.is_rev, k) << 26 | ((k + 1) % slen == 0 ? 0x80000000u : 0u);
-		}
 	const int minsc = P.min_seed_len * P.a;              // KSW_XSUBO | min_seed_len * a
 	const int sat_limit = byte_flavour ? 255 - P.shift : 0x10000;
-	int sat = 0;
-	MswPassOut f = msw_pass(cell, P, pac, live, S, tlen, rq.rb, 1, 0x10000, sat_limit, live ? rows + r : nullptr, (size_t)n_req, &sat);
 	MswRes out;
 	out.score = f.score; out.te = f.te; out.qe = f.qe; out.score2 = -1; out.te2 = -1; out.tb = -1; out.qb = -1; out.flags = sat;
 	// b[]: runs of rows whose maximum reaches minsc; second best = best run outside te +- ceil(score / max)
-	// (the quad's own stores to rows[] a few lines up: same wave, same addresses, program order)
+	// (the quad's own stores to rows[]: same wave, same addresses, program order)
 	if (live && j == 0 && !sat && f.te >= 0) {
 		const int d = (f.score + P.max_sc - 1) / P.max_sc;
 		const int low = f.te - d, high = f.te + d;
@@ -217,6 +202,184 @@ __global__ __launch_bounds__(64) void msw_kernel(MswParams P, int n_req, const M
 	if (live && j == 0) res[r] = out;
 }
 
+// list: the requests this launch works on (null: all of them, in order)
+__global__ __launch_bounds__(64) void msw_kernel(MswParams P, int n_work, int n_req, const int *__restrict__ list, const MswReq *__restrict__ req,
+                                                 const uint8_t *__restrict__ seq, const int64_t *__restrict__ off, const int *__restrict__ lens,
+                                                 const uint8_t *__restrict__ pac, MswRes *__restrict__ res, uint16_t *__restrict__ rows)
+{
+	extern __shared__ uint32_t cell[];   // [positions of a quarter][64 lanes]
+	const int lane = threadIdx.x, j = lane & 3;
+	const int slot = blockIdx.x * 16 + (lane >> 2);
+	const bool live = slot < n_work;
+	const int r = live ? (list ? list[slot] : slot) : 0;
+	MswReq rq;
+	rq.rb = rq.re = 0; rq.read = 0; rq.is_rev = 0;
+	if (live) rq = req[r];
+	const int qlen = live ? lens[rq.read] : 0;
+	const int tlen = (int)(rq.re - rq.rb);
+	const bool byte_flavour = qlen * P.a < 250;          // KSW_XBYTE as mem_matesw sets it
+	const int PP = byte_flavour ? 16 : 8;
+	const int slen = (qlen + PP - 1) / PP;
+	const int npos = slen * PP, S = npos >> 2;           // positions per lane (npos is a multiple of 8)
+	const uint8_t *ms = seq + (live ? off[rq.read] : 0);
+	// query codes -> LDS (reverse-complemented for the orientations that need it), H = E = 0
+	if (live)
+		for (int kk = 0; kk < S; ++kk) {
+			const int k = j * S + kk;
+			cell[kk * 64 + lane] = msw_code(ms, qlen, rq.is_rev, k) << 26 | ((k + 1) % slen == 0 ? 0x80000000u : 0u);
+		}
+	const int sat_limit = byte_flavour ? 255 - P.shift : 0x10000;
+	int sat = 0;
+	MswPassOut f = msw_pass(cell, P, pac, live, S, tlen, rq.rb, 1, 0x10000, sat_limit, live ? rows + r : nullptr, (size_t)n_req, &sat);
+	msw_tail(cell, P, pac, live, rq, qlen, ms, r, n_req, f, sat, rows, res);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// msw2_kernel (round 4): TWO requests of the same mate in the same orientation per quad — the rescue windows of a repeat read's
+// anchors: 50 windows for one mate — in the byte flavour (qlen * a < 250: every H, E, F below 256).  The forward pass (the whole
+// window; four fifths of the work) runs both alignments in the two 16-bit halves of every register: v_pk_add_i16 / v_pk_sub_i16 /
+// v_pk_max_i16 on {H, E, Fseg, Ffull}, 13 vector instructions per cell instead of 25.  What makes that cheap is what the two share:
+// the query (one set of codes and segment flags: a dword of eight 4-bit codes per eight positions, read once per eight cells) and
+// the row loop; what differs per row — the two target bases — selects one of 16 rows of a 128-entry table in LDS that holds, per
+// query code, the two substitution scores as a packed pair.  The row state of a position is one dword: H and E of both alignments
+// as four bytes, unpacked and repacked with one v_perm_b32 each.  Row maxima, best cell, saturation are kept per alignment as in
+// msw_pass (32-bit keys); the reverse pass and the b[] scan run per alignment through msw_tail, as for single requests.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef short msw_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ msw_s2 s2_of(uint32_t v) { return __builtin_bit_cast(msw_s2, v); }
+__device__ __forceinline__ uint32_t u_of(msw_s2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ msw_s2 s2_max(msw_s2 a, msw_s2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ msw_s2 s2_splat(int v) { msw_s2 r; r.x = (short)v; r.y = (short)v; return r; }
+
+__global__ __launch_bounds__(64) void msw2_kernel(MswParams P, int n_pairs, int n_req, const int *__restrict__ pairs, const MswReq *__restrict__ req,
+                                                  const uint8_t *__restrict__ seq, const int64_t *__restrict__ off, const int *__restrict__ lens,
+                                                  const uint8_t *__restrict__ pac, MswRes *__restrict__ res, uint16_t *__restrict__ rows, int s_max)
+{
+	extern __shared__ uint32_t lds2[];
+	uint32_t *cell = lds2;                                   // [s_max][64]: H_A, E_A, H_B, E_B as bytes (reverse passes: msw_pass's layout)
+	uint32_t *codes = lds2 + (size_t)s_max * 64;             // [(s_max + 7) / 8][64]: eight 4-bit entries per dword: query code, bit 3 = end of a segment
+	uint32_t *stab = codes + (size_t)((s_max + 7) >> 3) * 64;   // [16][8]: (target base A, target base B) x query code -> the two scores, packed
+	const int lane = threadIdx.x, j = lane & 3;
+	for (int e = lane; e < 128; e += 64) {
+		const int ta = e >> 5, tb = (e >> 3) & 3, q = e & 7;
+		const int sa = q < 4 ? (int)(int8_t)(P.slo[ta] >> (8 * q)) : q == 4 ? P.s4[ta] : 0;
+		const int sb = q < 4 ? (int)(int8_t)(P.slo[tb] >> (8 * q)) : q == 4 ? P.s4[tb] : 0;
+		stab[e] = (uint32_t)(uint16_t)(int16_t)sa | (uint32_t)(uint16_t)(int16_t)sb << 16;
+	}
+	const int slot = blockIdx.x * 16 + (lane >> 2);
+	const bool live = slot < n_pairs;
+	const int rA = live ? pairs[2 * slot] : 0, rB = live ? pairs[2 * slot + 1] : 0;
+	MswReq qa, qb;
+	qa.rb = qa.re = 0; qa.read = 0; qa.is_rev = 0; qb = qa;
+	if (live) { qa = req[rA]; qb = req[rB]; }
+	const int qlen = live ? lens[qa.read] : 0;
+	const int tnA = (int)(qa.re - qa.rb), tnB = (int)(qb.re - qb.rb);
+	const int slen = (qlen + 15) / 16, npos = slen * 16, S = npos >> 2;   // byte flavour: 16 segments
+	const uint8_t *ms = seq + (live ? off[qa.read] : 0);
+	if (live) {
+		for (int kk = 0; kk < S; ++kk) cell[kk * 64 + lane] = 0;
+		for (int c = 0; c * 8 < S; ++c) {
+			uint32_t cd = 0;
+			for (int u = 0; u < 8 && c * 8 + u < S; ++u) {
+				const int k = j * S + c * 8 + u;
+				cd |= (msw_code(ms, qlen, qa.is_rev, k) | ((k + 1) % slen == 0 ? 8u : 0u)) << (4 * u);
+			}
+			codes[c * 64 + lane] = cd;
+		}
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	const int sat_limit = 255 - P.shift;
+	// ---- the forward pass of both ----
+	int gmaxA = 0, teA = -1, qeA = -1, gmaxB = 0, teB = -1, qeB = -1, satA = 0, satB = 0;
+	{
+		const int tn = tnA > tnB ? tnA : tnB;
+		bool run = live && tn > 0 && S > 0;
+		const msw_s2 oe_del = s2_splat(P.o_del + P.e_del), oe_ins = s2_splat(P.o_ins + P.e_ins), e_del = s2_splat(P.e_del), e_ins = s2_splat(P.e_ins);
+		const msw_s2 zero = s2_splat(0);
+		int Swave = run ? S : 0;
+		for (int o = 32; o; o >>= 1) Swave = max(Swave, __shfl_xor(Swave, o));
+		uint32_t co_diag = 0, co_fseg = 0, co_ffull = 0, co_keyA = 0, co_keyB = 0;
+		auto base_at = [&](const MswReq &rq, int tnx, int i) -> int {   // (rows past the end of the shorter window: its last row again, results unused)
+			const int ii = i < tnx ? i : tnx - 1;
+			return ii >= 0 ? msw_base(pac, P.l_pac, rq.rb + ii) : 0;
+		};
+		int ta_next = (run && j == 0) ? base_at(qa, tnA, 0) : 0, tb_next = (run && j == 0) ? base_at(qb, tnB, 0) : 0;
+		uint16_t *rowsA = rows + rA, *rowsB = rows + rB;
+		for (int t = 0; __any(run); ++t) {
+			const int i = t - j;
+			const bool act = run && i >= 0 && i < tn;
+			const int ta = ta_next, tb = tb_next;
+			if (run && i + 1 >= 0 && i + 1 < tn) { ta_next = base_at(qa, tnA, i + 1); tb_next = base_at(qb, tnB, i + 1); }
+			const uint32_t *srow = stab + ((ta << 2 | tb) << 3);
+			const uint32_t ci_diag = (uint32_t)msw_dpp<MSW_QP(0, 0, 1, 2)>((int)co_diag), ci_fseg = (uint32_t)msw_dpp<MSW_QP(0, 0, 1, 2)>((int)co_fseg);
+			const uint32_t ci_ffull = (uint32_t)msw_dpp<MSW_QP(0, 0, 1, 2)>((int)co_ffull);
+			const uint32_t ci_keyA = (uint32_t)msw_dpp<MSW_QP(0, 0, 1, 2)>((int)co_keyA), ci_keyB = (uint32_t)msw_dpp<MSW_QP(0, 0, 1, 2)>((int)co_keyB);
+			msw_s2 diag = s2_of(j ? ci_diag : 0u), fseg = s2_of(j ? ci_fseg : 0u), ffull = s2_of(j ? ci_ffull : 0u);
+			uint32_t keyA = j ? ci_keyA : 0u, keyB = j ? ci_keyB : 0u;
+			const int kbase = j * S;
+			const int kmax = act ? S : 0;
+			auto step = [&](uint32_t &w, int kk, uint32_t cd, int u) {
+				const msw_s2 hd = s2_of(__builtin_amdgcn_perm(0u, w, 0x0c020c00u));   // H_A | H_B << 16   (row i - 1)
+				msw_s2 e = s2_of(__builtin_amdgcn_perm(0u, w, 0x0c030c01u));          // E_A | E_B << 16
+				const uint32_t q = __builtin_amdgcn_ubfe(cd, 4 * u, 3);
+				const int m = __builtin_amdgcn_sbfe((int)cd, 4 * u + 3, 1);           // -1 at the last position of a segment
+				const msw_s2 s = s2_of(srow[q]);
+				const msw_s2 h = s2_max(s2_max(diag + s, e), fseg);                    // Hpre(i, k) of both
+				const uint32_t posc = (uint32_t)(0xffff - (kbase + kk));
+				keyA = max(keyA, u_of(h) << 16 | posc);
+				keyB = max(keyB, (u_of(h) & 0xffff0000u) | posc);
+				const msw_s2 hfin = s2_max(h, ffull);
+				e = s2_max(s2_max(e - e_del, h - oe_del), zero);
+				const msw_s2 t2 = h - oe_ins;
+				fseg = s2_of(u_of(s2_max(s2_max(fseg - e_ins, t2), zero)) & ~(uint32_t)m);
+				ffull = s2_max(s2_max(ffull - e_ins, t2), zero);
+				diag = hd;
+				w = __builtin_amdgcn_perm(u_of(e), u_of(hfin), 0x06020400u);            // bytes: H_A, E_A, H_B, E_B
+			};
+			for (int c = 0; c * 8 < Swave; ++c) {
+				const uint32_t cd = c * 8 < kmax ? codes[c * 64 + lane] : 0u;
+#pragma unroll
+				for (int u = 0; u < 8; u += 2) {
+					const int k = c * 8 + u;
+					if (k < kmax) {
+						uint32_t w0 = cell[k * 64 + lane], w1 = cell[(k + 1) * 64 + lane];
+						step(w0, k, cd, u); step(w1, k + 1, cd, u + 1);
+						cell[k * 64 + lane] = w0; cell[(k + 1) * 64 + lane] = w1;
+					}
+				}
+			}
+			if (act) { co_diag = u_of(diag); co_fseg = u_of(fseg); co_ffull = u_of(ffull); co_keyA = keyA; co_keyB = keyB; }
+			int stop = 0;
+			if (act && j == 3) {
+				if (i < tnA && !satA) {
+					const int imax = (int)(keyA >> 16);
+					rowsA[(size_t)i * n_req] = (uint16_t)imax;
+					if (imax > gmaxA) { gmaxA = imax; teA = i; qeA = 0xffff - (int)(keyA & 0xffff); if (gmaxA >= sat_limit) satA = 1; }
+				}
+				if (i < tnB && !satB) {
+					const int imax = (int)(keyB >> 16);
+					rowsB[(size_t)i * n_req] = (uint16_t)imax;
+					if (imax > gmaxB) { gmaxB = imax; teB = i; qeB = 0xffff - (int)(keyB & 0xffff); if (gmaxB >= sat_limit) satB = 1; }
+				}
+				if ((i + 1 >= tnA || satA) && (i + 1 >= tnB || satB)) stop = 1;
+			}
+			stop = msw_dpp<MSW_QP(3, 3, 3, 3)>(stop);
+			if (stop) run = false;
+		}
+	}
+	MswPassOut fA, fB;
+	fA.score = msw_dpp<MSW_QP(3, 3, 3, 3)>(gmaxA); fA.te = msw_dpp<MSW_QP(3, 3, 3, 3)>(teA); fA.qe = msw_dpp<MSW_QP(3, 3, 3, 3)>(qeA);
+	fB.score = msw_dpp<MSW_QP(3, 3, 3, 3)>(gmaxB); fB.te = msw_dpp<MSW_QP(3, 3, 3, 3)>(teB); fB.qe = msw_dpp<MSW_QP(3, 3, 3, 3)>(qeB);
+	satA = msw_dpp<MSW_QP(3, 3, 3, 3)>(satA); satB = msw_dpp<MSW_QP(3, 3, 3, 3)>(satB);
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	msw_tail(cell, P, pac, live, qa, qlen, ms, rA, n_req, fA, satA, rows, res);
+	msw_tail(cell, P, pac, live, qb, qlen, ms, rB, n_req, fB, satB, rows, res);
+}
+
 } // namespace
 
 size_t msw_lds_bytes(int max_len)
@@ -224,19 +387,60 @@ size_t msw_lds_bytes(int max_len)
 	return (size_t)((max_len + 15) / 16 * 16 / 4) * 64 * 4;   // a quarter of the padded query per lane (padding to 16 covers both lane widths)
 }
 
+size_t msw2_lds_bytes(int max_len)
+{
+	const int s_max = (max_len + 15) / 16 * 16 / 4;
+	return ((size_t)s_max * 64 + (size_t)((s_max + 7) / 8) * 64 + 128) * 4;
+}
+
+// h_req: the requests as the host holds them (for the pairing), or null: every request on its own.  h_list / d_list: room for
+// n_req ints each (host side page-locked in the pipeline): the pairs first (2 ints each), then the single requests.
 void launch_msw(void *stream, const MswParams &P, int n_req, const MswReq *d_req, const uint8_t *d_seq, const int64_t *d_off, const int *d_len,
-                const uint8_t *d_pac, MswRes *d_res, uint16_t *d_rows, int max_len)
+                const uint8_t *d_pac, MswRes *d_res, uint16_t *d_rows, int max_len, const MswReq *h_req, const int *h_len, int *h_list, int *d_list)
 {
 	if (n_req <= 0) return;
-	const size_t lds = msw_lds_bytes(max_len);
+	const size_t lds = msw_lds_bytes(max_len), lds2 = msw2_lds_bytes(max_len);
 	if (lds > 160 * 1024) die("mate-rescue kernel: reads of %d bp do not fit the LDS row buffers", max_len);
-	static size_t s_attr = 0;
+	static size_t s_attr = 0, s_attr2 = 0;
 	if (lds > s_attr) {
 		HIP_OK(hipFuncSetAttribute((const void *)msw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 		s_attr = lds;
 	}
-	const int blocks = (n_req + 15) / 16;
-	hipLaunchKernelGGL(msw_kernel, dim3(blocks), dim3(64), lds, (hipStream_t)stream, P, n_req, d_req, d_seq, d_off, d_len, d_pac, d_res, d_rows);
+	static const bool pairing = !(getenv("MPIBWA_MSW_PAIRS") && atoi(getenv("MPIBWA_MSW_PAIRS")) == 0);
+	int n_pairs = 0, n_single = n_req;
+	const int *d_single = nullptr;
+	if (pairing && h_req && h_len && h_list && d_list && lds2 <= 160 * 1024) {
+		// two requests next to each other for the same mate in the same orientation (mem_sam_pe lists an end's anchors one after the
+		// other: the windows of a repeat read's anchors are such runs), both in the byte flavour
+		int *pl = h_list, np = 0, ns = 0;
+		for (int k = 0; k < n_req;) {
+			if (k + 1 < n_req && h_req[k].read == h_req[k + 1].read && h_req[k].is_rev == h_req[k + 1].is_rev && h_len[h_req[k].read] * P.a < 250 &&
+			    h_req[k].re > h_req[k].rb && h_req[k + 1].re > h_req[k + 1].rb) {
+				pl[2 * np] = k; pl[2 * np + 1] = k + 1; ++np; k += 2;
+			} else ++k;
+		}
+		// (second sweep: the singles behind the pairs)
+		int *sl = h_list + 2 * np;
+		for (int k = 0, p = 0; k < n_req; ++k) {
+			if (p < np && pl[2 * p] == k) { ++p; ++k; continue; }
+			sl[ns++] = k;
+		}
+		n_pairs = np; n_single = ns;
+		HIP_OK(hipMemcpyAsync(d_list, h_list, (size_t)n_req * sizeof(int), hipMemcpyHostToDevice, (hipStream_t)stream));
+		d_single = d_list + 2 * np;
+		if (n_pairs) {
+			if (lds2 > s_attr2) {
+				HIP_OK(hipFuncSetAttribute((const void *)msw2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+				s_attr2 = lds2;
+			}
+			const int s_max = (max_len + 15) / 16 * 16 / 4;
+			hipLaunchKernelGGL(msw2_kernel, dim3((n_pairs + 15) / 16), dim3(64), lds2, (hipStream_t)stream, P, n_pairs, n_req, (const int *)d_list, d_req, d_seq, d_off,
+			                   d_len, d_pac, d_res, d_rows, s_max);
+		}
+	}
+	if (n_single)
+		hipLaunchKernelGGL(msw_kernel, dim3((n_single + 15) / 16), dim3(64), lds, (hipStream_t)stream, P, n_single, n_req, d_single, d_req, d_seq, d_off, d_len, d_pac,
+		                   d_res, d_rows);
 	HIP_OK(hipGetLastError());
 }
 

@@ -400,7 +400,8 @@ struct Workspace {
 	DevBuf heavy, hoff, grp_scratch, grp_clist, grp_ustart, grp_unit_rd, grp_unit_av, grp_nunits, c_rabs, c_rcnt;
 	PinBuf h_regs2;
 	PinBuf h_flat, h_sa, h_qbl, h_chains, h_seeds, h_srt, h_regs, h_nregs, h_mreq[2], h_mres[2], h_ahdr[2], h_apool[2];
-	DevBuf mreq[2], mres[2], mrows[2], alist[2];
+	DevBuf mreq[2], mres[2], mrows[2], alist[2], mlist[2];
+	PinBuf h_mlist[2];
 	DevBuf seq, off, len, intv, nintv, cnt, scratch, nseeds, lrep, seed_off, rows, qbl, sa;
 	DevBuf chain_off, chains, seeds, srt, reg_off, regs, nregs, tab, areq, ahdr, apool, agap, acnt, areq2, ahdr2, apool2, acnt2;
 	// SAM text on the device (sam_kernel.hip): line descriptors, names / qualities of the chunk, contig names, output arena per part
@@ -1540,9 +1541,12 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		HIP_OK(hipMemcpyAsync(d_req, P.mreq, P.n_mreq * sizeof(MswReq), hipMemcpyHostToDevice, P.st));
 		const MswParams mp = msw_params(opt, bns->l_pac);
 		P.mev.start(P.st);
+		int *h_ml = (int *)WS.h_mlist[slot].ensure(P.n_mreq * sizeof(int) + 64), *d_ml = (int *)WS.mlist[slot].ensure(P.n_mreq * sizeof(int) + 64);
+		static_assert(sizeof(MswReq) == sizeof(MswReqH), "host/device record layouts differ");
 		for (size_t b = 0; b < P.n_mreq; b += per) {
 			const int cnt = (int)std::min(per, P.n_mreq - b);
-			launch_msw(P.st, mp, cnt, d_req + b, d_seq, d_off, d_len, (const uint8_t *)ix.d_pac, d_res + b, d_rows, max_len);
+			launch_msw(P.st, mp, cnt, d_req + b, d_seq, d_off, d_len, (const uint8_t *)ix.d_pac, d_res + b, d_rows, max_len, (const MswReq *)(P.mreq + b), lens,
+			           h_ml + b, d_ml + b);
 		}
 		P.mev.stop(P.st);
 		HIP_OK(hipMemcpyAsync(P.mres, d_res, P.n_mreq * sizeof(MswRes), hipMemcpyDeviceToHost, P.st));   // pinned: truly asynchronous

@@ -216,7 +216,19 @@ def _matesw_cases(rng, l_pac, ref, n_req, read_lens):
         # the kernel aligns the (reverse-complemented) read: store the read so that its transform is q
         stored = q if not is_rev else np.where(q[::-1] < 4, 3 - q[::-1], 4).astype(np.uint8)
         reads.append(stored)
-        rb.append(b); re.append(b + tl); rd.append(i); rev.append(is_rev)
+        rb.append(b); re.append(b + tl); rd.append(len(reads) - 1); rev.append(is_rev)
+        # more windows for the same mate in the same orientation, as the anchors of a repeat read ask for: requests next to each other
+        # that the library aligns two per quad (msw2_kernel) — the same window shifted, another place, a much shorter / longer one
+        for _ in range(int(rng.choice([0, 0, 1, 1, 2, 3]))):
+            kind = rng.random()
+            if kind < 0.4:
+                b2 = min(max(b + int(rng.integers(-200, 200)), strand * l_pac), strand * l_pac + l_pac - tl)
+                tl2 = tl
+            else:
+                tl2 = int(rng.integers(max(ql // 2, 19), ql + 600))
+                s2 = int(rng.integers(0, 2))
+                b2 = int(rng.integers(0, l_pac - tl2)) + s2 * l_pac
+            rb.append(b2); re.append(b2 + tl2); rd.append(len(reads) - 1); rev.append(is_rev)
     return reads, rb, re, rd, rev
 
 
@@ -235,7 +247,8 @@ def test_matesw_kernel_matches_reference_ksw_align2(engine):
     opt_p = engine.opt()
     opt = opt_p.contents
     mat = np.frombuffer(bytes(opt.mat), dtype=np.int8).copy()
-    reads, rb, re, rd, rev = _matesw_cases(rng, l_pac, ref, 3000, [50, 100, 150, 151, 249, 250, 251, 301])
+    reads, rb, re, rd, rev = _matesw_cases(rng, l_pac, ref, 2000, [50, 100, 150, 151, 249, 250, 251, 301])
+    assert sum(1 for i in range(1, len(rd)) if rd[i] == rd[i - 1]) > 1000   # (runs of requests for one mate: the two-per-quad kernel's food)
     got, ms = engine.matesw(opt_p, l_pac, pac, reads, rb, re, rd, rev)
     use_ref = po.ref_available()
     if use_ref:
@@ -249,7 +262,7 @@ def test_matesw_kernel_matches_reference_ksw_align2(engine):
     for i in range(len(rb)):
         tl = re[i] - rb[i]
         win = np.ascontiguousarray(dref[rb[i]:re[i]])
-        s = reads[i]
+        s = reads[rd[i]]
         q = s if not rev[i] else np.where(s[::-1] < 4, 3 - s[::-1], 4).astype(np.uint8)
         q = np.ascontiguousarray(q)
         xtra = 0x40000 | 0x80000 | (0x10000 if len(q) * opt.a < 250 else 0) | (opt.min_seed_len * opt.a)
