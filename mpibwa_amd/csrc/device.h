@@ -256,7 +256,7 @@ struct MswParams {
 };
 size_t msw_lds_bytes(int max_len);
 // d_rows: scratch of n_req * (longest window) u16
-// h_req / h_len (read lengths) / h_list / d_list (n_req ints each) given: requests next to each other for the same mate and orientation
+// h_req / h_len (read lengths) / h_list / d_list (2 n_req ints each) given: requests next to each other for the same mate and orientation
 // are aligned two per quad in packed 16-bit arithmetic (msw2_kernel); otherwise every request on its own
 void launch_msw(void *stream, const MswParams &P, int n_req, const MswReq *d_req, const uint8_t *d_seq, const int64_t *d_off, const int *d_len,
                 const uint8_t *d_pac, MswRes *d_res, uint16_t *d_rows, int max_len, const MswReq *h_req = nullptr, const int *h_len = nullptr,

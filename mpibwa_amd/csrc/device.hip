@@ -675,9 +675,9 @@ extern "C" int mi355x_matesw_batch(const mem_opt_t *opt, int64_t l_pac, const ui
 	HIP_OK(hipMemcpy(d_req, rq.data(), (size_t)n_req * sizeof(MswReq), hipMemcpyHostToDevice));
 	Timer tm;
 	tm.start(st);
-	std::vector<int> h_list(n_req + 16);
+	std::vector<int> h_list(2 * (size_t)n_req + 16);
 	int *d_list;
-	HIP_OK(hipMalloc(&d_list, (size_t)(n_req + 16) * sizeof(int)));
+	HIP_OK(hipMalloc(&d_list, (2 * (size_t)n_req + 16) * sizeof(int)));
 	launch_msw(st, msw_params(opt, l_pac), n_req, d_req, d_seq, d_off, d_len, d_pac, d_res, d_rows, max_len, rq.data(), lens.data(), h_list.data(), d_list);
 	double ms = tm.stop(st);
 	HIP_OK(hipGetLastError());

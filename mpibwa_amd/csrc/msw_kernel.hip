@@ -168,7 +168,9 @@ __device__ __forceinline__ void msw_tail(uint32_t *cell, const MswParams &P, con
 	out.score = f.score; out.te = f.te; out.qe = f.qe; out.score2 = -1; out.te2 = -1; out.tb = -1; out.qb = -1; out.flags = sat;
 	// b[]: runs of rows whose maximum reaches minsc; second best = best run outside te +- ceil(score / max)
 	// (the quad's own stores to rows[]: same wave, same addresses, program order)
-	if (live && j == 0 && !sat && f.te >= 0) {
+	// (a window whose best row stays below minsc has no such row at all — nine rescue windows in ten of a repeat read's anchors: the
+	// scan of its 600 row maxima, one dependent global load each, was as long as the forward pass itself)
+	if (live && j == 0 && !sat && f.te >= 0 && f.score >= minsc) {
 		const int d = (f.score + P.max_sc - 1) / P.max_sc;
 		const int low = f.te - d, high = f.te + d;
 		int last_sc = -1, last_i = -1;
@@ -268,10 +270,13 @@ __global__ __launch_bounds__(64) void msw2_kernel(MswParams P, int n_pairs, int 
 	}
 	const int slot = blockIdx.x * 16 + (lane >> 2);
 	const bool live = slot < n_pairs;
-	const int rA = live ? pairs[2 * slot] : 0, rB = live ? pairs[2 * slot + 1] : 0;
+	// (rB < 0: a request without a partner rides alone — its own launch of a few hundred waves would be as long as one wave's walk
+	// through a window, behind this one)
+	const int rA = live ? pairs[2 * slot] : 0, rB = live ? pairs[2 * slot + 1] : -1;
+	const bool hasB = rB >= 0;
 	MswReq qa, qb;
 	qa.rb = qa.re = 0; qa.read = 0; qa.is_rev = 0; qb = qa;
-	if (live) { qa = req[rA]; qb = req[rB]; }
+	if (live) { qa = req[rA]; if (hasB) qb = req[rB]; else { qb = qa; qb.re = qb.rb; } }
 	const int qlen = live ? lens[qa.read] : 0;
 	const int tnA = (int)(qa.re - qa.rb), tnB = (int)(qb.re - qb.rb);
 	const int slen = (qlen + 15) / 16, npos = slen * 16, S = npos >> 2;   // byte flavour: 16 segments
@@ -306,7 +311,7 @@ __global__ __launch_bounds__(64) void msw2_kernel(MswParams P, int n_pairs, int 
 			return ii >= 0 ? msw_base(pac, P.l_pac, rq.rb + ii) : 0;
 		};
 		int ta_next = (run && j == 0) ? base_at(qa, tnA, 0) : 0, tb_next = (run && j == 0) ? base_at(qb, tnB, 0) : 0;
-		uint16_t *rowsA = rows + rA, *rowsB = rows + rB;
+		uint16_t *rowsA = rows + rA, *rowsB = rows + (hasB ? rB : rA);
 		for (int t = 0; __any(run); ++t) {
 			const int i = t - j;
 			const bool act = run && i >= 0 && i < tn;
@@ -377,7 +382,7 @@ __global__ __launch_bounds__(64) void msw2_kernel(MswParams P, int n_pairs, int 
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 	msw_tail(cell, P, pac, live, qa, qlen, ms, rA, n_req, fA, satA, rows, res);
-	msw_tail(cell, P, pac, live, qb, qlen, ms, rB, n_req, fB, satB, rows, res);
+	if (__any(live && hasB)) msw_tail(cell, P, pac, live && hasB, qb, qlen, ms, hasB ? rB : 0, n_req, fB, satB, rows, res);
 }
 
 } // namespace
@@ -394,7 +399,7 @@ size_t msw2_lds_bytes(int max_len)
 }
 
 // h_req: the requests as the host holds them (for the pairing), or null: every request on its own.  h_list / d_list: room for
-// n_req ints each (host side page-locked in the pipeline): the pairs first (2 ints each), then the single requests.
+// 2 n_req ints each (host side page-locked in the pipeline): the pairs first (2 ints each), then the single requests.
 void launch_msw(void *stream, const MswParams &P, int n_req, const MswReq *d_req, const uint8_t *d_seq, const int64_t *d_off, const int *d_len,
                 const uint8_t *d_pac, MswRes *d_res, uint16_t *d_rows, int max_len, const MswReq *h_req, const int *h_len, int *h_list, int *d_list)
 {
@@ -412,22 +417,23 @@ void launch_msw(void *stream, const MswParams &P, int n_req, const MswReq *d_req
 	if (pairing && h_req && h_len && h_list && d_list && lds2 <= 160 * 1024) {
 		// two requests next to each other for the same mate in the same orientation (mem_sam_pe lists an end's anchors one after the
 		// other: the windows of a repeat read's anchors are such runs), both in the byte flavour
-		int *pl = h_list, np = 0, ns = 0;
+		// work items of msw2_kernel from the front of the list (two ints each; a byte-flavour request without a partner: (k, -1)), the
+		// requests of the word flavour (reads of 250 bp and more) for msw_kernel from its back
+		int *pl = h_list, np = 0, ns = 0, n_alone = 0;
+		int *sl_end = h_list + 2 * (size_t)n_req;
 		for (int k = 0; k < n_req;) {
-			if (k + 1 < n_req && h_req[k].read == h_req[k + 1].read && h_req[k].is_rev == h_req[k + 1].is_rev && h_len[h_req[k].read] * P.a < 250 &&
-			    h_req[k].re > h_req[k].rb && h_req[k + 1].re > h_req[k + 1].rb) {
+			const bool byte_k = h_len[h_req[k].read] * P.a < 250;
+			if (!byte_k) { *--sl_end = k; ++ns; ++k; continue; }
+			if (k + 1 < n_req && h_req[k].read == h_req[k + 1].read && h_req[k].is_rev == h_req[k + 1].is_rev && h_req[k].re > h_req[k].rb &&
+			    h_req[k + 1].re > h_req[k + 1].rb) {
 				pl[2 * np] = k; pl[2 * np + 1] = k + 1; ++np; k += 2;
-			} else ++k;
-		}
-		// (second sweep: the singles behind the pairs)
-		int *sl = h_list + 2 * np;
-		for (int k = 0, p = 0; k < n_req; ++k) {
-			if (p < np && pl[2 * p] == k) { ++p; ++k; continue; }
-			sl[ns++] = k;
+			} else { pl[2 * np] = k; pl[2 * np + 1] = -1; ++np; ++n_alone; ++k; }
 		}
 		n_pairs = np; n_single = ns;
-		HIP_OK(hipMemcpyAsync(d_list, h_list, (size_t)n_req * sizeof(int), hipMemcpyHostToDevice, (hipStream_t)stream));
-		d_single = d_list + 2 * np;
+		static const bool say = getenv("MPIBWA_CPUSEC") != nullptr;
+		if (say) fprintf(stderr, "[msw] %d requests: %d quads of two windows for one mate, %d of one, %d in the word flavour\n", n_req, np - n_alone, n_alone, ns);
+		HIP_OK(hipMemcpyAsync(d_list, h_list, (size_t)2 * n_req * sizeof(int), hipMemcpyHostToDevice, (hipStream_t)stream));
+		d_single = d_list + (sl_end - h_list);
 		if (n_pairs) {
 			if (lds2 > s_attr2) {
 				HIP_OK(hipFuncSetAttribute((const void *)msw2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));

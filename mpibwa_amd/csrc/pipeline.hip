@@ -1541,12 +1541,12 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 		HIP_OK(hipMemcpyAsync(d_req, P.mreq, P.n_mreq * sizeof(MswReq), hipMemcpyHostToDevice, P.st));
 		const MswParams mp = msw_params(opt, bns->l_pac);
 		P.mev.start(P.st);
-		int *h_ml = (int *)WS.h_mlist[slot].ensure(P.n_mreq * sizeof(int) + 64), *d_ml = (int *)WS.mlist[slot].ensure(P.n_mreq * sizeof(int) + 64);
+		int *h_ml = (int *)WS.h_mlist[slot].ensure(2 * P.n_mreq * sizeof(int) + 64), *d_ml = (int *)WS.mlist[slot].ensure(2 * P.n_mreq * sizeof(int) + 64);
 		static_assert(sizeof(MswReq) == sizeof(MswReqH), "host/device record layouts differ");
 		for (size_t b = 0; b < P.n_mreq; b += per) {
 			const int cnt = (int)std::min(per, P.n_mreq - b);
 			launch_msw(P.st, mp, cnt, d_req + b, d_seq, d_off, d_len, (const uint8_t *)ix.d_pac, d_res + b, d_rows, max_len, (const MswReq *)(P.mreq + b), lens,
-			           h_ml + b, d_ml + b);
+			           h_ml + 2 * b, d_ml + 2 * b);
 		}
 		P.mev.stop(P.st);
 		HIP_OK(hipMemcpyAsync(P.mres, d_res, P.n_mreq * sizeof(MswRes), hipMemcpyDeviceToHost, P.st));   // pinned: truly asynchronous
