@@ -23,6 +23,9 @@
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
+#include <utility>
+#include <vector>
 #include "device.h"
 
 namespace mbw {
@@ -1118,15 +1121,14 @@ void launch_chain(void *stream, const ChainParams &P, int n_reads, const int *d_
 			hipLaunchKernelGGL((chain_kernel<CK_MAXSEEDS_BIG, CK_MAXCH, CK_MAXSEEDS>), grid, block, lds_big, st, CHAIN_ARGS, (const int *)list_b, (const unsigned int *)(count + 2));
 		}
 		static const bool use_general = getenv("MPIBWA_CHAIN_GENERAL") && atoi(getenv("MPIBWA_CHAIN_GENERAL")) != 0;
+		bool launch_t = false;
 		if (big >= 2 && !use_general) {
 			// the reads with more than 9 chains (up to 255 seeds): a wavefront per read with the B-tree in LDS (on a low-complexity
 			// reference a third of the reads are of this kind; a lane per read with the tree in HBM — chain_general_kernel, rounds 2-3 —
 			// took 51 ms per chunk there)
 			int *list_t = list_a;   // (the 64-seed retry is done with it)
 			hipLaunchKernelGGL(chain_pick_kernel, pgrid, pblock, 0, st, n_reads, d_len, d_nseeds, (const int *)d_nchains, noflt, 0, CK_MAXSEEDS_BIG, n_reads, list_t, count);
-			hipLaunchKernelGGL((chain_heavy_kernel<256>), dim3(HV_WAVES_T), dim3(64), hv_lds_bytes(256), st, P, (const int *)list_t, (const unsigned int *)count, count + 3,
-			                   n_reads, d_len, d_nseeds, d_lrep, (const i64 *)d_seed_off, (const unsigned long long *)d_sa, d_qbl, (const i64 *)d_ann_off, d_ann_alt, n_seqs, d_tab,
-			                   hv_scr, d_chains, d_seeds, d_srt, d_nchains);
+			launch_t = true;   // (launched below, next to the instantiations for more seeds)
 		}
 		if (big >= 2 && use_general) {
 			// the scratch holds gen_cap reads at a time: several rounds over it (on a low-complexity reference a third of the reads have
@@ -1150,13 +1152,42 @@ void launch_chain(void *stream, const ChainParams &P, int n_reads, const int *d_
 			uint8_t *scr_s = hv_scr + HV_WAVES_T * hv_scratch_bytes(256);
 			hipLaunchKernelGGL(chain_pick_kernel, pgrid, pblock, 0, st, n_reads, d_len, d_nseeds, (const int *)d_nchains, noflt, CK_MAXSEEDS_BIG, 1024, n_reads, list_h1, count + 4);
 			hipLaunchKernelGGL(chain_pick_kernel, pgrid, pblock, 0, st, n_reads, d_len, d_nseeds, (const int *)d_nchains, noflt, 1024, 4096, n_reads, list_h2, count + 6);
-			hipLaunchKernelGGL((chain_heavy_kernel<4096>), dim3(HV_WAVES_L), dim3(64), hv_lds_bytes(4096), st, P, (const int *)list_h2, (const unsigned int *)(count + 6), count + 7,
+			// The instantiations are latency-bound launches of a few hundred to a few thousand waves each: side by side on two side streams
+			// of the call's stream (created once per stream) instead of one after the other — 23 -> 10 ms per sub-batch with one call in flight.
+			struct Side { hipStream_t s[2]; hipEvent_t fork, join[2]; };
+			static std::mutex side_mu;
+			static std::vector<std::pair<hipStream_t, Side>> sides;
+			Side sd;
+			{
+				std::lock_guard<std::mutex> lk(side_mu);
+				bool found = false;
+				for (auto &e : sides) if (e.first == st) { sd = e.second; found = true; break; }
+				if (!found) {
+					for (int k = 0; k < 2; ++k) { HIP_OK(hipStreamCreateWithFlags(&sd.s[k], hipStreamNonBlocking)); HIP_OK(hipEventCreateWithFlags(&sd.join[k], hipEventDisableTiming)); }
+					HIP_OK(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming));
+					sides.emplace_back(st, sd);
+				}
+			}
+			HIP_OK(hipEventRecord(sd.fork, st));
+			for (int k = 0; k < 2; ++k) HIP_OK(hipStreamWaitEvent(sd.s[k], sd.fork, 0));
+			hipLaunchKernelGGL((chain_heavy_kernel<4096>), dim3(HV_WAVES_L), dim3(64), hv_lds_bytes(4096), sd.s[0], P, (const int *)list_h2, (const unsigned int *)(count + 6), count + 7,
 			                   n_reads, d_len, d_nseeds, d_lrep, (const i64 *)d_seed_off, (const unsigned long long *)d_sa, d_qbl, (const i64 *)d_ann_off, d_ann_alt, n_seqs, d_tab,
 			                   scr_s + HV_WAVES_S * hv_scratch_bytes(1024), d_chains, d_seeds, d_srt, d_nchains);
-			hipLaunchKernelGGL((chain_heavy_kernel<1024>), dim3(HV_WAVES_S), dim3(64), hv_lds_bytes(1024), st, P, (const int *)list_h1, (const unsigned int *)(count + 4), count + 5,
+			hipLaunchKernelGGL((chain_heavy_kernel<1024>), dim3(HV_WAVES_S), dim3(64), hv_lds_bytes(1024), sd.s[1], P, (const int *)list_h1, (const unsigned int *)(count + 4), count + 5,
 			                   n_reads, d_len, d_nseeds, d_lrep, (const i64 *)d_seed_off, (const unsigned long long *)d_sa, d_qbl, (const i64 *)d_ann_off, d_ann_alt, n_seqs, d_tab,
 			                   scr_s, d_chains, d_seeds, d_srt, d_nchains);
+			if (launch_t) {
+				hipLaunchKernelGGL((chain_heavy_kernel<256>), dim3(HV_WAVES_T), dim3(64), hv_lds_bytes(256), st, P, (const int *)list_a, (const unsigned int *)count, count + 3,
+				                   n_reads, d_len, d_nseeds, d_lrep, (const i64 *)d_seed_off, (const unsigned long long *)d_sa, d_qbl, (const i64 *)d_ann_off, d_ann_alt, n_seqs, d_tab,
+				                   hv_scr, d_chains, d_seeds, d_srt, d_nchains);
+				launch_t = false;
+			}
+			for (int k = 0; k < 2; ++k) { HIP_OK(hipEventRecord(sd.join[k], sd.s[k])); HIP_OK(hipStreamWaitEvent(st, sd.join[k], 0)); }
 		}
+		if (launch_t)   // (MPIBWA_CHAIN_HEAVY=0: the 256-seed instantiation on its own)
+			hipLaunchKernelGGL((chain_heavy_kernel<256>), dim3(HV_WAVES_T), dim3(64), hv_lds_bytes(256), st, P, (const int *)list_a, (const unsigned int *)count, count + 3,
+			                   n_reads, d_len, d_nseeds, d_lrep, (const i64 *)d_seed_off, (const unsigned long long *)d_sa, d_qbl, (const i64 *)d_ann_off, d_ann_alt, n_seqs, d_tab,
+			                   hv_scr, d_chains, d_seeds, d_srt, d_nchains);
 	}
 #undef CHAIN_ARGS
 	HIP_OK(hipGetLastError());
