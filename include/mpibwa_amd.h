@@ -276,11 +276,12 @@ int mi355x_global_batch(const mem_opt_t *opt, int64_t l_pac, const uint8_t *pac,
 /* Pairing decisions of mem_sam_pe (src/bwamem_pair.c:250-393 with mem_sort_dedup_patch src/bwamem.c:437-489, the test of
  * mem_matesw :118-128, mem_mark_primary_se src/bwamem.c:493-569, mem_pair :182-243, mem_approx_mapq_se src/bwamem.c:952-976,
  * the XA test of src/bwamem_extra.c:91-110) for n_pairs pairs given by the regions of their ends as phase 1 leaves them
- * (regs: 4 records of 64 bytes per read — rb, re (int64), qb, qe, rid, score, truesc, w, seedcov, seedlen0 (int32), frac_rep
+ * (regs: mi355x_pair_maxreg() records of 64 bytes per read — rb, re (int64), qb, qe, rid, score, truesc, w, seedcov, seedlen0 (int32), frac_rep
  * (float), pad; n_regs per read), computed by pair_simple_kernel.  status[k] = 1: the pair is decided — desc (56 bytes per read:
  * rb, re, qb, qe, req, rid, flag, mapq, score, sub) and req (40 bytes per read: rb, re, read, qb, qe, w2, truesc, pad) describe the
  * two records of its paired branch; any other value: the kernel leaves the pair to the library's host path (the value names
  * the test that said so).  Returns 0, or -1 when the kernel cannot use these insert-size statistics. */
+int mi355x_pair_maxreg(void);
 int mi355x_pair_batch(const mem_opt_t *opt, const bntseq_t *bns, const mem_pestat_t pes[4], int64_t n_processed, int n_pairs,
                       const void *regs, const int *n_regs, int max_len, uint8_t *status, void *desc, void *req);
 

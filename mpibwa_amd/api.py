@@ -17,7 +17,7 @@ EXPORTS = [
     "mem_process_seqs", "mem_opt_init", "bwa_fill_scmat", "bwa_idx_load_from_disk", "bwa_mem2idx", "bwa_idx_destroy",
     "mi355x_index_upload", "mi355x_index_alloc", "mi355x_index_buffers", "mi355x_index_d2d", "mi355x_index_commit",
     "mi355x_finalize", "mi355x_index_build", "mi355x_index_build_gpu",
-    "mi355x_smem_batch", "mi355x_sa_batch", "mi355x_sa_batch2", "mi355x_sa_dense_info", "mi355x_extend_batch", "mi355x_matesw_batch", "mi355x_chain_batch", "mi355x_pair_batch", "mi355x_fastq_scan", "mi355x_fastq_chunks", "mi355x_fastq_fill", "mi355x_last_stats", "mi355x_host_cpus", "mi355x_collect_sam", "mi355x_collect_sam_into", "mi355x_host_ksw_align2",
+    "mi355x_smem_batch", "mi355x_sa_batch", "mi355x_sa_batch2", "mi355x_sa_dense_info", "mi355x_extend_batch", "mi355x_matesw_batch", "mi355x_chain_batch", "mi355x_pair_batch", "mi355x_pair_maxreg", "mi355x_fastq_scan", "mi355x_fastq_chunks", "mi355x_fastq_fill", "mi355x_last_stats", "mi355x_host_cpus", "mi355x_collect_sam", "mi355x_collect_sam_into", "mi355x_host_ksw_align2",
     "bwa_set_rg", "bwa_insert_header", "bwa_idx2mem", "mi355x_write_map", "mi355x_init", "mi355x_rank_host_threads", "mi355x_index_checksums", "mi355x_init_bcast_seconds", "mi355x_global_batch", "mi355x_device_count", "mi355x_device_memory", "mi355x_buffer_growths",
 ]
 
@@ -299,9 +299,10 @@ class Engine:
     AREQ_DT = np.dtype([("rb", "<i8"), ("re", "<i8"), ("read", "<i4"), ("qb", "<i4"), ("qe", "<i4"), ("w2", "<i4"), ("truesc", "<i4"), ("pad", "<i4")])
 
     def pairs(self, opt, pes, regs, n_regs, max_len=150, n_processed=0):
-        """pair_simple_kernel on pairs given by their regions: regs (2 n_pairs, 4) of REG_DT, n_regs (2 n_pairs).
+        """pair_simple_kernel on pairs given by their regions: regs (2 n_pairs, mi355x_pair_maxreg()) of REG_DT, n_regs (2 n_pairs).
         -> status (n_pairs,) uint8, desc (2 n_pairs,) DESC_DT, req (2 n_pairs,) AREQ_DT"""
         regs = np.ascontiguousarray(regs, dtype=self.REG_DT)
+        assert regs.shape[1] == self.lib.mi355x_pair_maxreg()
         n_regs = np.ascontiguousarray(n_regs, dtype=np.int32)
         n_pairs = len(n_regs) // 2
         status = np.zeros(n_pairs, dtype=np.uint8)

@@ -214,7 +214,8 @@ void launch_sam_emit(void *stream, const SamParams &P, int n_reads, const SamDes
                      uint8_t *d_arena, size_t arena_bytes, unsigned long long *d_arena_used, unsigned long long *d_out_off, int *d_out_len);
 
 // ---- pairing decisions of the pairs with one plain hit per end (pair_kernel.hip) ----
-#define PR_MAXREG 4               // regions per read the kernel looks at (a read with more is the host's)
+#define PR_MAXREG 8               // regions per read the kernel looks at (a read with more is the host's); 4 until round 4
+extern "C" int mi355x_pair_maxreg(void);
 struct PairParams {
 	int64_t l_pac;
 	int a, b, pen_unpaired, min_seed_len, w, o_del, e_del, o_ins, e_ins, max_chain_gap, T, max_matesw;

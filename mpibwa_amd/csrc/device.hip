@@ -424,6 +424,7 @@ void pair_tables(const mem_opt_t *opt, const mem_pestat_t pes[4], const PairPara
 // (regs: PR_MAXREG DevReg records per read, n_regs per read) as they stand after phase 1; status[k] = 1: decided — desc[2k], desc[2k+1]
 // (SamDesc) and req[2k], req[2k+1] (AlnReq) are what mem_sam_pe's paired branch reports; else the code of the test that sent the pair to
 // the host.  Returns 0, or -1 when the insert-size statistics are not usable by the kernel.
+extern "C" int mi355x_pair_maxreg(void) { return PR_MAXREG; }
 extern "C" int mi355x_pair_batch(const mem_opt_t *opt, const bntseq_t *bns, const mem_pestat_t pes[4], int64_t n_processed, int n_pairs,
                                  const void *regs, const int *n_regs, int max_len, uint8_t *status, void *desc, void *req)
 {

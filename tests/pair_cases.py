@@ -1,5 +1,5 @@
 """Adversarial region lists for the pairing stage: what mem_chain2aln could leave for the two ends of a pair (1-4 regions per end),
-built around a true fragment and bent in the ways that steer mem_sam_pe's decisions — overlapping and contained hits (the redundancy
+built around a true fragment (1-9 regions per end) and bent in the ways that steer mem_sam_pe's decisions — overlapping and contained hits (the redundancy
 pass), equal scores (hash tie-breaks of the primary marking and of mem_pair), hits on the other strand / another contig / an ALT contig,
 mates at every distance and orientation, short and clipped hits."""
 import numpy as np
@@ -40,7 +40,7 @@ def adversarial_pairs(rng, n_pairs, l_pac, offs, lq=150, orient="FR"):
         ends = []
         for e in range(2):
             regs = []
-            n = int(rng.choice([1, 1, 2, 2, 3, 4]))
+            n = int(rng.choice([1, 1, 2, 2, 3, 4, 5, 6, 8, 9]))
             fwd_read = (e == 0) != flip
             base_p = p if fwd_read == (orient == "FR") else p + frag - lq   # FR: the forward read upstream; RF: downstream
             base_rev = not fwd_read

@@ -77,17 +77,20 @@ def test_pair_kernel_matches_the_reference_mem_sam_pe(genome, which_pes, kw):
     rng = np.random.default_rng(500 + which_pes + len(kw))
     pairs = adversarial_pairs(rng, 3000, l_pac, offs, orient=PES_SETS[which_pes][1])
     pes = _pes(PES_SETS[which_pes][0])
-    regs = np.zeros((2 * len(pairs), 4), dtype=api.Engine.REG_DT)
+    maxreg = int(eng.lib.mi355x_pair_maxreg())
+    regs = np.zeros((2 * len(pairs), maxreg), dtype=api.Engine.REG_DT)
     n_regs = np.zeros(2 * len(pairs), dtype=np.int32)
     for k, ends in enumerate(pairs):
         for e in range(2):
             n_regs[2 * k + e] = len(ends[e])
+            if len(ends[e]) > maxreg:
+                continue      # (the kernel leaves such a pair to the host: only the count matters)
             for f in ("rb", "re", "qb", "qe", "rid", "score", "truesc", "w", "seedcov", "seedlen0", "frac_rep"):
                 regs[2 * k + e, :len(ends[e])][f] = ends[e][f]
     id0 = 1234
     status, desc, req = eng.pairs(opt, pes, regs, n_regs, max_len=150, n_processed=2 * id0)
     a, q_del, r_del, q_ins, r_ins, w_opt = opt.contents.a, opt.contents.o_del, opt.contents.e_del, opt.contents.o_ins, opt.contents.e_ins, opt.contents.w
-    n_taken = n_ref_plain = n_multi = n_tie = 0
+    n_taken = n_ref_plain = n_multi = n_tie = n_many = 0
     for k, ends in enumerate(pairs):
         want = po.ref_pair(ropt, ref.bns, ref.pac, pes, id0 + k, 150, ends[0], ends[1])
         plain = want["paired"] and want["n_align"] == 0 and want["n_xa"] == (0, 0) and want["n_lines"] == 2
@@ -97,6 +100,7 @@ def test_pair_kernel_matches_the_reference_mem_sam_pe(genome, which_pes, kw):
         n_taken += 1
         assert plain, (k, "the kernel decided a pair the reference treats otherwise", want, ends)
         n_multi += len(ends[0]) + len(ends[1]) > 2
+        n_many += len(ends[0]) > 4 or len(ends[1]) > 4
         n_tie += len(set(ends[0]["score"])) < len(ends[0]) or len(set(ends[1]["score"])) < len(ends[1])
         for e in range(2):
             d, rq, L = desc[2 * k + e], req[2 * k + e], want["lines"][e]
@@ -114,4 +118,4 @@ def test_pair_kernel_matches_the_reference_mem_sam_pe(genome, which_pes, kw):
     if which_pes == 2:
         assert n_taken == 0 and n_ref_plain == 0
     else:
-        assert n_taken > 0.5 * n_ref_plain and n_taken > 250 and n_multi > 100 and n_tie > 30, (n_taken, n_ref_plain, n_multi, n_tie)
+        assert n_taken > 0.5 * n_ref_plain and n_taken > 100 and n_multi > 60 and n_tie > 20 and n_many > 10, (n_taken, n_ref_plain, n_multi, n_tie, n_many)
