@@ -99,7 +99,6 @@ __global__ void grp_units_kernel(int n_el, int n_heavy, const u64 *__restrict__ 
 
 } // namespace
 
-struct GrpSizes { size_t key, val, tmp; };
 static size_t cub_tmp_bytes(int n_el)
 {
 	size_t a = 0, b = 0, c = 0, d = 0;

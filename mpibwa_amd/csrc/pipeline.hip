@@ -569,11 +569,7 @@ bool device_memory_pressure(size_t wanted)
 		n_busy = now_busy;
 	}
 	--g_waiting_for_memory;
-	if (!ok) {
-		// everybody waits: the call that holds the least gives up its turn?  It cannot — its buffers are in use.  The last resort is
-		// the one the library always had; report what is held so that the caller can lower its number of calls in flight.
-		return false;
-	}
+	if (!ok) return false;   // every call in flight waits here: nobody will end (the caller of ensure() reports and ends the process)
 	release_idle_locked(lk);
 	return true;
 }
@@ -728,22 +724,21 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	int64_t *off = (int64_t *)W.h_off.ensure((size_t)(n + 1) * 8 + 64);   // 16-byte aligned slot of every read in the packed buffer
 	int *lens = (int *)W.h_len.ensure((size_t)n * 4 + 64);
 	int max_len = 0;
-	int64_t total_bases = 0;
 	{   // lengths and a prefix sum over 667 000 records the caller has just written: by blocks, on all threads
 		const int BLK = 8192, nb = (n + BLK - 1) / BLK;
-		std::vector<int64_t> bsum(nb + 1, 0), bbases(nb, 0);
+		std::vector<int64_t> bsum(nb + 1, 0);
 		std::vector<int> bmax(nb, 0);
 		parallel_for(n_thr, nb, 1, [&](int b) {
 			const int lo = b * BLK, hi = std::min(n, lo + BLK);
-			int64_t sl = 0, tb = 0;
+			int64_t sl = 0;
 			int m = 0;
 			for (int i = lo; i < hi; ++i) {
 				const int l = seqs[i].l_seq;
-				lens[i] = l; sl += (l + 15) & ~15; tb += l; m = std::max(m, l);
+				lens[i] = l; sl += (l + 15) & ~15; m = std::max(m, l);
 			}
-			bsum[b + 1] = sl; bbases[b] = tb; bmax[b] = m;
+			bsum[b + 1] = sl; bmax[b] = m;
 		});
-		for (int b = 0; b < nb; ++b) { bsum[b + 1] += bsum[b]; total_bases += bbases[b]; max_len = std::max(max_len, bmax[b]); }
+		for (int b = 0; b < nb; ++b) { bsum[b + 1] += bsum[b]; max_len = std::max(max_len, bmax[b]); }
 		parallel_for(n_thr, nb, 1, [&](int b) {
 			const int lo = b * BLK, hi = std::min(n, lo + BLK);
 			int64_t o = bsum[b];
@@ -765,7 +760,6 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	HIP_OK(hipMemcpyAsync(d_off, off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
 	HIP_OK(hipMemcpyAsync(d_len, lens, (size_t)n * 4, hipMemcpyHostToDevice, st));
 	HIP_OK(hipStreamSynchronize(st));
-	unsigned long long *d_cnt = (unsigned long long *)W.cnt.ensure(256);
 	stage(23);
 	// contig table for the chaining kernel: start of every contig (+ l_pac) and its ALT flag
 	std::vector<int64_t> ann_off(bns->n_seqs + 1);
@@ -1452,7 +1446,6 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 	// alignments nor plans nor formats it (it only copies the two finished records out, or takes the pair back if the device
 	// hands a record back).
 	const uint8_t *pstat = nullptr;
-	const uint8_t *d_pstat = nullptr;
 	const AlnReq *d_pr_req = nullptr;
 	const SamDesc *d_pr_desc = nullptr;
 	double pair_dev_ms = 0;
@@ -1482,7 +1475,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			HIP_OK(hipMemcpyAsync(hs, d_status, (size_t)n_units, hipMemcpyDeviceToHost, st));
 			stream_wait(st);
 			HIP_OK(hipGetLastError());
-			pstat = hs; d_pstat = d_status; d_pr_req = d_rq; d_pr_desc = d_ds;
+			pstat = hs; d_pr_req = d_rq; d_pr_desc = d_ds;
 		}
 		pair_dev_ms = now_ms() - tp0;
 	}

@@ -5,11 +5,11 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc_kernels
 rm -rf $OUT; mkdir -p $OUT
-for k in smem_kernel smem_p3_kernel c2a_kernel msw_kernel aln_kernel pair_simple_kernel; do
+for k in ${PMC_KERNELS:-smem_kernel c2a_kernel msw2_kernel chain_heavy_kernel}; do
   i=0
   for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU"; do
     i=$((i+1))
-    timeout 400 rocprofv3 --pmc $set --kernel-include-regex "${k}[^_]" -d $OUT/${k}_$i --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --in-flight 1 --no-cpu-baseline > $OUT/${k}_$i.log 2>&1
+    timeout 400 rocprofv3 --pmc $set --kernel-include-regex "${k}[^_]" -d $OUT/${k}_$i --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --in-flight 1 --no-cpu-baseline --alt-legs "" --quick > $OUT/${k}_$i.log 2>&1
     echo "== $k set $i rc=$?"
   done
 done
@@ -32,7 +32,7 @@ for k, o in out.items():
         o["valu_active_frac_of_wave_cycles"] = round(o.get("SQ_ACTIVE_INST_VALU", 0) / o["SQ_WAVE_CYCLES"], 3)
     if o.get("SQ_WAVES"):
         o["valu_insts_per_wave"] = round(o.get("SQ_INSTS_VALU", 0) / o["SQ_WAVES"], 1)
-json.dump({"note": "two mem_process_seqs calls of 333 334 pairs (bench.py --steps 1 --warmup 0 --in-flight 1 + its single-call pass); "
+json.dump({"note": "four mem_process_seqs calls of 333 334 pairs on SURVEY 8d's config 1 (bench.py --steps 1 --warmup 1 --in-flight 1 --quick: three warm-up calls + the timed one); "
                    "SQ_* summed over all dispatches of the kernel, cycle counters in the units rocprofv3 reports",
            "kernels": out}, open(os.path.join(os.path.dirname(sys.argv[1]), "pmc_kernels.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
