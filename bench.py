@@ -124,7 +124,7 @@ def main():
             t_leg = time.perf_counter()
             leg = {"workload": spec, "command": " ".join(cmd[1:])}
             try:
-                r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=float(os.environ.get("MPIBWA_BENCH_LEG_TIMEOUT", "420")))
+                r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=float(os.environ.get("MPIBWA_BENCH_LEG_TIMEOUT", "300")))
                 lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
                 if lines:
                     d = json.loads(lines[-1])

@@ -11,7 +11,8 @@ from test_driver import EXE, mpiexec
 pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
 wd = "/tmp/mpibwa_bench"
 os.makedirs(wd, exist_ok=True)
-idx = bigindex.make_or_get(wd, genome_mbp=3100, seed=38, log=lambda *a: print(*a, flush=True))
+idx = bigindex.make_or_get(wd, genome_mbp=3100, seed=38, log=lambda *a: print(*a, flush=True),
+                           model=os.environ.get("MPIBWA_BENCH_GENOME_MODEL", "grch38like"), repeat_frac=float(os.environ.get("MPIBWA_BENCH_REPEAT_FRAC", "0.05")))
 eng = idx.engine
 r1, r2 = os.path.join(wd, "e2e_R1.fastq"), os.path.join(wd, "e2e_R2.fastq")
 with open(r1, "wb") as f1, open(r2, "wb") as f2:
