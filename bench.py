@@ -370,7 +370,11 @@ def main():
                 "launch_ms": round(acc["k_smem_ms"] / n_launch, 3), "algo_bytes_per_launch": int(acc["smem_bytes"] / n_launch),
                 "launches_per_step": round(n_launch / args.steps, 2),
                 # the same with the occ blocks left out that the third pass takes from its jump table instead of fetching
-                "frac_without_jump_table_blocks": round((acc["smem_bytes"] - tab) / (acc["k_smem_ms"] * 1e-3) / 1e9 / 8000.0, 4) if acc.get("k_smem_ms") else None}
+                "frac_without_jump_table_blocks": round((acc["smem_bytes"] - tab) / (acc["k_smem_ms"] * 1e-3) / 1e9 / 8000.0, 4) if acc.get("k_smem_ms") else None,
+                "note": "achieved = the REFERENCE's occ-block fetches for these reads (SURVEY 8d: 64 B per block bwt_extend touches + read + output, counted on "
+                        "the device by the counting variant of the kernel) / the production launches' duration; the production kernel takes results of up to 14 "
+                        "bases from k-mer tables and results of the third pass's first 12 steps from a jump table instead of fetching those blocks: the HBM bytes "
+                        "it really moves are `traffic` (PMC, ~0.46 x algorithmic)"}
     if alone.get("k_smem_ms") and alone.get("n_sub"):
         a1 = alone["smem_bytes"] / (alone["k_smem_ms"] * 1e-3) / 1e9
         roofline["one_call_in_flight"] = {"launch_ms": round(alone["k_smem_ms"] / alone["n_sub"], 3), "achieved": round(a1, 1),
