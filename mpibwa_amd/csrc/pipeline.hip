@@ -450,20 +450,22 @@ static std::condition_variable g_ctx_cv;
 static int g_admit = MAX_CALLS;             // (under g_ctx_mu)
 // What a call context holds in HBM once it has seen a chunk (the largest seen so far) — what a call that starts on a fresh context
 // will come to hold.  A call is only let in next to others when the HBM that is free, less what the calls in flight may still grow
-// by, covers that (+ the runtime's reserve); until a first call has ended nobody knows, and at most two run at once.  On references
+// by, covers that (+ the runtime's reserve); until a first call has ended nobody knows and a generous guess stands in.  On references
 // whose chunks need tens of GB per context (half the genome in repeats) this is what keeps eight callers from filling the HBM
 // together and then all waiting for each other.
 static size_t g_footprint = 0;              // (under g_ctx_mu)
-static bool room_for_another_call(const CallCtx *cand, int n_busy)
+static bool room_for_another_call(const CallCtx *cand, int n_busy, int n_reads)
 {
 	if (n_busy == 0) return true;
-	if (g_footprint == 0) return n_busy < 2;
+	// (before any call has ended: 64 KB per read of the chunk — what a chunk needs when half the reference is high-copy repeats, ten
+	// times what an ordinary one does: the first calls of a run start side by side as far as that fits, five on a 288-GB device)
+	const size_t foot = g_footprint ? g_footprint : (size_t)std::max(n_reads, 1) * 65536;
 	size_t fr = 0, tot = 0;
 	if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return true; }
 	size_t promised = 0;
 	for (int i = 0; i < MAX_CALLS; ++i)
-		if (g_ctx[i].busy && g_ctx[i].device_bytes() < g_footprint) promised += g_footprint - g_ctx[i].device_bytes();
-	const size_t have = cand->device_bytes(), need = (have < g_footprint ? g_footprint - have : 0) + ((size_t)8 << 30);
+		if (g_ctx[i].busy && g_ctx[i].device_bytes() < foot) promised += foot - g_ctx[i].device_bytes();
+	const size_t have = cand->device_bytes(), need = (have < foot ? foot - have : 0) + ((size_t)8 << 30);
 	return fr >= promised + need;
 }
 static int g_waiting_for_memory = 0;        // calls stuck in device_memory_pressure (under g_ctx_mu)
@@ -486,7 +488,7 @@ struct CtxLease {
 				for (int pass = 0; pass < 2 && !cand; ++pass)
 					for (int i = 0; i < MAX_CALLS && !cand; ++i)
 						if (!g_ctx[i].busy && (pass == 1 || g_ctx[i].device_bytes() > 0)) cand = &g_ctx[i];
-				if (cand && room_for_another_call(cand, n_busy)) { c = cand; c->busy = true; }
+				if (cand && room_for_another_call(cand, n_busy, n)) { c = cand; c->busy = true; }
 			}
 			if (c) break;
 			g_ctx_cv.wait_for(lk, std::chrono::milliseconds(20));   // (a call that ends wakes the waiters; so does memory given back without one ending)
