@@ -219,6 +219,14 @@ int  mi355x_rank_host_threads(int *ranks_on_node);
 /* device-computed checksums of the three resident index arrays (occ blocks, sampled SA, pac): mi355x_init compares every rank's
  * with rank 0's after its broadcast and ends the run on a difference; a host that broadcasts by other means does the same with this */
 int  mi355x_index_checksums(uint64_t out[3]);
+/* The first-use cost of `n_calls` call contexts (work buffers on the device and page-locked on the host, streams, the host thread
+ * pool, the kernels' code objects: 1-2 s per context otherwise paid by the first chunks of the loop the reference brackets with
+ * MPI_Wtime, src/mainParallel.c:1238-1319) paid now: n_calls mem_process_seqs calls side by side on n_reads reads of read_len
+ * bases sampled from the reference itself, text thrown away.  opt / bwt / bns / pac: what the chunk loop will pass.  A caller
+ * with other work left before its loop runs this on a thread of its own meanwhile.  n_calls is also taken as what the caller
+ * will keep in flight: with three or more, its calls run in their many-callers mode from the first one on (otherwise the library
+ * finds out by itself after two of them).  Returns the seconds it took. */
+double mi355x_prewarm(const mem_opt_t *opt, const bwt_t *bwt, const bntseq_t *bns, const uint8_t *pac, int n_reads, int read_len, int n_calls);
 /* seconds spent in the RCCL broadcast of the last mi355x_init (0 when none took place) */
 double mi355x_init_bcast_seconds(void);
 

@@ -18,7 +18,7 @@ EXPORTS = [
     "mi355x_index_upload", "mi355x_index_alloc", "mi355x_index_buffers", "mi355x_index_d2d", "mi355x_index_commit",
     "mi355x_finalize", "mi355x_index_build", "mi355x_index_build_gpu",
     "mi355x_smem_batch", "mi355x_sa_batch", "mi355x_sa_batch2", "mi355x_sa_dense_info", "mi355x_extend_batch", "mi355x_matesw_batch", "mi355x_chain_batch", "mi355x_pair_batch", "mi355x_pair_maxreg", "mi355x_fastq_scan", "mi355x_fastq_chunks", "mi355x_fastq_fill", "mi355x_last_stats", "mi355x_host_cpus", "mi355x_collect_sam", "mi355x_collect_sam_into", "mi355x_host_ksw_align2",
-    "bwa_set_rg", "bwa_insert_header", "bwa_idx2mem", "mi355x_write_map", "mi355x_init", "mi355x_rank_host_threads", "mi355x_index_checksums", "mi355x_init_bcast_seconds", "mi355x_global_batch", "mi355x_device_count", "mi355x_device_memory", "mi355x_buffer_growths",
+    "bwa_set_rg", "bwa_insert_header", "bwa_idx2mem", "mi355x_write_map", "mi355x_init", "mi355x_rank_host_threads", "mi355x_index_checksums", "mi355x_init_bcast_seconds", "mi355x_global_batch", "mi355x_device_count", "mi355x_device_memory", "mi355x_buffer_growths", "mi355x_prewarm",
 ]
 
 
@@ -205,6 +205,13 @@ class Engine:
         batch = abi.SeqBatch(libc, reads, with_qual=with_qual, comment=comment)
         self.lib.mem_process_seqs(opt, self.bwt, self.bns, self.pac, n_processed, batch.n, batch.arr, pes0)
         return batch.take_sam()
+
+    def prewarm(self, opt, n_reads, read_len=150, n_calls=1):
+        """First-use cost of n_calls call contexts paid now (include/mpibwa_amd.h: mi355x_prewarm); seconds it took."""
+        self.lib.mi355x_prewarm.restype = C.c_double
+        self.lib.mi355x_prewarm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        as_p = lambda x: C.cast(x, C.c_void_p)
+        return float(self.lib.mi355x_prewarm(as_p(opt), as_p(self.bwt), as_p(self.bns), as_p(self.pac), int(n_reads), int(read_len), int(n_calls)))
 
     def process_batch(self, opt, batch, n_processed=0, pes0=None):
         self.lib.mem_process_seqs(opt, self.bwt, self.bns, self.pac, n_processed, batch.n, batch.arr, pes0)

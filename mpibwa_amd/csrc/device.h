@@ -54,6 +54,7 @@ DevIndex &dev_index();
 bool index_matches(const bwt_t *bwt, const bntseq_t *bns, const char **what);
 // calls of mem_process_seqs currently inside the library (pipeline.hip); index upload / release need it to be 0
 int calls_in_flight();
+void expect_calls_in_flight(int n);   // pipeline.hip: how many calls the caller says it keeps in flight (mi355x_prewarm)
 // serialises "is the index resident / the right one, then count the call in" (mem_process_seqs) against upload and release
 std::recursive_mutex &index_mutex();
 void note_buffer_growth(size_t from, size_t to, const char *kind);   // counted by mi355x_buffer_growths()

@@ -250,7 +250,29 @@ static void parallel_blocks(int n_threads, int n, int chunk, F f)
 
 // MPIBWA_C2A_EARLY: 1 (default) the extension row loops stop early, 0 they run the reference's rows, 2 both with a fatal error on any difference
 static int c2a_early_mode() { const char *e = getenv("MPIBWA_C2A_EARLY"); return e ? atoi(e) : 1; }
-static std::mutex g_smem_turn, g_c2a_turn, g_pes_lock;
+// The turns on the big kernels are taken in the order of arrival.  With a plain mutex a caller whose thread had to be scheduled
+// first (more runnable threads than cores) kept losing the turn to callers that were already running: now and then a chunk that
+// takes 0.6 s took 3 s with eight callers, the others none the faster for it.
+class TurnLock {
+public:
+	void lock()
+	{
+		std::unique_lock<std::mutex> lk(m_);
+		const unsigned long long mine = next_++;
+		cv_.wait(lk, [&]() { return serving_ == mine; });
+	}
+	void unlock()
+	{
+		{ std::lock_guard<std::mutex> lk(m_); ++serving_; }
+		cv_.notify_all();
+	}
+private:
+	std::mutex m_;
+	std::condition_variable cv_;
+	unsigned long long next_ = 0, serving_ = 0;
+};
+static TurnLock g_smem_turn, g_c2a_turn;
+static std::mutex g_pes_lock;
 
 static double now_ms()
 {
@@ -435,9 +457,10 @@ struct CallCtx {
 	hipStream_t p_streams[MAX_LANES] = {nullptr}, a_streams[2] = {nullptr, nullptr}, d_streams[2] = {nullptr, nullptr};
 	bool busy = false;
 	const bseq1_t *seq_lo = nullptr, *seq_hi = nullptr;   // the caller's array while the call runs
+	int calls_done = 0;   // since its buffers were last given back (under g_ctx_mu)
 	struct Close { Close() { g_devbuf_owner = nullptr; } } close_;
 	size_t device_bytes() const { size_t b = 0; for (const DevBuf *d : bufs) b += d->cap; return b; }
-	void release_device() { for (DevBuf *d : bufs) d->release(); }
+	void release_device() { for (DevBuf *d : bufs) d->release(); calls_done = 0; }
 };
 static const int MAX_CALLS = 12;
 static CallCtx g_ctx[MAX_CALLS];
@@ -462,12 +485,20 @@ static bool room_for_another_call(const CallCtx *cand, int n_busy, int n_reads)
 	const size_t foot = g_footprint ? g_footprint : (size_t)std::max(n_reads, 1) * 65536;
 	size_t fr = 0, tot = 0;
 	if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return true; }
+	// (a context that has been through a call holds what a chunk needs, give or take; only the fresh ones still have their growth
+	// to come.  Counting the difference to the LARGEST context against every one of them kept callers at the door for seconds on a
+	// device whose contexts were all in place: eight of them, each a little smaller than the largest, "owed" more than was free)
 	size_t promised = 0;
 	for (int i = 0; i < MAX_CALLS; ++i)
-		if (g_ctx[i].busy && g_ctx[i].device_bytes() < foot) promised += foot - g_ctx[i].device_bytes();
-	const size_t have = cand->device_bytes(), need = (have < foot ? foot - have : 0) + ((size_t)8 << 30);
+		if (g_ctx[i].busy && g_ctx[i].calls_done == 0 && g_ctx[i].device_bytes() < foot) promised += foot - g_ctx[i].device_bytes();
+	const size_t have = cand->device_bytes(), need = (cand->calls_done == 0 && have < foot ? foot - have + ((size_t)8 << 30) : (size_t)1 << 30);
 	return fr >= promised + need;
 }
+// what the caller has said about itself (mi355x_prewarm's n_calls): with three or more calls kept in flight, the first calls of its
+// loop run in the busy mode too — they used to start as lone callers (two sub-batches, each waiting for its turns among the
+// others' kernels) and took 2-3 s instead of 0.6
+static std::atomic<int> g_expected_calls(0);
+void expect_calls_in_flight(int n) { g_expected_calls.store(n, std::memory_order_relaxed); }
 static int g_waiting_for_memory = 0;        // calls stuck in device_memory_pressure (under g_ctx_mu)
 static std::condition_variable g_mem_cv;    // a call has ended
 struct CtxLease {
@@ -478,6 +509,7 @@ struct CtxLease {
 	bool crowded = false;
 	CtxLease(const bseq1_t *seqs, int n)
 	{
+		const double t_door = now_ms();
 		std::unique_lock<std::mutex> lk(g_ctx_mu);
 		for (;;) {
 			int n_busy = 0;
@@ -502,8 +534,10 @@ struct CtxLease {
 		}
 		c->seq_lo = seqs; c->seq_hi = seqs + n;
 		const double now = now_ms();
+		static const bool door_log = getenv("MPIBWA_DOOR_LOG") != nullptr;   // calls that waited to be let in (admission by HBM head room)
+		if (door_log && now - t_door > 50.) fprintf(stderr, "[door] a call of %d reads waited %.0f ms to be admitted next to %d others\n", n, now - t_door, others);
 		if (others >= 2) last_crowded_ms() = now;
-		crowded = now - last_crowded_ms() < 2000.0;
+		crowded = now - last_crowded_ms() < 2000.0 || g_expected_calls.load(std::memory_order_relaxed) >= 3;
 	}
 	static double &last_crowded_ms() { static double t = -1e30; return t; }   // (under g_ctx_mu)
 	~CtxLease()
@@ -516,6 +550,7 @@ struct CtxLease {
 			for (int i = 0; i < MAX_CALLS; ++i) n_busy += g_ctx[i].busy ? 1 : 0;
 			if (n_busy >= 3) last_crowded_ms() = now_ms();
 			if (c->device_bytes() > g_footprint) g_footprint = c->device_bytes();
+			++c->calls_done;
 			c->busy = false; c->seq_lo = c->seq_hi = nullptr;
 		}
 		g_ctx_cv.notify_all();
@@ -932,7 +967,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			// the sub-batches (and the other calls in flight) take turns on the big kernels: each one fills the chip by itself, and running them one
 			// after the other staggers the sub-batches so that the host stages of one fall under the kernels of the other
 			stage(20);
-			std::unique_lock<std::mutex> turn(g_smem_turn, std::defer_lock);
+			std::unique_lock<TurnLock> turn(g_smem_turn, std::defer_lock);
 			if (take_turns) turn.lock();
 			stage(21);
 			ev_smem.start(st);
@@ -1246,7 +1281,7 @@ extern "C" void mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const b
 			memcpy(ep.mat, opt->mat, 25);
 			ep.o_del = opt->o_del; ep.e_del = opt->e_del; ep.o_ins = opt->o_ins; ep.e_ins = opt->e_ins; ep.zdrop = opt->zdrop;
 			stage(50);
-			std::unique_lock<std::mutex> turn(g_c2a_turn, std::defer_lock);
+			std::unique_lock<TurnLock> turn(g_c2a_turn, std::defer_lock);
 			if (take_turns) turn.lock();
 			stage(51);
 			ev_ext.start(st);

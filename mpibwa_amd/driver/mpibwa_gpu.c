@@ -1,6 +1,6 @@
 /* mpibwa_gpu.c — a thin MPI host program around the C ABI of libmpibwa_amd.so: one rank per GPU,
  *
- *     mpiexec -n N mpibwa_gpu mem [bwa mem options] [-K bases] [--in-flight chunks] [--dry-run] -o OUT PREFIX R1.fastq [R2.fastq]
+ *     mpiexec -n N mpibwa_gpu mem [bwa mem options] [-K bases] [--in-flight chunks] [--no-prewarm] [--dry-run] -o OUT PREFIX R1.fastq [R2.fastq]
  *
  * The `mem` options are the reference's (src/mainParallel.c:311-398: -k -w -A -B -O -E -L -U -T -c -d -r -D -m -s -G -N -W -y -X -h -Q -I -R -H
  * -P -a -M -S -Y -V -5 -q -j -C -v -t -K -o); -p, -x, -b, -g, -f and -z are not offered.
@@ -194,6 +194,29 @@ typedef struct {
 #define MPI_ENTER(L) do { if ((L)->serialize) pthread_mutex_lock(&(L)->mpi_mu); } while (0)
 #define MPI_LEAVE(L) do { if ((L)->serialize) pthread_mutex_unlock(&(L)->mpi_mu); } while (0)
 
+/* mi355x_prewarm on a thread of its own (no MPI inside) */
+typedef struct { const mem_opt_t *opt; bwaidx_t *idx; int n_reads, len, n_calls, started; double secs; } warm_t;
+static void *warm_main(void *arg)
+{
+	warm_t *w = arg;
+	w->secs = mi355x_prewarm(w->opt, w->idx->bwt, w->idx->bns, w->idx->pac, w->n_reads, w->len, w->n_calls);
+	return 0;
+}
+/* bases of the first record of a FASTQ file (0: not one) */
+static int first_read_len(const char *path)
+{
+	FILE *fp = fopen(path, "r");
+	if (!fp) return 0;
+	char *line = malloc(1 << 20);
+	int len = 0;
+	if (fgets(line, 1 << 20, fp) && line[0] == '@' && fgets(line, 1 << 20, fp)) {
+		len = (int)strcspn(line, "\r\n");
+	}
+	free(line);
+	fclose(fp);
+	return len;
+}
+
 /* a buffer a worker keeps from chunk to chunk (no allocation, no page faults per chunk) */
 static void *grown(void **p, size_t *cap, size_t need)
 {
@@ -278,13 +301,13 @@ int main(int argc, char **argv)
 	MPI_Init_thread(&argc, &argv, MPI_THREAD_MULTIPLE, &provided);
 	MPI_Comm_rank(MPI_COMM_WORLD, &g_rank);
 	MPI_Comm_size(MPI_COMM_WORLD, &g_size);
-	int n_threads = 0, copy_comment = 0, dry = 0, n_workers = 6;
+	int n_threads = 0, copy_comment = 0, dry = 0, n_workers = 6, prewarm = 1;
 	int scale_a = 0, set_b = 0, set_T = 0, set_U = 0, set_d = 0, set_O = 0, set_E = 0, set_L = 0;
 	int64_t K = 0;
 	const char *out_path = 0, *pos[4];
 	int n_pos = 0;
 	if (argc < 2 || strcmp(argv[1], "mem") != 0) {
-		if (g_rank == 0) fprintf(stderr, "usage: mpiexec -n N %s mem [bwa mem options] [-K bases] [--in-flight chunks] [--dry-run] -o OUT PREFIX R1.fastq [R2.fastq]\n", argv[0]);
+		if (g_rank == 0) fprintf(stderr, "usage: mpiexec -n N %s mem [bwa mem options] [-K bases] [--in-flight chunks] [--no-prewarm] [--dry-run] -o OUT PREFIX R1.fastq [R2.fastq]\n", argv[0]);
 		MPI_Finalize();
 		return 1;
 	}
@@ -297,6 +320,7 @@ int main(int argc, char **argv)
 	for (int i = 2; i < argc; ++i) {
 		const char *a = argv[i];
 		if (!strcmp(a, "--dry-run")) { dry = 1; continue; }
+		if (!strcmp(a, "--no-prewarm")) { prewarm = 0; continue; }
 		if (!strcmp(a, "--in-flight") && i + 1 < argc) { n_workers = atoi(argv[++i]); continue; }
 		if (a[0] != '-' || !a[1]) { if (n_pos < 3) pos[n_pos++] = a; continue; }
 		if (a[2]) DIE("unknown option %s (options take their value as the next argument)", a);
@@ -398,6 +422,69 @@ int main(int argc, char **argv)
 	if (n_threads > 0) opt->n_threads = n_threads;
 	if (paired) opt->flag |= MEM_F_PE;
 	if (K <= 0) K = (int64_t)opt->chunk_size * opt->n_threads;   /* src/mainParallel.c:635 */
+	if (provided < MPI_THREAD_SERIALIZED) n_workers = 1;
+	if (n_workers < 1) n_workers = 1;
+	if (n_workers > 12) n_workers = 12;   /* the library runs up to twelve calls side by side (fewer when their work buffers do not fit) */
+
+	/* The index goes first: while this thread reads the FASTQ offsets below, another one pays the first-use cost of the call
+	 * contexts (mi355x_prewarm: work buffers, streams, thread pool, code objects) on reads sampled from the reference, so that the
+	 * chunk loop starts at its steady rate.  --no-prewarm: the first chunk of every worker pays it, as before. */
+	bwaidx_t *idx = 0, idx_map;
+	pthread_t warm_th;
+	warm_t warm;
+	memset(&warm, 0, sizeof warm);
+	if (!dry) {
+		/* ---- index: host copy from the bwa files, device copy through mi355x_init ---- */
+		/* PREFIX.map present (mpiBWAIdx / mi355x_write_map): the ranks of a node share ONE host copy of the index — a private
+		 * file mapping whose bulk (BWT, SA, pac: read-only) stays in the page cache; only the pages bwa_mem2idx writes pointers
+		 * into become private (the reference maps the image into an MPI shared window, src/parallel_aux.c:1745-1838).
+		 * Otherwise every rank reads the five bwa files. */
+		{
+			char *mp = malloc(strlen(prefix) + 8);
+			sprintf(mp, "%s.map", prefix);
+			int fd = open(mp, O_RDONLY);
+			if (fd >= 0) {
+				struct stat sb;
+				if (fstat(fd, &sb) != 0) DIE("cannot stat %s", mp);
+				void *img = mmap(0, (size_t)sb.st_size, PROT_READ | PROT_WRITE, MAP_PRIVATE, fd, 0);
+				if (img == MAP_FAILED) DIE("cannot map %s", mp);
+				close(fd);
+				memset(&idx_map, 0, sizeof idx_map);
+				if (bwa_mem2idx((int64_t)sb.st_size, (uint8_t *)img, &idx_map) != 0) DIE("%s is not an index image", mp);
+				idx = &idx_map;
+				if (g_rank == 0) fprintf(stderr, "[mpibwa_gpu] index attached from %s (%.2f GB, shared by the ranks of a node)\n", mp, sb.st_size / 1e9);
+			} else idx = bwa_idx_load_from_disk(prefix, 7);
+			free(mp);
+		}
+		if (!idx) DIE("cannot load the index %s", prefix);
+		MPI_Comm node;
+		MPI_OK(MPI_Comm_split_type(MPI_COMM_WORLD, MPI_COMM_TYPE_SHARED, g_rank, MPI_INFO_NULL, &node));
+		int local_rank, local_size;
+		MPI_Comm_rank(node, &local_rank); MPI_Comm_size(node, &local_size);
+		const int n_dev = mi355x_device_count();
+		if (n_dev <= 0) DIE("no MI355X visible to rank %d", g_rank);
+		if (local_size <= n_dev && local_size > 1) {   /* one rank per GPU: one H2D on the node, RCCL broadcast to the other GPUs */
+			mi355x_comm_t comm = {local_rank, local_size, bcast_cb, &node};
+			mi355x_init(local_rank, idx, &comm);
+		} else mi355x_init(local_rank % n_dev, idx, 0);
+		if (ignore_alt)   /* -j (src/parallel_aux.c:1831-1833) */
+			for (int i = 0; i < idx->bns->n_seqs; ++i) idx->bns->anns[i].is_alt = 0;
+		if (g_rank != 0 && bwa_verbose > 1) bwa_verbose = 1;
+		if (prewarm) {
+			struct stat sb;
+			const int len = first_read_len(pos[1]);
+			if (len > 0 && stat(pos[1], &sb) == 0) {
+				/* reads of one chunk (both ends), and of this rank's share of the input: a record is at least 2 * len + 6 bytes */
+				const int64_t per_chunk = K / len + (paired ? 2 : 1), in_file = (int64_t)sb.st_size / (2 * len + 6) * (paired ? 2 : 1);
+				const int64_t mine = in_file / g_size;
+				warm.n_reads = (int)(per_chunk < mine ? per_chunk : mine);
+				warm.n_calls = (int)((mine + per_chunk - 1) / per_chunk);
+				if (warm.n_calls > n_workers) warm.n_calls = n_workers;
+				warm.len = len; warm.opt = opt; warm.idx = idx;
+				if (warm.n_reads >= 20000 && warm.n_calls >= 1 && pthread_create(&warm_th, 0, warm_main, &warm) == 0) warm.started = 1;
+			}
+		}
+	}
 
 	/* ---- partition ---- */
 	fq_t f1, f2;
@@ -460,44 +547,11 @@ int main(int argc, char **argv)
 		return 0;
 	}
 
-	/* ---- index: host copy from the bwa files, device copy through mi355x_init ---- */
-	/* PREFIX.map present (mpiBWAIdx / mi355x_write_map): the ranks of a node share ONE host copy of the index — a private
-	 * file mapping whose bulk (BWT, SA, pac: read-only) stays in the page cache; only the pages bwa_mem2idx writes pointers
-	 * into become private (the reference maps the image into an MPI shared window, src/parallel_aux.c:1745-1838).
-	 * Otherwise every rank reads the five bwa files. */
-	bwaidx_t *idx = 0, idx_map;
-	{
-		char *mp = malloc(strlen(prefix) + 8);
-		sprintf(mp, "%s.map", prefix);
-		int fd = open(mp, O_RDONLY);
-		if (fd >= 0) {
-			struct stat sb;
-			if (fstat(fd, &sb) != 0) DIE("cannot stat %s", mp);
-			void *img = mmap(0, (size_t)sb.st_size, PROT_READ | PROT_WRITE, MAP_PRIVATE, fd, 0);
-			if (img == MAP_FAILED) DIE("cannot map %s", mp);
-			close(fd);
-			memset(&idx_map, 0, sizeof idx_map);
-			if (bwa_mem2idx((int64_t)sb.st_size, (uint8_t *)img, &idx_map) != 0) DIE("%s is not an index image", mp);
-			idx = &idx_map;
-			if (g_rank == 0) fprintf(stderr, "[mpibwa_gpu] index attached from %s (%.2f GB, shared by the ranks of a node)\n", mp, sb.st_size / 1e9);
-		} else idx = bwa_idx_load_from_disk(prefix, 7);
-		free(mp);
-	}
-	if (!idx) DIE("cannot load the index %s", prefix);
-	MPI_Comm node;
-	MPI_OK(MPI_Comm_split_type(MPI_COMM_WORLD, MPI_COMM_TYPE_SHARED, g_rank, MPI_INFO_NULL, &node));
-	int local_rank, local_size;
-	MPI_Comm_rank(node, &local_rank); MPI_Comm_size(node, &local_size);
-	const int n_dev = mi355x_device_count();
-	if (n_dev <= 0) DIE("no MI355X visible to rank %d", g_rank);
-	if (local_size <= n_dev && local_size > 1) {   /* one rank per GPU: one H2D on the node, RCCL broadcast to the other GPUs */
-		mi355x_comm_t comm = {local_rank, local_size, bcast_cb, &node};
-		mi355x_init(local_rank, idx, &comm);
-	} else mi355x_init(local_rank % n_dev, idx, 0);
-	if (ignore_alt)   /* -j (src/parallel_aux.c:1831-1833) */
-		for (int i = 0; i < idx->bns->n_seqs; ++i) idx->bns->anns[i].is_alt = 0;
-	if (g_rank != 0 && bwa_verbose > 1) bwa_verbose = 1;
 
+	if (warm.started) {
+		pthread_join(warm_th, 0);
+		if (bwa_verbose >= 3) fprintf(stderr, "[mpibwa_gpu] rank %d: %d call contexts warmed on %d sampled reads each in %.2f s, beside the FASTQ scan\n", g_rank, warm.n_calls, warm.n_reads, warm.secs);
+	}
 	/* ---- output: rank 0 writes the header, then everybody appends through the shared file pointer ---- */
 	MPI_File out;
 	if (g_rank == 0) {
@@ -522,9 +576,6 @@ int main(int argc, char **argv)
 	if (g_rank == 0) *counter_mem = 0;
 	MPI_Barrier(MPI_COMM_WORLD);
 	const double t_loop = MPI_Wtime();
-	if (provided < MPI_THREAD_SERIALIZED) n_workers = 1;
-	if (n_workers < 1) n_workers = 1;
-	if (n_workers > 8) n_workers = 8;   /* the library runs eight calls side by side */
 	loop_t L;
 	memset(&L, 0, sizeof L);
 	L.opt = opt; L.idx = idx; L.win = win; L.out = out; L.f1 = f1.fh; L.f2 = paired ? f2.fh : MPI_FILE_NULL;
@@ -534,7 +585,7 @@ int main(int argc, char **argv)
 	pthread_mutex_init(&L.mpi_mu, 0);
 	pthread_mutex_init(&L.fetch_mu, 0);
 	pthread_mutex_init(&L.write_mu, 0);
-	pthread_t th[8];
+	pthread_t th[12];
 	for (int w = 1; w < n_workers; ++w)
 		if (pthread_create(&th[w], 0, chunk_worker, &L) != 0) DIE("cannot start worker thread %d", w);
 	chunk_worker(&L);

@@ -278,6 +278,25 @@ def test_work_buffers_stand_still_once_a_caller_is_warm(both, reads_pe, monkeypa
 
 
 @needs_ref
+def test_prewarm_is_an_ordinary_caller(both, reads_pe):
+    """mi355x_prewarm runs calls on reads sampled from the resident reference and throws their text away: it takes time, leaves
+    the per-thread statistics of a real call behind, changes nothing about what later calls return, and single-end / odd counts
+    / nothing to do are handled."""
+    eng, ref = both
+    ra = simulate.reads_to_ascii(reads_pe)
+    want = ref.process(ref.opt(flag=abi.MEM_F_PE), ra)
+    opt = eng.opt(flag=abi.MEM_F_PE)
+    secs = eng.prewarm(opt, 4001, read_len=150, n_calls=3)       # 4000 reads (whole pairs) x 3 calls side by side
+    assert secs > 0
+    assert eng.stats()["n_reads"] == 4000
+    assert eng.process(opt, ra) == want
+    assert eng.prewarm(eng.opt(), 1500, read_len=101, n_calls=1) > 0   # single end
+    assert eng.stats()["n_reads"] == 1500
+    assert eng.prewarm(opt, 0, read_len=150, n_calls=2) == 0
+    assert eng.process(opt, ra) == want
+
+
+@needs_ref
 def test_long_indels_take_the_wide_band_paths(both, genome):
     """Reads with insertions / deletions of 8 to 40 bp: their CIGARs need bands beyond the narrow direction matrix (the
     full-size variant of the CIGAR kernel, and the host for the few that outgrow that too).  Same bytes as the reference."""

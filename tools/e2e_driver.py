@@ -45,10 +45,11 @@ res = {"reads": 2 * pairs, "chunks": len(counts), "python_loop": {"in_flight": 4
 print("python loop: %.2f s" % py_s, flush=True)
 api.load_library().mi355x_finalize()          # the driver process brings its own copy of the index onto the GPU
 env = dict(os.environ); env.pop("LD_LIBRARY_PATH", None); env["MPIBWA_DRV_PROF"] = "1"
-for P in [int(x) for x in os.environ.get("E2E_P", "1,4,8").split(",")]:
+for item in os.environ.get("E2E_P", "1,4,8").split(","):   # "8": eight chunks in flight; "8n": the same with --no-prewarm
+    P, extra = int(item.rstrip("n")), (["--no-prewarm"] if item.endswith("n") else [])
     o = os.path.join(wd, "e2e_drv.sam")
     t0 = time.time()
-    r = subprocess.run([mpiexec(), "-n", "1", EXE, "mem", "-t", str(cores), "-K", "100000000", "--in-flight", str(P), "-o", o, idx.prefix, r1, r2],
+    r = subprocess.run([mpiexec(), "-n", "1", EXE, "mem", "-t", str(cores), "-K", "100000000", "--in-flight", str(P)] + extra + ["-o", o, idx.prefix, r1, r2],
                        capture_output=True, text=True, env=env, timeout=1500)
     wall = time.time() - t0
     m = re.search(r"chunk loop: (\d+) reads in (\d+) chunks.* ([\d.]+) s = ([\d.]+) Mreads/s", r.stderr)
@@ -57,11 +58,13 @@ for P in [int(x) for x in os.environ.get("E2E_P", "1,4,8").split(",")]:
     if len(done) > 2 * P:   # the rate once every worker has its buffers and its call context: chunks finishing after the first P
         steady = round((len(done) - P) * (2 * pairs / len(done)) / (done[-1] - done[P - 1]) / 1e6, 3)
     if os.environ.get("E2E_SHOW"):
-        print("\n".join(l for l in r.stderr.splitlines() if "chunk " in l), flush=True)
+        print("\n".join(l for l in r.stderr.splitlines() if "chunk " in l or "warmed" in l), flush=True)
+    wm = re.search(r"(\d+) call contexts warmed on (\d+) sampled reads each in ([\d.]+) s", r.stderr)
     if r.returncode != 0 or not m:
         print(r.stderr[-3000:]); raise SystemExit("driver failed")
     md5, nl = body_md5(o)
-    res["driver"].append({"P": P, "chunk_loop_s": float(m.group(3)), "Mreads_per_s": float(m.group(4)), "process_wall_s": round(wall, 2), "Mreads_per_s_after_first_P_chunks": steady,
+    res["driver"].append({"P": P, "args": extra, "chunk_loop_s": float(m.group(3)), "Mreads_per_s": float(m.group(4)), "process_wall_s": round(wall, 2), "Mreads_per_s_after_first_P_chunks": steady,
+                          "prewarm": {"contexts": int(wm.group(1)), "reads_each": int(wm.group(2)), "seconds_beside_the_fastq_scan": float(wm.group(3))} if wm else None,
                           "same_records_as_python_loop": md5 == want})
     print(res["driver"][-1], flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
