@@ -177,50 +177,50 @@ int mark_primary_se(const mem_opt_t *opt, HRegV &v, int64_t id)
 	return n_pri;
 }
 
+// Single-end mapping quality of a hit from its score, the best competing score and how much of it its seeds cover.  The
+// double-precision expressions are the reference's, operation for operation (src/bwamem.c:952-975): a product evaluated in another
+// order rounds differently and moves a MAPQ by one.
 int approx_mapq_se(const mem_opt_t *opt, const HReg *a)
 {
-	int mapq, l, sub = a->sub ? a->sub : opt->min_seed_len * opt->a;
-	double identity;
-	sub = a->csub > sub ? a->csub : sub;
-	if (sub >= a->score) return 0;
-	l = a->qe - a->qb > a->re - a->rb ? a->qe - a->qb : (int)(a->re - a->rb);
-	identity = 1. - (double)(l * opt->a - a->score) / (opt->a + opt->b) / l;
-	if (a->score == 0) mapq = 0;
-	else if (opt->mapQ_coef_len > 0) {
-		double tmp = l < opt->mapQ_coef_len ? 1. : opt->mapQ_coef_fac / log(l);
-		tmp *= identity * identity;
-		mapq = (int)(6.02 * (a->score - sub) / opt->a * tmp * tmp + .499);
-	} else {
-		mapq = (int)(30.0 * (1. - (double)sub / a->score) * log(a->seedcov) + .499);
-		mapq = identity < 0.95 ? (int)(mapq * identity * identity + .499) : mapq;
+	// the competitor: the best overlapping hit, at least a minimal seed's worth, or the best other chain of the same region
+	int rival = a->sub ? a->sub : opt->min_seed_len * opt->a;
+	if (a->csub > rival) rival = a->csub;
+	if (rival >= a->score) return 0;
+	const int q_span = a->qe - a->qb, r_span = (int)(a->re - a->rb);
+	const int span = q_span > r_span ? q_span : r_span;
+	const double identity = 1. - (double)(span * opt->a - a->score) / (opt->a + opt->b) / span;
+	int q = 0;
+	if (a->score != 0) {
+		if (opt->mapQ_coef_len > 0) {   // -Q: the length-scaled form
+			double f = span < opt->mapQ_coef_len ? 1. : opt->mapQ_coef_fac / log(span);
+			f *= identity * identity;
+			q = (int)(6.02 * (a->score - rival) / opt->a * f * f + .499);
+		} else {
+			q = (int)(30.0 * (1. - (double)rival / a->score) * log(a->seedcov) + .499);
+			if (identity < 0.95) q = (int)(q * identity * identity + .499);
+		}
 	}
-	if (a->sub_n > 0) mapq -= (int)(4.343 * log(a->sub_n + 1) + .499);
-	if (mapq > 60) mapq = 60;
-	if (mapq < 0) mapq = 0;
-	mapq = (int)(mapq * (1. - a->frac_rep) + .499);
-	return mapq;
+	if (a->sub_n > 0) q -= (int)(4.343 * log(a->sub_n + 1) + .499);   // many equally good competitors
+	q = q > 60 ? 60 : q < 0 ? 0 : q;
+	return (int)(q * (1. - a->frac_rep) + .499);                       // seeds in repeats count for less
 }
 
+// -5: of the primary hits worth reporting (not ALT, score >= T) the one that starts first in the read becomes a[0]; every
+// `secondary` link that named one of the two exchanged slots follows it (src/bwamem.c:977-1001).
 void reorder_primary5(int T, HRegV &a)
 {
-	int n = (int)a.size(), n_pri = 0, left_st = INT_MAX, left_k = -1;
-	for (int k = 0; k < n; ++k)
-		if (a[k].secondary < 0 && !a[k].is_alt && a[k].score >= T) ++n_pri;
-	if (n_pri <= 1) return;
+	const int n = (int)a.size();
+	auto reportable_primary = [&](const HReg &r) { return r.secondary < 0 && !r.is_alt && r.score >= T; };
+	int count = 0, first = -1;
 	for (int k = 0; k < n; ++k) {
-		HReg *p = &a[k];
-		if (p->secondary >= 0 || p->is_alt || p->score < T) continue;
-		if (p->qb < left_st) { left_st = p->qb; left_k = k; }
+		if (!reportable_primary(a[k])) continue;
+		++count;
+		if (first < 0 || a[k].qb < a[first].qb) first = k;   // the earliest of equal starts stays
 	}
-	if (left_k == 0) return;
-	std::swap(a[0], a[left_k]);
-	for (int k = 1; k < n; ++k) {
-		HReg *p = &a[k];
-		if (p->secondary == 0) p->secondary = left_k;
-		else if (p->secondary == left_k) p->secondary = 0;
-		if (p->secondary_all == 0) p->secondary_all = left_k;
-		else if (p->secondary_all == left_k) p->secondary_all = 0;
-	}
+	if (count <= 1 || first == 0) return;
+	std::swap(a[0], a[first]);
+	auto relink = [&](int &link) { if (link == 0) link = first; else if (link == first) link = 0; };
+	for (int k = 1; k < n; ++k) { relink(a[k].secondary); relink(a[k].secondary_all); }
 }
 
 // ---------------------------------------------------------------------------
