@@ -108,3 +108,21 @@ def test_driver_takes_the_reference_mem_options(example):
     os.remove(prefix + ".map")
     assert r.returncode == 0 and "index attached from" in r.stderr, r.stderr[-2000:]
     assert sorted(_body(out2)) == sorted(want.splitlines(keepends=True))
+
+
+@pytest.mark.skipif(mpiexec() is None or not os.path.exists(EXE), reason="mpibwa_gpu or mpiexec not present")
+def test_driver_warms_its_call_contexts_beside_the_fastq_scan(example):
+    """One rank, the 20 036 reads of the example as one chunk: the driver loads the index first and warms a call context on as many
+    sampled reads while it reads the FASTQ offsets (mi355x_prewarm; it says so on stderr; inputs under 20 000 reads per chunk are
+    not worth it); --no-prewarm does not; the records are the same either way, and the real mpiBWA's."""
+    d, prefix, fq = example
+    env = dict(os.environ); env.pop("LD_LIBRARY_PATH", None)
+    outs = []
+    for extra in ([], ["--no-prewarm"]):
+        out = os.path.join(d, "warm%d.sam" % len(extra))
+        r = subprocess.run([mpiexec(), "-n", "1", EXE, "mem", "-t", "8", "--in-flight", "8"] + extra + ["-o", out, prefix] + fq,
+                           capture_output=True, text=True, timeout=900, env=env, cwd=d)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert ("call contexts warmed" in r.stderr) == (not extra), r.stderr[-3000:]
+        outs.append(_body(out))
+    assert outs[0] == outs[1] and hashlib.md5(b"".join(outs[0])).hexdigest() == KNOWN_MD5
