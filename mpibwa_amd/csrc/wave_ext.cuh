@@ -56,16 +56,17 @@ struct WxParams {
 
 struct WxResult { int score, qle, tle, gtle, gscore, max_off; };
 
-// LDS of one wave: H and E (qlen + 2 cells, and a strip of pad so that the lanes of a row read and write a full strip without
-// bounds tests), the query bases (staged by the caller: one byte per column, + pad), and one write-only cell.
-struct WxLds { int *H, *E; uint8_t *Qs; int *dummy; };
-__host__ __device__ inline int wx_lds_ints(int max_qlen) { return 2 * (max_qlen + 2 + 64) + ((max_qlen + 64 + 3) >> 2) + 1; }
+// LDS of one wave: the row state eh[] as {h, e} pairs like the reference's eh_t — one 8-byte load and one 8-byte store per lane
+// and strip (qlen + 2 cells, and a strip of pad so that the lanes of a row read and write a full strip without bounds tests),
+// the query bases (staged by the caller: one byte per column, + pad), and one write-only cell.
+struct WxLds { int2 *HE; uint8_t *Qs; int2 *dummy; };
+__host__ __device__ inline int wx_lds_ints(int max_qlen) { return 2 * (max_qlen + 2 + 64) + (((max_qlen + 64 + 7) & ~7) >> 2) + 2; }   // (even: waves stay 8-byte aligned)
 __device__ __forceinline__ WxLds wx_lds(int *base, int max_qlen)
 {
 	WxLds L;
-	L.H = base; L.E = L.H + (max_qlen + 2 + 64);
-	L.Qs = (uint8_t *)(L.E + (max_qlen + 2 + 64));
-	L.dummy = (int *)(L.Qs + ((max_qlen + 64 + 3) & ~3));
+	L.HE = (int2 *)base;
+	L.Qs = (uint8_t *)(L.HE + (max_qlen + 2 + 64));
+	L.dummy = (int2 *)(L.Qs + ((max_qlen + 64 + 7) & ~7));
 	return L;
 }
 
@@ -100,7 +101,7 @@ __device__ __forceinline__ WxResult wave_extend(int qlen, int tlen, TF tf, const
                                                 unsigned long long &cells, int max_sc = 1, int clip = 0x3fffffff)
 {
 	const int lane = threadIdx.x & 63;
-	int *const H = L.H, *const E = L.E;
+	int2 *const HE = L.HE;
 	const uint8_t *const Qs = L.Qs;
 	// The extension's shape is the same in every lane, but it was read through vector loads: pin it to scalar registers,
 	// or the row loop's whole bookkeeping (band limits, live range, strip counts, loop tests) is compiled into vector
@@ -123,7 +124,7 @@ __device__ __forceinline__ WxResult wave_extend(int qlen, int tlen, TF tf, const
 			if (j == 1) v = h1;
 			else v = (h1 - (j - 2) * e_ins > e_ins) ? t : 0;
 		}
-		H[j] = v; E[j] = 0;
+		HE[j] = make_int2(v, 0);
 	}
 	__builtin_amdgcn_wave_barrier();
 	int best = h0, best_i = -1, best_j = -1, best_ie = -1, gscore = -1, max_off = 0;
@@ -155,18 +156,25 @@ __device__ __forceinline__ WxResult wave_extend(int qlen, int tlen, TF tf, const
 		const int n_col = end - beg;               // negative: the band has moved past the live cells, the row is empty
 		int lanekey = -1;                          // (h << 13 | column), per lane over the strips of the row
 		int A = beg * e_ins;                       // F(i,beg) = 0
-		int h_carry = hleft0, h_last = hleft0;     // h of the column before the strip; h of the row's last column
+		int h_carry = hleft0, h_cin = hleft0;      // h of the column before the strip (h_cin: before the row's last strip)
+		int h_strip = 0;                           // the h of the row's last strip, a column per lane
 		int first_nz = end, last_nz = -1;          // first / last cell of [beg,end] with H or E non-zero after the row
+		const int jb = beg + lane;
 		for (int s0 = 0; s0 <= n_col; s0 += 64) {
-			const int j = beg + s0 + lane;
-			const bool act = s0 + lane < n_col, wr = s0 + lane <= n_col;
-			const int diag = H[j], e = E[j];
-			const int qraw = (int)Qs[j];
-			const int qb = act ? qraw : 4;
-			const int sc = (int)(int8_t)__builtin_amdgcn_perm(shi, slo, (uint32_t)qb | 0x0c0c0c00u);
+			const int j = jb + s0;
+			const bool act = j < end, wr = j <= end;
+			// The lanes past the row's last column (they only exist in the row's LAST strip, to the right of every live lane) run on
+			// whatever the pad holds (stale cells of earlier rows, any byte for a base): M, h and e' are forced to 0 for them — e' has to
+			// be a real 0 in the one lane behind the last column (eh[end].e, src/ksw.c:447) — their g = j * e_ins is never seen by a live
+			// lane (the scans run left to right; A and h_carry are only read off lanes that are live when they matter), and
+			// their key (0 << 13 | j) can only win when every live h is 0: then the row maximum is 0 and the loop ends before anybody
+			// looks at the column.
+			const int2 he = HE[j];
+			const int diag = he.x, e = he.y;
+			const int sc = (int)(int8_t)__builtin_amdgcn_perm(shi, slo, (uint32_t)Qs[j] | 0x0c0c0c00u);
 			const int M = (act && diag) ? diag + sc : 0;
 			int tI = M - oe_ins; tI = tI > 0 ? tI : 0;
-			const int g = act ? tI + j * e_ins : WX_NEG;
+			const int g = tI + j * e_ins;
 			const int incl = wx_scan_max(g);
 			const int excl = wx_prev_lane(incl, WX_NEG);
 			const int f = max(A, excl + e_ins) - j * e_ins;
@@ -174,26 +182,28 @@ __device__ __forceinline__ WxResult wave_extend(int qlen, int tlen, TF tf, const
 			int tD = M - oe_del; tD = tD > 0 ? tD : 0;
 			const int en = act ? max(e - e_del, tD) : 0;
 			const int h_prev = wx_prev_lane(h, h_carry);
-			(wr ? H + j : L.dummy)[0] = h_prev;
-			(wr ? E + j : L.dummy)[0] = en;
+			*(wr ? HE + j : L.dummy) = make_int2(h_prev, en);
 			A = max(A, __builtin_amdgcn_readlane(incl, 63) + e_ins);
-			lanekey = max(lanekey, act ? (h << 13 | j) : -1);   // the largest column wins ties
-			const unsigned long long nz = __ballot(wr && (h_prev | en) != 0);
+			lanekey = max(lanekey, h << 13 | j);   // the largest column wins ties
+			// (behind the lane that writes eh[end], h_prev and e' are 0 by the masks above: no test for "a lane that writes")
+			const unsigned long long nz = __builtin_amdgcn_ballot_w64((h_prev | en) != 0);
 			if (nz) {
 				const int lo = beg + s0 + __ffsll((long long)nz) - 1, hi = beg + s0 + 63 - __clzll(nz);
 				if (lo < end && lo < first_nz) first_nz = lo;
 				if (hi > last_nz) last_nz = hi;
 			}
+			h_cin = h_carry;
 			h_carry = __builtin_amdgcn_readlane(h, 63);
-			const int last = n_col - 1 - s0;       // the row's last column sits in this strip
-			if (last >= 0 && last < 64) h_last = __builtin_amdgcn_readlane(h, last);
+			h_strip = h;
 		}
+		// h of the row's last column: in the last strip when that has live lanes, else what was carried into it (also: an empty row)
+		const int h_last = (n_col > 0 && (n_col & 63)) ? __builtin_amdgcn_readlane(h_strip, (n_col - 1) & 63) : n_col > 0 ? h_cin : hleft0;
 		int rowkey = -1;
 		if (n_col > 0) {
 			rowkey = __builtin_amdgcn_readlane(wx_scan_max(lanekey), 63);
 			cells += (unsigned long long)n_col;
 		} else if (n_col < 0) {
-			if (lane == 0) { H[end] = hleft0; E[end] = 0; }   // src/ksw.c:447 with an empty range (the loop ends below: m == 0)
+			if (lane == 0) HE[end] = make_int2(hleft0, 0);   // src/ksw.c:447 with an empty range (the loop ends below: m == 0)
 		}
 		__builtin_amdgcn_wave_barrier();
 		const int jfin = n_col > 0 ? end : beg;    // value of the reference's column counter after its loop
@@ -222,8 +232,9 @@ __device__ __forceinline__ WxResult wave_extend(int qlen, int tlen, TF tf, const
 		if (EARLY && (i & 3) == 3 && (gscore >= 0 || rowmax + (qlen - 1 - rowmax_j) * max_sc <= best - clip)) {
 			int b = WX_NEG;
 			for (int j = lane; j <= qlen; j += 64) {
-				const int hv = j < qlen ? H[j] + (qlen - j) * max_sc : WX_NEG;
-				const int ev = E[j] + (qlen - 1 - j) * max_sc;
+				const int2 he = HE[j];
+				const int hv = j < qlen ? he.x + (qlen - j) * max_sc : WX_NEG;
+				const int ev = he.y + (qlen - 1 - j) * max_sc;
 				b = max(b, max(hv, ev));
 			}
 			b = __builtin_amdgcn_readlane(wx_scan_max(b), 63);
