@@ -35,6 +35,7 @@
 // wave touch 64 consecutive dwords (no bank conflicts) and the whole DP runs out of LDS and registers.  HBM traffic is the
 // target window (2 bits per row) and one u16 per row for the b[] pass.  The work is VALU-bound: ~30 integer ops per cell.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "device.h"
 
 namespace mbw {
@@ -252,6 +253,12 @@ __device__ __forceinline__ msw_s2 s2_of(uint32_t v) { return __builtin_bit_cast(
 __device__ __forceinline__ uint32_t u_of(msw_s2 v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ msw_s2 s2_max(msw_s2 a, msw_s2 b) { return __builtin_elementwise_max(a, b); }
 __device__ __forceinline__ msw_s2 s2_splat(int v) { msw_s2 r; r.x = (short)v; r.y = (short)v; return r; }
+typedef unsigned short msw_u2 __attribute__((ext_vector_type(2)));
+// max(a - b, 0) per half for values that are never negative: v_pk_sub_u16 with the clamp bit, no separate maximum with 0
+__device__ __forceinline__ msw_s2 s2_sub0(msw_s2 a, msw_s2 b)
+{
+	return __builtin_bit_cast(msw_s2, __builtin_elementwise_sub_sat(__builtin_bit_cast(msw_u2, a), __builtin_bit_cast(msw_u2, b)));
+}
 
 __global__ __launch_bounds__(64) void msw2_kernel(MswParams P, int n_pairs, int n_req, const int *__restrict__ pairs, const MswReq *__restrict__ req,
                                                   const uint8_t *__restrict__ seq, const int64_t *__restrict__ off, const int *__restrict__ lens,
@@ -296,9 +303,20 @@ __global__ __launch_bounds__(64) void msw2_kernel(MswParams P, int n_pairs, int 
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 	const int sat_limit = 255 - P.shift;
+	// the segment length when every live quad of the wave has the same one (else 0: the flags in the codes decide)
+	int slen_u = 0;
+	{
+		const unsigned long long lv = __builtin_amdgcn_ballot_w64(live);
+		if (lv) {
+			const int first = __builtin_amdgcn_readlane(slen, __ffsll((long long)lv) - 1);
+			slen_u = __builtin_amdgcn_ballot_w64(live && slen != first) ? 0 : first;
+		}
+	}
 	// ---- the forward pass of both ----
 	int gmaxA = 0, teA = -1, qeA = -1, gmaxB = 0, teB = -1, qeB = -1, satA = 0, satB = 0;
-	{
+	// (two copies of the pass — segment ends known to the scalar unit, or read from the codes — so that neither has a branch per cell)
+	auto forward = [&](auto uniform_segments) {
+		constexpr bool UNI = decltype(uniform_segments)::value;
 		const int tn = tnA > tnB ? tnA : tnB;
 		bool run = live && tn > 0 && S > 0;
 		const msw_s2 oe_del = s2_splat(P.o_del + P.e_del), oe_ins = s2_splat(P.o_ins + P.e_ins), e_del = s2_splat(P.e_del), e_ins = s2_splat(P.e_ins);
@@ -325,32 +343,42 @@ __global__ __launch_bounds__(64) void msw2_kernel(MswParams P, int n_pairs, int 
 			uint32_t keyA = j ? ci_keyA : 0u, keyB = j ? ci_keyB : 0u;
 			const int kbase = j * S;
 			const int kmax = act ? S : 0;
-			auto step = [&](uint32_t &w, int kk, uint32_t cd, int u) {
+			// (H, E and both F are never negative and h = Hpre is not either: "max(x - c, 0)" is one saturating subtraction.  seg_end: the
+			// end of a segment as a wave-uniform fact — slen_u > 0: every live quad of the wave has that segment length, which is the rule
+			// (the reads of a chunk are of one length) — or bit 3 of the position's code)
+			auto step = [&](uint32_t &w, int kk, uint32_t cd, int u, bool seg_end) {
 				const msw_s2 hd = s2_of(__builtin_amdgcn_perm(0u, w, 0x0c020c00u));   // H_A | H_B << 16   (row i - 1)
 				msw_s2 e = s2_of(__builtin_amdgcn_perm(0u, w, 0x0c030c01u));          // E_A | E_B << 16
 				const uint32_t q = __builtin_amdgcn_ubfe(cd, 4 * u, 3);
-				const int m = __builtin_amdgcn_sbfe((int)cd, 4 * u + 3, 1);           // -1 at the last position of a segment
 				const msw_s2 s = s2_of(srow[q]);
 				const msw_s2 h = s2_max(s2_max(diag + s, e), fseg);                    // Hpre(i, k) of both
 				const uint32_t posc = (uint32_t)(0xffff - (kbase + kk));
 				keyA = max(keyA, u_of(h) << 16 | posc);
 				keyB = max(keyB, (u_of(h) & 0xffff0000u) | posc);
 				const msw_s2 hfin = s2_max(h, ffull);
-				e = s2_max(s2_max(e - e_del, h - oe_del), zero);
-				const msw_s2 t2 = h - oe_ins;
-				fseg = s2_of(u_of(s2_max(s2_max(fseg - e_ins, t2), zero)) & ~(uint32_t)m);
-				ffull = s2_max(s2_max(ffull - e_ins, t2), zero);
+				e = s2_max(s2_sub0(e, e_del), s2_sub0(h, oe_del));
+				const msw_s2 t2 = s2_sub0(h, oe_ins);
+				fseg = s2_max(s2_sub0(fseg, e_ins), t2);
+				if constexpr (UNI) fseg = seg_end ? zero : fseg;
+				else fseg = s2_of(u_of(fseg) & ~(uint32_t)__builtin_amdgcn_sbfe((int)cd, 4 * u + 3, 1));   // -1 at the last position of a segment
+				ffull = s2_max(s2_sub0(ffull, e_ins), t2);
 				diag = hd;
 				w = __builtin_amdgcn_perm(u_of(e), u_of(hfin), 0x06020400u);            // bytes: H_A, E_A, H_B, E_B
 			};
+			int seg_pos = 0;   // position inside the segment (a lane's quarter is four whole segments: the same in every lane)
 			for (int c = 0; c * 8 < Swave; ++c) {
 				const uint32_t cd = c * 8 < kmax ? codes[c * 64 + lane] : 0u;
 #pragma unroll
 				for (int u = 0; u < 8; u += 2) {
 					const int k = c * 8 + u;
+					bool end0 = false, end1 = false;
+					if constexpr (UNI) {
+						end0 = ++seg_pos == slen_u; if (end0) seg_pos = 0;
+						end1 = ++seg_pos == slen_u; if (end1) seg_pos = 0;
+					}
 					if (k < kmax) {
 						uint32_t w0 = cell[k * 64 + lane], w1 = cell[(k + 1) * 64 + lane];
-						step(w0, k, cd, u); step(w1, k + 1, cd, u + 1);
+						step(w0, k, cd, u, end0); step(w1, k + 1, cd, u + 1, end1);
 						cell[k * 64 + lane] = w0; cell[(k + 1) * 64 + lane] = w1;
 					}
 				}
@@ -373,7 +401,8 @@ __global__ __launch_bounds__(64) void msw2_kernel(MswParams P, int n_pairs, int 
 			stop = msw_dpp<MSW_QP(3, 3, 3, 3)>(stop);
 			if (stop) run = false;
 		}
-	}
+	};
+	if (slen_u > 0) forward(std::true_type{}); else forward(std::false_type{});
 	MswPassOut fA, fB;
 	fA.score = msw_dpp<MSW_QP(3, 3, 3, 3)>(gmaxA); fA.te = msw_dpp<MSW_QP(3, 3, 3, 3)>(teA); fA.qe = msw_dpp<MSW_QP(3, 3, 3, 3)>(qeA);
 	fB.score = msw_dpp<MSW_QP(3, 3, 3, 3)>(gmaxB); fB.te = msw_dpp<MSW_QP(3, 3, 3, 3)>(teB); fB.qe = msw_dpp<MSW_QP(3, 3, 3, 3)>(qeB);
