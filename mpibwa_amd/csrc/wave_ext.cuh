@@ -43,6 +43,13 @@ __device__ __forceinline__ int wx_scan_max(int v)
 	             : "+v"(v));
 	return v;
 }
+// minimum of two wave-uniform values on the scalar unit
+__device__ __forceinline__ int wx_smin(int a, int b)
+{
+	int r;
+	asm("s_min_i32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b) : "scc");
+	return r;
+}
 // value of the previous lane (lane 0 gets `first`)
 __device__ __forceinline__ int wx_prev_lane(int v, int first)
 {
@@ -113,6 +120,8 @@ __device__ __forceinline__ WxResult wave_extend(int qlen, int tlen, TF tf, const
 	max_sc = __builtin_amdgcn_readfirstlane(max_sc);
 	clip = __builtin_amdgcn_readfirstlane(clip);
 	const int oe_del = P.o_del + P.e_del, oe_ins = P.o_ins + P.e_ins, e_del = P.e_del, e_ins = P.e_ins;
+	int lane_e = lane * e_ins;
+	asm volatile("" : "+v"(lane_e));   // (opaque: or the compiler folds it back into a multiplication per row, two in fact: +j e and -j e)
 	// first row (src/ksw.c:389-393)
 	for (int j = lane; j <= qlen; j += 64) {
 		int v = 0;
@@ -149,8 +158,7 @@ __device__ __forceinline__ WxResult wave_extend(int qlen, int tlen, TF tf, const
 		}
 		const uint32_t slo = (uint32_t)__builtin_amdgcn_readlane(vslo, i - tv_base), shi = (uint32_t)__builtin_amdgcn_readlane(vshi, i - tv_base);
 		if (beg < i - w) beg = i - w;
-		if (end > i + w + 1) end = i + w + 1;
-		if (end > qlen) end = qlen;
+		end = wx_smin(wx_smin(end, i + w + 1), qlen);   // (left to itself the compiler does this three-way minimum on the vector unit and reads it back)
 		int hleft0 = 0;
 		if (beg == 0) { hleft0 = h0 - (P.o_del + e_del * (i + 1)); if (hleft0 < 0) hleft0 = 0; }
 		const int n_col = end - beg;               // negative: the band has moved past the live cells, the row is empty
@@ -160,7 +168,8 @@ __device__ __forceinline__ WxResult wave_extend(int qlen, int tlen, TF tf, const
 		int h_strip = 0;                           // the h of the row's last strip, a column per lane
 		int first_nz = end, last_nz = -1;          // first / last cell of [beg,end] with H or E non-zero after the row
 		const int jb = beg + lane;
-		for (int s0 = 0; s0 <= n_col; s0 += 64) {
+		int je = lane_e + beg * e_ins;             // j * e_ins of the strip in hand (a multiplication per lane and row costs four additions' time)
+		for (int s0 = 0; s0 <= n_col; s0 += 64, je += 64 * e_ins) {
 			const int j = jb + s0;
 			const bool act = j < end, wr = j <= end;
 			// The lanes past the row's last column (they only exist in the row's LAST strip, to the right of every live lane) run on
@@ -174,10 +183,10 @@ __device__ __forceinline__ WxResult wave_extend(int qlen, int tlen, TF tf, const
 			const int sc = (int)(int8_t)__builtin_amdgcn_perm(shi, slo, (uint32_t)Qs[j] | 0x0c0c0c00u);
 			const int M = (act && diag) ? diag + sc : 0;
 			int tI = M - oe_ins; tI = tI > 0 ? tI : 0;
-			const int g = tI + j * e_ins;
+			const int g = tI + je;
 			const int incl = wx_scan_max(g);
 			const int excl = wx_prev_lane(incl, WX_NEG);
-			const int f = max(A, excl + e_ins) - j * e_ins;
+			const int f = max(A, excl + e_ins) - je;
 			const int h = act ? max(max(M, e), f) : 0;
 			int tD = M - oe_del; tD = tD > 0 ? tD : 0;
 			const int en = act ? max(e - e_del, tD) : 0;
