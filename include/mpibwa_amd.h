@@ -219,6 +219,9 @@ int  mi355x_rank_host_threads(int *ranks_on_node);
 /* device-computed checksums of the three resident index arrays (occ blocks, sampled SA, pac): mi355x_init compares every rank's
  * with rank 0's after its broadcast and ends the run on a difference; a host that broadcasts by other means does the same with this */
 int  mi355x_index_checksums(uint64_t out[3]);
+/* mem_process_seqs calls the library runs side by side at most (further callers wait; fewer are admitted while their work buffers
+ * would not fit in HBM): the most worker threads a chunk loop has use for */
+int  mi355x_max_calls(void);
 /* The first-use cost of `n_calls` call contexts (work buffers on the device and page-locked on the host, streams, the host thread
  * pool, the kernels' code objects: 1-2 s per context otherwise paid by the first chunks of the loop the reference brackets with
  * MPI_Wtime, src/mainParallel.c:1238-1319) paid now: n_calls mem_process_seqs calls side by side on n_reads reads of read_len

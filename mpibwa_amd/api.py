@@ -18,7 +18,7 @@ EXPORTS = [
     "mi355x_index_upload", "mi355x_index_alloc", "mi355x_index_buffers", "mi355x_index_d2d", "mi355x_index_commit",
     "mi355x_finalize", "mi355x_index_build", "mi355x_index_build_gpu",
     "mi355x_smem_batch", "mi355x_sa_batch", "mi355x_sa_batch2", "mi355x_sa_dense_info", "mi355x_extend_batch", "mi355x_matesw_batch", "mi355x_chain_batch", "mi355x_pair_batch", "mi355x_pair_maxreg", "mi355x_fastq_scan", "mi355x_fastq_chunks", "mi355x_fastq_fill", "mi355x_last_stats", "mi355x_host_cpus", "mi355x_collect_sam", "mi355x_collect_sam_into", "mi355x_host_ksw_align2",
-    "bwa_set_rg", "bwa_insert_header", "bwa_idx2mem", "mi355x_write_map", "mi355x_init", "mi355x_rank_host_threads", "mi355x_index_checksums", "mi355x_init_bcast_seconds", "mi355x_global_batch", "mi355x_device_count", "mi355x_device_memory", "mi355x_buffer_growths", "mi355x_prewarm",
+    "bwa_set_rg", "bwa_insert_header", "bwa_idx2mem", "mi355x_write_map", "mi355x_init", "mi355x_rank_host_threads", "mi355x_index_checksums", "mi355x_init_bcast_seconds", "mi355x_global_batch", "mi355x_device_count", "mi355x_device_memory", "mi355x_buffer_growths", "mi355x_prewarm", "mi355x_max_calls",
 ]
 
 

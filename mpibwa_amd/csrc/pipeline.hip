@@ -626,6 +626,8 @@ extern "C" void mi355x_last_stats(mi355x_stats_t *st)
 	*st = g_stats;
 }
 extern "C" int mi355x_host_cpus(void) { return usable_cpus(); }
+// calls the library runs side by side at most (further callers wait at the door; fewer are admitted when their work buffers do not fit)
+extern "C" int mi355x_max_calls(void) { return MAX_CALLS; }
 // host threads the library will use for this rank's calls: its share of the node's usable CPUs (the launcher's local size), and
 // how many ranks it believes share the node
 extern "C" int mi355x_rank_host_threads(int *ranks_on_node)

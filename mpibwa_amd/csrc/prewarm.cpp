@@ -76,7 +76,7 @@ extern "C" double mi355x_prewarm(const mem_opt_t *opt, const bwt_t *bwt, const b
 	if (!opt || !bwt || !bns || !pac) die("mi355x_prewarm: opt, bwt, bns and pac are the ones the chunk loop will pass to mem_process_seqs");
 	if (opt->flag & MEM_F_PE) n_reads &= ~1;
 	if (n_reads <= 0 || read_len <= 0 || n_calls <= 0 || bns->l_pac < read_len) return 0.;
-	if (n_calls > 12) n_calls = 12;
+	if (n_calls > mi355x_max_calls()) n_calls = mi355x_max_calls();
 	expect_calls_in_flight(n_calls);   // (pipeline.hip: three or more = the caller's calls run in their busy mode from the first one on)
 	const auto t0 = std::chrono::steady_clock::now();
 	std::vector<std::thread> th;

@@ -47,6 +47,7 @@
 #define DIE(...) do { fprintf(stderr, "[mpibwa_gpu] " __VA_ARGS__); fputc('\n', stderr); MPI_Abort(MPI_COMM_WORLD, 1); } while (0)
 #define MPI_OK(call) do { int e_ = (call); if (e_ != MPI_SUCCESS) DIE("%s failed (%s:%d)", #call, __FILE__, __LINE__); } while (0)
 
+#define MAX_WORKERS 32
 static int g_rank, g_size;
 
 /* ---- one FASTQ file as this rank sees it ---- */
@@ -424,7 +425,8 @@ int main(int argc, char **argv)
 	if (K <= 0) K = (int64_t)opt->chunk_size * opt->n_threads;   /* src/mainParallel.c:635 */
 	if (provided < MPI_THREAD_SERIALIZED) n_workers = 1;
 	if (n_workers < 1) n_workers = 1;
-	if (n_workers > 12) n_workers = 12;   /* the library runs up to twelve calls side by side (fewer when their work buffers do not fit) */
+	if (n_workers > mi355x_max_calls()) n_workers = mi355x_max_calls();   /* what the library runs side by side (fewer when their work buffers do not fit) */
+	if (n_workers > MAX_WORKERS) n_workers = MAX_WORKERS;
 
 	/* The index goes first: while this thread reads the FASTQ offsets below, another one pays the first-use cost of the call
 	 * contexts (mi355x_prewarm: work buffers, streams, thread pool, code objects) on reads sampled from the reference, so that the
@@ -585,7 +587,7 @@ int main(int argc, char **argv)
 	pthread_mutex_init(&L.mpi_mu, 0);
 	pthread_mutex_init(&L.fetch_mu, 0);
 	pthread_mutex_init(&L.write_mu, 0);
-	pthread_t th[12];
+	pthread_t th[MAX_WORKERS];
 	for (int w = 1; w < n_workers; ++w)
 		if (pthread_create(&th[w], 0, chunk_worker, &L) != 0) DIE("cannot start worker thread %d", w);
 	chunk_worker(&L);
