@@ -323,7 +323,7 @@ __global__ __launch_bounds__(64) void msw2_kernel(MswParams P, int n_pairs, int 
 		const msw_s2 zero = s2_splat(0);
 		int Swave = run ? S : 0;
 		for (int o = 32; o; o >>= 1) Swave = max(Swave, __shfl_xor(Swave, o));
-		uint32_t co_diag = 0, co_fseg = 0, co_ffull = 0, co_keyA = 0, co_keyB = 0;
+		uint32_t co_diag = 0, co_fseg = 0, co_ffull = 0, co_key = 0;
 		auto base_at = [&](const MswReq &rq, int tnx, int i) -> int {   // (rows past the end of the shorter window: its last row again, results unused)
 			const int ii = i < tnx ? i : tnx - 1;
 			return ii >= 0 ? msw_base(pac, P.l_pac, rq.rb + ii) : 0;
@@ -338,23 +338,28 @@ __global__ __launch_bounds__(64) void msw2_kernel(MswParams P, int n_pairs, int 
 			const uint32_t *srow = stab + ((ta << 2 | tb) << 3);
 			const uint32_t ci_diag = (uint32_t)msw_dpp<MSW_QP(0, 0, 1, 2)>((int)co_diag), ci_fseg = (uint32_t)msw_dpp<MSW_QP(0, 0, 1, 2)>((int)co_fseg);
 			const uint32_t ci_ffull = (uint32_t)msw_dpp<MSW_QP(0, 0, 1, 2)>((int)co_ffull);
-			const uint32_t ci_keyA = (uint32_t)msw_dpp<MSW_QP(0, 0, 1, 2)>((int)co_keyA), ci_keyB = (uint32_t)msw_dpp<MSW_QP(0, 0, 1, 2)>((int)co_keyB);
+			const uint32_t ci_key = (uint32_t)msw_dpp<MSW_QP(0, 0, 1, 2)>((int)co_key);
 			msw_s2 diag = s2_of(j ? ci_diag : 0u), fseg = s2_of(j ? ci_fseg : 0u), ffull = s2_of(j ? ci_ffull : 0u);
-			uint32_t keyA = j ? ci_keyA : 0u, keyB = j ? ci_keyB : 0u;
-			const int kbase = j * S;
+			// the row maximum of each alignment and the first position that reaches it as ONE 16-bit key per alignment: h * 256 + (255 -
+			// position) — the byte flavour has h < 250 and at most 256 positions.  Inside a block of eight cells the key is taken relative
+			// to the block (h * 256 + 7 - u: one packed multiply-add with constants and one packed maximum per cell), the block's offset is
+			// added once per block.
+			msw_u2 key = __builtin_bit_cast(msw_u2, j ? ci_key : 0u);
+			msw_u2 c256 = {256, 256};
+			asm volatile("" : "+v"(c256));   // (opaque: h * 256 + rel is to be one v_pk_mad_u16, not a shift and an or)
+			msw_u2 poscv = {(unsigned short)(248 - j * S), (unsigned short)(248 - j * S)};   // 255 - 7 - (first position of the block)
 			const int kmax = act ? S : 0;
 			// (H, E and both F are never negative and h = Hpre is not either: "max(x - c, 0)" is one saturating subtraction.  seg_end: the
 			// end of a segment as a wave-uniform fact — slen_u > 0: every live quad of the wave has that segment length, which is the rule
 			// (the reads of a chunk are of one length) — or bit 3 of the position's code)
-			auto step = [&](uint32_t &w, int kk, uint32_t cd, int u, bool seg_end) {
+			auto step = [&](uint32_t &w, uint32_t cd, int u, bool seg_end, msw_u2 &mblk) {
 				const msw_s2 hd = s2_of(__builtin_amdgcn_perm(0u, w, 0x0c020c00u));   // H_A | H_B << 16   (row i - 1)
 				msw_s2 e = s2_of(__builtin_amdgcn_perm(0u, w, 0x0c030c01u));          // E_A | E_B << 16
 				const uint32_t q = __builtin_amdgcn_ubfe(cd, 4 * u, 3);
 				const msw_s2 s = s2_of(srow[q]);
 				const msw_s2 h = s2_max(s2_max(diag + s, e), fseg);                    // Hpre(i, k) of both
-				const uint32_t posc = (uint32_t)(0xffff - (kbase + kk));
-				keyA = max(keyA, u_of(h) << 16 | posc);
-				keyB = max(keyB, (u_of(h) & 0xffff0000u) | posc);
+				const msw_u2 rel = {(unsigned short)(7 - u), (unsigned short)(7 - u)};
+				mblk = __builtin_elementwise_max(mblk, __builtin_bit_cast(msw_u2, h) * c256 + rel);
 				const msw_s2 hfin = s2_max(h, ffull);
 				e = s2_max(s2_sub0(e, e_del), s2_sub0(h, oe_del));
 				const msw_s2 t2 = s2_sub0(h, oe_ins);
@@ -366,8 +371,10 @@ __global__ __launch_bounds__(64) void msw2_kernel(MswParams P, int n_pairs, int 
 				w = __builtin_amdgcn_perm(u_of(e), u_of(hfin), 0x06020400u);            // bytes: H_A, E_A, H_B, E_B
 			};
 			int seg_pos = 0;   // position inside the segment (a lane's quarter is four whole segments: the same in every lane)
-			for (int c = 0; c * 8 < Swave; ++c) {
+			const msw_u2 eight = {8, 8};
+			for (int c = 0; c * 8 < Swave; ++c, poscv -= eight) {
 				const uint32_t cd = c * 8 < kmax ? codes[c * 64 + lane] : 0u;
+				msw_u2 mblk = {0, 0};
 #pragma unroll
 				for (int u = 0; u < 8; u += 2) {
 					const int k = c * 8 + u;
@@ -378,23 +385,25 @@ __global__ __launch_bounds__(64) void msw2_kernel(MswParams P, int n_pairs, int 
 					}
 					if (k < kmax) {
 						uint32_t w0 = cell[k * 64 + lane], w1 = cell[(k + 1) * 64 + lane];
-						step(w0, k, cd, u, end0); step(w1, k + 1, cd, u + 1, end1);
+						step(w0, cd, u, end0, mblk); step(w1, cd, u + 1, end1, mblk);
 						cell[k * 64 + lane] = w0; cell[(k + 1) * 64 + lane] = w1;
 					}
 				}
+				if (c * 8 < kmax) key = __builtin_elementwise_max(key, mblk + poscv);
 			}
-			if (act) { co_diag = u_of(diag); co_fseg = u_of(fseg); co_ffull = u_of(ffull); co_keyA = keyA; co_keyB = keyB; }
+			const uint32_t keyAB = __builtin_bit_cast(uint32_t, key);
+			if (act) { co_diag = u_of(diag); co_fseg = u_of(fseg); co_ffull = u_of(ffull); co_key = keyAB; }
 			int stop = 0;
 			if (act && j == 3) {
 				if (i < tnA && !satA) {
-					const int imax = (int)(keyA >> 16);
+					const int imax = (int)(keyAB >> 8 & 0xff);
 					rowsA[(size_t)i * n_req] = (uint16_t)imax;
-					if (imax > gmaxA) { gmaxA = imax; teA = i; qeA = 0xffff - (int)(keyA & 0xffff); if (gmaxA >= sat_limit) satA = 1; }
+					if (imax > gmaxA) { gmaxA = imax; teA = i; qeA = 255 - (int)(keyAB & 0xff); if (gmaxA >= sat_limit) satA = 1; }
 				}
 				if (i < tnB && !satB) {
-					const int imax = (int)(keyB >> 16);
+					const int imax = (int)(keyAB >> 24);
 					rowsB[(size_t)i * n_req] = (uint16_t)imax;
-					if (imax > gmaxB) { gmaxB = imax; teB = i; qeB = 0xffff - (int)(keyB & 0xffff); if (gmaxB >= sat_limit) satB = 1; }
+					if (imax > gmaxB) { gmaxB = imax; teB = i; qeB = 255 - (int)(keyAB >> 16 & 0xff); if (gmaxB >= sat_limit) satB = 1; }
 				}
 				if ((i + 1 >= tnA || satA) && (i + 1 >= tnB || satB)) stop = 1;
 			}
