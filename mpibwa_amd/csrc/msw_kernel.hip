@@ -355,7 +355,8 @@ __global__ __launch_bounds__(64) void msw2_kernel(MswParams P, int n_pairs, int 
 			auto step = [&](uint32_t &w, uint32_t cd, int u, bool seg_end, msw_u2 &mblk) {
 				const msw_s2 hd = s2_of(__builtin_amdgcn_perm(0u, w, 0x0c020c00u));   // H_A | H_B << 16   (row i - 1)
 				msw_s2 e = s2_of(__builtin_amdgcn_perm(0u, w, 0x0c030c01u));          // E_A | E_B << 16
-				const uint32_t q = __builtin_amdgcn_ubfe(cd, 4 * u, 3);
+				uint32_t q = __builtin_amdgcn_ubfe(cd, 4 * u, 3);
+				asm("" : "+v"(q));   // (opaque: v_bfe_u32 + v_lshl_add_u32 for the table address; folded, it is shift + and + add)
 				const msw_s2 s = s2_of(srow[q]);
 				const msw_s2 h = s2_max(s2_max(diag + s, e), fseg);                    // Hpre(i, k) of both
 				const msw_u2 rel = {(unsigned short)(7 - u), (unsigned short)(7 - u)};
