@@ -353,6 +353,26 @@ char *mi355x_collect_sam(bseq1_t *seqs, int n, size_t *total_len);
 /* the same into a buffer the caller keeps from chunk to chunk (*buf / *cap: replaced when a chunk needs more); returns the length */
 size_t mi355x_collect_sam_into(bseq1_t *seqs, int n, char **buf, size_t *cap);
 
+/* ---- the caller's side behind the call: what mpiBWA does with a chunk's SAM text before it reaches the file ----
+ * -f fixmate (fixmate(), src/fixmate.c:601-827): the lines of a pair get the mate's contig / position / strand, MQ, MC and ms tags;
+ * seqs[2p].sam / seqs[2p+1].sam are replaced (malloc family).  mi355x_fixmate_pair: one pair, returns its number of SAM lines or -1
+ * when the text is not a pair's (left untouched); mi355x_fixmate: the pairs of a chunk on the rank's host threads (call_fixmate,
+ * src/parallel_aux.c:2164-2206), returns the lines or -(first read of a failing pair) - 1. */
+int     mi355x_fixmate_pair(bseq1_t *s1, bseq1_t *s2, const bntseq_t *bns);
+int64_t mi355x_fixmate(bseq1_t *seqs, int n, const bntseq_t *bns);
+/* -g / -b output (deflate_block, src/bgzf.c:245-330; compress_and_write_bgzf_thread / _bam_thread, src/parallel_aux.c:2941-3176):
+ * SAM text as BGZF blocks of whole records, compressed side by side, byte-identical for any thread count.  out needs
+ * mi355x_bgzf_bound(len) bytes; returns the compressed size (0: cap too small).  mi355x_bgzf_eof: the 28-byte empty block the
+ * reference appends to its .bam (src/mainParallel.c:1509-1516). */
+size_t  mi355x_bgzf_bound(size_t len);
+size_t  mi355x_bgzf_compress(const char *text, size_t len, int level, uint8_t *out, size_t cap);
+size_t  mi355x_bgzf_eof(uint8_t out[28]);
+/* mpiBWAByChr's routing (src/mainParallelByChromosome.c:1340-1455, :3437-3486): the records of `sam` by destination — contig
+ * 0 .. n_seqs-1 by RNAME, then "discordant" (only when discordant != 0; a record whose RNAME and RNEXT are two different contigs
+ * goes to its contig AND there), last "unmapped" (RNAME '*').  out_text[d] (malloc, NULL when empty) / out_len[d] for
+ * d < n_seqs + 1 + (discordant != 0).  Returns the number of records or -(offset of a malformed line) - 1. */
+int64_t mi355x_route_by_chr(const char *sam, size_t len, const bntseq_t *bns, int discordant, char **out_text, size_t *out_len);
+
 #ifdef __cplusplus
 }
 #endif

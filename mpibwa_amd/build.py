@@ -55,7 +55,7 @@ def build(force=False, verbose=False):
         with ThreadPoolExecutor(max_workers=n_par) as ex:
             list(ex.map(run, jobs))
     if force or _stale(OUT, objs):
-        cmd = [HIPCC, "-shared", "-o", OUT] + objs + ["-Wl,-Bsymbolic", "-Wl,-soname,libmpibwa_amd.so", "-lpthread", "-lm", "-ldl"]
+        cmd = [HIPCC, "-shared", "-o", OUT] + objs + ["-Wl,-Bsymbolic", "-Wl,-soname,libmpibwa_amd.so", "-lpthread", "-lm", "-ldl", "-lz"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
