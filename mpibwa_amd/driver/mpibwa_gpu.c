@@ -1,9 +1,11 @@
 /* mpibwa_gpu.c — a thin MPI host program around the C ABI of libmpibwa_amd.so: one rank per GPU,
  *
- *     mpiexec -n N mpibwa_gpu mem [bwa mem options] [-K bases] [--in-flight chunks] [--no-prewarm] [--dry-run] -o OUT PREFIX R1.fastq [R2.fastq]
+ *     mpiexec -n N mpibwa_gpu mem [bwa mem options] [-f] [-g | -b] [--by-chr] [-K bases] [--in-flight chunks] [--no-prewarm] [--dry-run] -o OUT PREFIX R1.fastq [R2.fastq]
  *
- * The `mem` options are the reference's (src/mainParallel.c:311-398: -k -w -A -B -O -E -L -U -T -c -d -r -D -m -s -G -N -W -y -X -h -Q -I -R -H
- * -P -a -M -S -Y -V -5 -q -j -C -v -t -K -o); -p, -x, -b, -g, -f and -z are not offered.
+ * The `mem` options are the reference's (src/mainParallel.c:291-398: -k -w -A -B -O -E -L -U -T -c -d -r -D -m -s -G -N -W -y -X -h -Q -I -R -H
+ * -P -a -M -S -Y -V -5 -q -j -C -v -t -K -o, and its output options -f (fixmate, :395), -g (BGZF, :299), -b (BGZF + EOF block under the
+ * name the reference calls BAM, :298)); -p, -x and -z are not offered.  --by-chr is mpiBWAByChr (src/mainParallelByChromosome.c): one file
+ * per contig plus discordant (pairs without -f) and unmapped in the directory of OUT.
  *
  * It does, with this repo's own code, what mpiBWA's main does around mem_process_seqs():
  *   - every rank takes a byte slice of each FASTQ file, finds the first record boundary in it and scans its records
@@ -26,6 +28,11 @@
  * the GPU half of one chunk under the host half of another — and appending the SAM text through the shared file pointer.
  * With MPI_THREAD_MULTIPLE the workers call MPI concurrently; with MPI_THREAD_SERIALIZED a mutex takes turns; below that
  * one worker runs (the reference's blocking loop, src/mainParallel.c:1112-1391).
+ *
+ * Behind the call (the caller's side; the passes are the library's, csrc/sampost.cpp): -f rewrites the lines of every pair with
+ * the mate's fields and the MQ / MC / ms tags (src/fixmate.c:601-827), -g / -b compress a chunk's text into BGZF blocks of whole records
+ * (src/parallel_aux.c:2941-3176; every record is written — the reference drops the last read of each thread's slice), --by-chr routes the
+ * records by RNAME (src/mainParallelByChromosome.c:1340-1455, :3437-3486).
  *
  * Plain C99 + MPI + pthreads; built by mpibwa_amd/build.py when an MPI installation is found (mpibwa_amd/mpibwa_gpu).
  */
@@ -186,6 +193,10 @@ typedef struct {
 	long long n_chunks;
 	int paired, lockstep, trimmed, copy_comment;
 	const mem_pestat_t *pes0;    /* -I */
+	int fixmate;                 /* -f */
+	int format, level;           /* 2 SAM text, 1 / 0 BGZF blocks (-b / -g: src/mainParallel.c:226, 298-299); zlib level (3: src/mainParallel.c:227) */
+	int by_chr, n_dest;          /* --by-chr: records go to dest[0 .. n_dest) (contigs, [discordant], unmapped) instead of `out` */
+	MPI_File *dest;
 	int serialize;               /* MPI_THREAD_SERIALIZED: one thread inside MPI at a time */
 	pthread_mutex_t mpi_mu, fetch_mu, write_mu;
 	int64_t n_fetched;           /* reads of the chunks this rank has taken so far (trimmed pairs: n_processed) */
@@ -225,14 +236,60 @@ static void *grown(void **p, size_t *cap, size_t need)
 	return *p;
 }
 
+/* a piece of a chunk's text to a file through its shared pointer: as it is, or as BGZF blocks (zbuf / czbuf: the worker's buffer).
+ * A chunk's text goes out in one piece per GiB: the pieces of one chunk must not be separated by another worker's text (the shared
+ * file pointer orders the ranks' writes, write_mu the workers' of one rank). */
+static void write_text(loop_t *L, MPI_File fh, const char *text, size_t len, void **zbuf, size_t *czbuf)
+{
+	const char *out = text;
+	size_t n = len;
+	if (L->format != 2) {
+		const size_t cap = mi355x_bgzf_bound(len);
+		uint8_t *z = grown(zbuf, czbuf, cap);
+		n = mi355x_bgzf_compress(text, len, L->level, z, cap);
+		if (len && !n) DIE("BGZF: %zu bytes of text do not fit their buffer", len);
+		out = (const char *)z;
+	}
+	const int many = n > (1u << 30);
+	if (many) pthread_mutex_lock(&L->write_mu);
+	MPI_ENTER(L);
+	for (size_t w = 0; w < n; ) {
+		int piece = n - w > (1u << 30) ? (1 << 30) : (int)(n - w);
+		MPI_Status st;
+		MPI_OK(MPI_File_write_shared(fh, out + w, piece, MPI_BYTE, &st));
+		w += (size_t)piece;
+	}
+	MPI_LEAVE(L);
+	if (many) pthread_mutex_unlock(&L->write_mu);
+}
+
+/* the header as the file's first bytes (rank 0, before the file is opened by everybody): text, or BGZF blocks of it
+ * (create_sam_header / create_bam_header, src/parallel_aux.c:1846-2026) */
+static void create_with_header(const char *path, const char *hdr, size_t hdr_len, int format, int level)
+{
+	FILE *fp = fopen(path, "w");
+	if (!fp) DIE("cannot create %s", path);
+	if (hdr_len && format == 2) fwrite(hdr, 1, hdr_len, fp);
+	else if (hdr_len) {
+		const size_t cap = mi355x_bgzf_bound(hdr_len);
+		uint8_t *z = malloc(cap);
+		const size_t n = mi355x_bgzf_compress(hdr, hdr_len, level, z, cap);
+		fwrite(z, 1, n, fp);
+		free(z);
+	}
+	if (fclose(fp) != 0) DIE("cannot write %s", path);
+}
+
 static void *chunk_worker(void *arg)
 {
 	loop_t *L = arg;
 	const long long *tab = L->tab;
 	const int paired = L->paired;
-	void *pb1 = 0, *pb2 = 0, *po1 = 0, *po2 = 0, *pbb = 0, *pseqs = 0;
-	size_t cb1 = 0, cb2 = 0, co1 = 0, co2 = 0, cbb = 0, cseqs = 0, csam = 0;
+	void *pb1 = 0, *pb2 = 0, *po1 = 0, *po2 = 0, *pbb = 0, *pseqs = 0, *zbuf = 0;
+	size_t cb1 = 0, cb2 = 0, co1 = 0, co2 = 0, cbb = 0, cseqs = 0, csam = 0, czbuf = 0;
 	char *sam = 0;
+	char **dtext = L->by_chr ? calloc((size_t)L->n_dest, sizeof(char *)) : 0;
+	size_t *dlen = L->by_chr ? calloc((size_t)L->n_dest, sizeof(size_t)) : 0;
 	const int prof = getenv("MPIBWA_DRV_PROF") != 0;
 	for (;;) {
 		long long one = 1, c = 0;
@@ -272,27 +329,28 @@ static void *chunk_worker(void *arg)
 		/* n_processed: 0 for single end and equal-size pairs, the reads this rank has done for trimmed pairs (src/mainParallel.c:1314, 2355-2357, 3093) */
 		mem_process_seqs(L->opt, L->idx->bwt, L->idx->bns, L->idx->pac, L->trimmed ? n_before : 0, n, seqs, L->pes0);
 		const double t3 = MPI_Wtime();
+		/* -f: the pairs' lines get their mates' fields and tags (call_fixmate, src/mainParallel.c:1321-1355) */
+		if (L->fixmate && paired) {
+			const int64_t r = mi355x_fixmate(seqs, n, L->idx->bns);
+			if (r < 0) DIE("fixmate: the SAM text of read %lld of chunk %lld is not a pair's", (long long)(-r - 1), c);
+		}
+		const double t3b = MPI_Wtime();
 		const size_t sam_len = mi355x_collect_sam_into(seqs, n, &sam, &csam);
 		const double t4 = MPI_Wtime();
-		/* a chunk's SAM goes out in one piece per GiB: the pieces of one chunk must not be separated by another worker's text (the
-		 * shared file pointer orders the ranks' writes, this mutex the workers' of one rank).  Chunks are written as their workers
-		 * finish them: with --in-flight > 1 the records of a file are not in input order (the reference's are not across ranks either). */
-		const int many = sam_len > (1u << 30);
-		if (many) pthread_mutex_lock(&L->write_mu);
-		MPI_ENTER(L);
-		for (size_t w = 0; w < sam_len; ) {
-			int piece = sam_len - w > (1u << 30) ? (1 << 30) : (int)(sam_len - w);
-			MPI_Status st;
-			MPI_OK(MPI_File_write_shared(L->out, sam + w, piece, MPI_BYTE, &st));
-			w += (size_t)piece;
+		/* Chunks are written as their workers finish them: with --in-flight > 1 the records of a file are not in input order (the
+		 * reference's are not across ranks either). */
+		if (!L->by_chr) write_text(L, L->out, sam, sam_len, &zbuf, &czbuf);
+		else {   /* every record to the file of its contig, pairs on two contigs to "discordant" as well, RNAME '*' to "unmapped" */
+			const int64_t r = mi355x_route_by_chr(sam, sam_len, L->idx->bns, L->n_dest == L->idx->bns->n_seqs + 2, dtext, dlen);
+			if (r < 0) DIE("chunk %lld: a SAM line without RNAME at byte %lld", c, (long long)(-r - 1));
+			for (int d = 0; d < L->n_dest; ++d)
+				if (dtext[d]) { write_text(L, L->dest[d], dtext[d], dlen[d], &zbuf, &czbuf); free(dtext[d]); dtext[d] = 0; }
 		}
-		MPI_LEAVE(L);
-		if (many) pthread_mutex_unlock(&L->write_mu);
 		if (prof)
-			fprintf(stderr, "[mpibwa_gpu] chunk %lld done at %.3f: read %.0f  scan+fill %.0f  align %.0f  collect %.0f  write %.0f ms\n", c, MPI_Wtime() - L->t_start,
-			        (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (MPI_Wtime() - t4) * 1e3);
+			fprintf(stderr, "[mpibwa_gpu] chunk %lld done at %.3f: read %.0f  scan+fill %.0f  align %.0f  fixmate %.0f  collect %.0f  write %.0f ms\n", c, MPI_Wtime() - L->t_start,
+			        (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t3b - t3) * 1e3, (t4 - t3b) * 1e3, (MPI_Wtime() - t4) * 1e3);
 	}
-	free(sam); free(pseqs); free(po1); free(po2); free(pbb); free(pb1); free(pb2);
+	free(sam); free(pseqs); free(po1); free(po2); free(pbb); free(pb1); free(pb2); free(zbuf); free(dtext); free(dlen);
 	return 0;
 }
 
