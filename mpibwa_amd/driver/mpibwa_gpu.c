@@ -361,12 +361,13 @@ int main(int argc, char **argv)
 	MPI_Comm_rank(MPI_COMM_WORLD, &g_rank);
 	MPI_Comm_size(MPI_COMM_WORLD, &g_size);
 	int n_threads = 0, copy_comment = 0, dry = 0, n_workers = 6, prewarm = 1;
+	int dofixmate = 0, write_format = 2, compression_level = 3, by_chr = 0;   /* src/mainParallel.c:223-227 */
 	int scale_a = 0, set_b = 0, set_T = 0, set_U = 0, set_d = 0, set_O = 0, set_E = 0, set_L = 0;
 	int64_t K = 0;
 	const char *out_path = 0, *pos[4];
 	int n_pos = 0;
 	if (argc < 2 || strcmp(argv[1], "mem") != 0) {
-		if (g_rank == 0) fprintf(stderr, "usage: mpiexec -n N %s mem [bwa mem options] [-K bases] [--in-flight chunks] [--no-prewarm] [--dry-run] -o OUT PREFIX R1.fastq [R2.fastq]\n", argv[0]);
+		if (g_rank == 0) fprintf(stderr, "usage: mpiexec -n N %s mem [bwa mem options] [-f] [-g | -b] [--by-chr] [-K bases] [--in-flight chunks] [--no-prewarm] [--dry-run] -o OUT PREFIX R1.fastq [R2.fastq]\n", argv[0]);
 		MPI_Finalize();
 		return 1;
 	}
@@ -380,11 +381,13 @@ int main(int argc, char **argv)
 		const char *a = argv[i];
 		if (!strcmp(a, "--dry-run")) { dry = 1; continue; }
 		if (!strcmp(a, "--no-prewarm")) { prewarm = 0; continue; }
+		if (!strcmp(a, "--by-chr")) { by_chr = 1; continue; }
+		if (!strcmp(a, "--level") && i + 1 < argc) { compression_level = atoi(argv[++i]); continue; }
 		if (!strcmp(a, "--in-flight") && i + 1 < argc) { n_workers = atoi(argv[++i]); continue; }
 		if (a[0] != '-' || !a[1]) { if (n_pos < 3) pos[n_pos++] = a; continue; }
 		if (a[2]) DIE("unknown option %s (options take their value as the next argument)", a);
 		const char c = a[1];
-		if (strchr("PapMSYV5qjC", c)) {   /* flags */
+		if (strchr("PapMSYV5qjCfbg", c)) {   /* flags */
 			if (c == 'P') opt->flag |= MEM_F_NOPAIRING;
 			else if (c == 'a') opt->flag |= MEM_F_ALL;
 			else if (c == 'p') DIE("-p (interleaved pairs in one file) is not supported: give R1 and R2");
@@ -396,6 +399,9 @@ int main(int argc, char **argv)
 			else if (c == 'q') opt->flag |= MEM_F_KEEP_SUPP_MAPQ;
 			else if (c == 'j') ignore_alt = 1;
 			else if (c == 'C') copy_comment = 1;
+			else if (c == 'f') dofixmate = 1;          /* src/mainParallel.c:395 */
+			else if (c == 'b') write_format = 1;       /* :298 */
+			else if (c == 'g') write_format = 0;       /* :299 */
 			continue;
 		}
 		if (!strchr("kwABTUtcdvrDmsGNWyKXhQOELRHIo", c)) DIE("unknown or unsupported option %s", a);
@@ -613,21 +619,51 @@ int main(int argc, char **argv)
 		if (bwa_verbose >= 3) fprintf(stderr, "[mpibwa_gpu] rank %d: %d call contexts warmed on %d sampled reads each in %.2f s, beside the FASTQ scan\n", g_rank, warm.n_calls, warm.n_reads, warm.secs);
 	}
 	/* ---- output: rank 0 writes the header, then everybody appends through the shared file pointer ---- */
-	MPI_File out;
-	if (g_rank == 0) {
-		FILE *fp = fopen(out_path, "w");
-		if (!fp) DIE("cannot create %s", out_path);
-		/* the reference's header (src/parallel_aux.c:1846-1915): @SQ lines, the -H lines, the read group, the program line */
-		for (int i = 0; i < idx->bns->n_seqs; ++i) fprintf(fp, "@SQ\tSN:%s\tLN:%d\n", idx->bns->anns[i].name, idx->bns->anns[i].len);
-		if (hdr_line) fprintf(fp, "%s\n", hdr_line);
-		if (rg_line) fprintf(fp, "%s\n", rg_line);
-		fprintf(fp, "@PG\tID:mpibwa_gpu\tPN:mpibwa_gpu\tVN:r3\tCL:%s", argv[0]);
-		for (int i = 1; i < argc; ++i) fprintf(fp, " %s", argv[i]);
-		fputc('\n', fp);
-		fclose(fp);
+	/* the reference's header (src/parallel_aux.c:1846-1915): @SQ lines, the -H lines, the read group, the program line */
+	char *hdr = 0;
+	size_t hdr_len = 0;
+	{
+		FILE *hp = open_memstream(&hdr, &hdr_len);
+		if (!hp) DIE("out of memory");
+		for (int i = 0; i < idx->bns->n_seqs; ++i) fprintf(hp, "@SQ\tSN:%s\tLN:%d\n", idx->bns->anns[i].name, idx->bns->anns[i].len);
+		if (hdr_line) fprintf(hp, "%s\n", hdr_line);
+		if (rg_line) fprintf(hp, "%s\n", rg_line);
+		fprintf(hp, "@PG\tID:mpibwa_gpu\tPN:mpibwa_gpu\tVN:r4\tCL:%s", argv[0]);
+		for (int i = 1; i < argc; ++i) fprintf(hp, " %s", argv[i]);
+		fputc('\n', hp);
+		fclose(hp);
 	}
-	MPI_Barrier(MPI_COMM_WORLD);
-	MPI_OK(MPI_File_open(MPI_COMM_WORLD, (char *)out_path, MPI_MODE_WRONLY | MPI_MODE_APPEND, MPI_INFO_NULL, &out));
+	MPI_File out = MPI_FILE_NULL, *dest = 0;
+	int n_dest = 0;
+	if (!by_chr) {
+		if (g_rank == 0) create_with_header(out_path, hdr, hdr_len, write_format, compression_level);
+		MPI_Barrier(MPI_COMM_WORLD);
+		MPI_OK(MPI_File_open(MPI_COMM_WORLD, (char *)out_path, MPI_MODE_WRONLY | MPI_MODE_APPEND, MPI_INFO_NULL, &out));
+	} else {
+		/* mpiBWAByChr (src/mainParallelByChromosome.c:983-1047): <directory of OUT>/<contig>.sam for every contig, discordant.sam for
+		 * pairs without -f, unmapped.sam; .bam / .gz with -b / -g.  The contig files start with the header; as text the other two do
+		 * not (create_sam_header_by_chr_file covers the contigs only, src/parallel_aux.c:2650-2723), compressed they do. */
+		struct stat sb;
+		char *dir = strdup(out_path);
+		if (!(stat(out_path, &sb) == 0 && S_ISDIR(sb.st_mode))) {
+			char *slash = strrchr(dir, '/');
+			if (slash) *slash = 0; else strcpy(dir, ".");
+		}
+		const int disc = paired && !dofixmate;
+		n_dest = idx->bns->n_seqs + 1 + disc;
+		dest = malloc(sizeof(MPI_File) * (size_t)n_dest);
+		const char *ext = write_format == 2 ? "sam" : write_format == 1 ? "bam" : "gz";
+		for (int d = 0; d < n_dest; ++d) {
+			const char *nm = d < idx->bns->n_seqs ? idx->bns->anns[d].name : (disc && d == idx->bns->n_seqs) ? "discordant" : "unmapped";
+			char *path = malloc(strlen(dir) + strlen(nm) + 8);
+			sprintf(path, "%s/%s.%s", dir, nm, ext);
+			if (g_rank == 0) create_with_header(path, hdr, d < idx->bns->n_seqs || write_format != 2 ? hdr_len : 0, write_format, compression_level);
+			MPI_Barrier(MPI_COMM_WORLD);
+			MPI_OK(MPI_File_open(MPI_COMM_WORLD, path, MPI_MODE_WRONLY | MPI_MODE_APPEND, MPI_INFO_NULL, &dest[d]));
+			free(path);
+		}
+		free(dir);
+	}
 
 	/* ---- the chunk loop: next chunk by fetch-and-add on rank 0's counter ---- */
 	long long *counter_mem = 0;
@@ -640,6 +676,7 @@ int main(int argc, char **argv)
 	memset(&L, 0, sizeof L);
 	L.opt = opt; L.idx = idx; L.win = win; L.out = out; L.f1 = f1.fh; L.f2 = paired ? f2.fh : MPI_FILE_NULL;
 	L.tab = tab_all; L.n_chunks = n_chunks; L.paired = paired; L.lockstep = lockstep; L.trimmed = trimmed; L.copy_comment = copy_comment; L.pes0 = pes0;
+	L.fixmate = dofixmate; L.format = write_format; L.level = compression_level; L.by_chr = by_chr; L.n_dest = n_dest; L.dest = dest;
 	L.serialize = provided < MPI_THREAD_MULTIPLE;
 	L.t_start = t_loop;
 	pthread_mutex_init(&L.mpi_mu, 0);
@@ -657,8 +694,17 @@ int main(int argc, char **argv)
 		fprintf(stderr, "[mpibwa_gpu] chunk loop: %lld reads in %lld chunks, %d rank(s) x %d chunks in flight, %.3f s = %.3f Mreads/s\n", n_reads, n_chunks, g_size,
 		        n_workers, dt, dt > 0 ? n_reads / dt * 1e-6 : 0.);
 	}
+	if (write_format == 1 && g_rank == 0) {   /* the empty block that ends the file the reference calls BAM (src/mainParallel.c:1508-1516) */
+		uint8_t eof[28];
+		MPI_Status st;
+		mi355x_bgzf_eof(eof);
+		if (!by_chr) MPI_OK(MPI_File_write_shared(out, eof, 28, MPI_BYTE, &st));
+		for (int d = 0; d < n_dest; ++d) MPI_OK(MPI_File_write_shared(dest[d], eof, 28, MPI_BYTE, &st));
+	}
 	MPI_Win_free(&win);
-	MPI_File_close(&out);
+	if (!by_chr) MPI_File_close(&out);
+	for (int d = 0; d < n_dest; ++d) MPI_File_close(&dest[d]);
+	free(dest); free(hdr);
 	MPI_File_close(&f1.fh);
 	if (paired) MPI_File_close(&f2.fh);
 	mi355x_finalize();

@@ -79,3 +79,31 @@ def test_partition_is_the_single_process_chunk_rule_for_any_rank_count(built, tm
             assert [t[2] for t in table] == want_off1
             if len(files) > 1:
                 assert [t[3] for t in table] == [int(src.f2.off[i]) for i in want_first]
+
+
+@pytest.mark.skipif(mpiexec() is None, reason="no mpiexec in this container")
+def test_output_options_on_the_cpu_with_the_reference_under_the_driver(built, genome, tmp_path, tmp_path_factory):
+    """-f, -g, -b and --by-chr of mpibwa_gpu end to end without a GPU: tests/csrc/driver_shim.c (LD_PRELOAD) answers the driver's device
+    entry points and hands mem_process_seqs to the reference's own library, so the driver's host side runs as it does on the GPU box
+    and the checks of tests/test_gpu_driver.py apply unchanged (there the records come from the product's kernels)."""
+    import tarfile
+    import test_gpu_driver as g
+    from oracle import pyoracle as po
+    if not os.path.exists(EXE) or not po.ref_available():
+        pytest.skip("mpibwa_gpu or oracle/_ref/libbwaref.so not built")
+    shim = str(tmp_path / "driver_shim.so")
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-O1", "-o", shim, os.path.join(ROOT, "tests", "csrc", "driver_shim.c"), "-ldl"])
+    d = tmp_path_factory.mktemp("drv_cpu")
+    with tarfile.open(os.path.join(EX, "hg19.small.tar.gz")) as t:
+        t.extractall(d)
+    fq = []
+    for k in (1, 2):
+        dst = str(d / ("R%d.fastq" % k))
+        with gzip.open(os.path.join(EX, "HCC1187C_R%d_10K.fastq.gz" % k), "rb") as gz, open(dst, "wb") as f:
+            f.write(gz.read())
+        fq.append(dst)
+    g._EXTRA_ENV.update({"LD_PRELOAD": shim, "MPIBWA_TEST_REFLIB": os.path.join(ROOT, "oracle", "_ref", "libbwaref.so")})
+    try:
+        g.check_output_options((str(d), os.path.join(str(d), "hg19.small.fa"), fq), genome, tmp_path)
+    finally:
+        g._EXTRA_ENV.clear()
