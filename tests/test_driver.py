@@ -81,18 +81,23 @@ def test_partition_is_the_single_process_chunk_rule_for_any_rank_count(built, tm
                 assert [t[3] for t in table] == [int(src.f2.off[i]) for i in want_first]
 
 
-@pytest.mark.skipif(mpiexec() is None, reason="no mpiexec in this container")
-def test_output_options_on_the_cpu_with_the_reference_under_the_driver(built, genome, tmp_path, tmp_path_factory):
+@pytest.fixture(scope="module")
+def shim_env(built, tmp_path_factory):
+    """environment that puts tests/csrc/driver_shim.c and the reference's library under a driver (see that file's header)"""
+    from oracle import pyoracle as po
+    if mpiexec() is None or not os.path.exists(EXE) or not po.ref_available():
+        pytest.skip("mpiexec, mpibwa_gpu or oracle/_ref/libbwaref.so not present")
+    shim = str(tmp_path_factory.mktemp("shim") / "driver_shim.so")
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-O1", "-o", shim, os.path.join(ROOT, "tests", "csrc", "driver_shim.c"), "-ldl"])
+    return {"LD_PRELOAD": shim, "MPIBWA_TEST_REFLIB": os.path.join(ROOT, "oracle", "_ref", "libbwaref.so")}
+
+
+def test_output_options_on_the_cpu_with_the_reference_under_the_driver(shim_env, genome, tmp_path, tmp_path_factory):
     """-f, -g, -b and --by-chr of mpibwa_gpu end to end without a GPU: tests/csrc/driver_shim.c (LD_PRELOAD) answers the driver's device
     entry points and hands mem_process_seqs to the reference's own library, so the driver's host side runs as it does on the GPU box
     and the checks of tests/test_gpu_driver.py apply unchanged (there the records come from the product's kernels)."""
     import tarfile
     import test_gpu_driver as g
-    from oracle import pyoracle as po
-    if not os.path.exists(EXE) or not po.ref_available():
-        pytest.skip("mpibwa_gpu or oracle/_ref/libbwaref.so not built")
-    shim = str(tmp_path / "driver_shim.so")
-    subprocess.check_call(["gcc", "-shared", "-fPIC", "-O1", "-o", shim, os.path.join(ROOT, "tests", "csrc", "driver_shim.c"), "-ldl"])
     d = tmp_path_factory.mktemp("drv_cpu")
     with tarfile.open(os.path.join(EX, "hg19.small.tar.gz")) as t:
         t.extractall(d)
@@ -102,8 +107,71 @@ def test_output_options_on_the_cpu_with_the_reference_under_the_driver(built, ge
         with gzip.open(os.path.join(EX, "HCC1187C_R%d_10K.fastq.gz" % k), "rb") as gz, open(dst, "wb") as f:
             f.write(gz.read())
         fq.append(dst)
-    g._EXTRA_ENV.update({"LD_PRELOAD": shim, "MPIBWA_TEST_REFLIB": os.path.join(ROOT, "oracle", "_ref", "libbwaref.so")})
+    g._EXTRA_ENV.update(shim_env)
     try:
         g.check_output_options((str(d), os.path.join(str(d), "hg19.small.fa"), fq), genome, tmp_path)
     finally:
         g._EXTRA_ENV.clear()
+
+
+REF_MAIN = os.path.join(ROOT, "oracle", "_ref", "mpiBWA_amd")
+REF_BYCHR = os.path.join(ROOT, "oracle", "_ref", "mpiBWAByChr_amd")
+
+
+def _records(path):
+    return sorted(ln for ln in open(path, "rb").read().splitlines(keepends=True) if not ln.startswith(b"@"))
+
+
+@pytest.mark.skipif(not (os.path.exists(REF_MAIN) and os.path.exists(REF_BYCHR)), reason="the reference's programs are not built (oracle/_ref)")
+def test_fixmate_and_by_chromosome_files_are_those_of_the_reference_programs(shim_env, genome, tmp_path):
+    """The reference's own programs — main() of mainParallel.c and of mainParallelByChromosome.c, compiled in place (oracle/Makefile) — and
+    mpibwa_gpu on the same input with the same library under both: `-f` gives the same records, `--by-chr` (with and without -f) the same
+    files with the same records and as many header lines, for pairs of every kind on three contigs.  Their -b / -g writers are not a
+    yardstick: they lose the last read of every thread's slice (src/parallel_aux.c:2953-2956), which this test shows; ours lose nothing
+    (tests/test_gpu_driver.py::check_output_options)."""
+    from mpibwa_amd import api, simulate
+    from test_sampost import _pairs_of_every_kind
+    d = str(tmp_path)
+    prefix = os.path.join(d, "g.fa")
+    for ext in ("", ".amb", ".ann", ".bwt", ".pac", ".sa"):
+        os.symlink(genome["prefix"] + ext, prefix + ext)
+    assert api.load_library().mi355x_write_map(prefix.encode(), (prefix + ".map").encode()) == 0   # (the reference's programs attach PREFIX.map)
+    reads = _pairs_of_every_kind(genome, n=3000, seed=14)
+    fq = [os.path.join(d, "r1.fastq"), os.path.join(d, "r2.fastq")]
+    simulate.write_fastq(fq[0], reads, 0)
+    simulate.write_fastq(fq[1], reads, 1)
+    env = dict(os.environ)
+    env.pop("LD_LIBRARY_PATH", None)
+    env.update(shim_env)
+
+    def run(exe, args):
+        r = subprocess.run([mpiexec(), "-n", "2", exe, "mem", "-t", "4", "-K", "300000"] + args + [prefix] + fq, capture_output=True, text=True, timeout=900, env=env, cwd=d)
+        assert r.returncode == 0, r.stderr[-3000:]
+    run(REF_MAIN, ["-o", os.path.join(d, "ref_plain")])
+    plain = _records(os.path.join(d, "ref_plain.sam"))
+    run(EXE, ["-o", os.path.join(d, "own_plain.sam")])
+    assert _records(os.path.join(d, "own_plain.sam")) == plain and len(plain) > 6000
+    # -f
+    run(REF_MAIN, ["-f", "-o", os.path.join(d, "ref_f")])
+    run(EXE, ["-f", "-o", os.path.join(d, "own_f.sam")])
+    fixed = _records(os.path.join(d, "ref_f.sam"))
+    assert _records(os.path.join(d, "own_f.sam")) == fixed and fixed != plain
+    # the per-contig files, with the discordant file (no -f) and without (-f)
+    for extra, src, files in (([], plain, ["chrS1", "chrS2", "chrS3", "discordant", "unmapped"]), (["-f"], fixed, ["chrS1", "chrS2", "chrS3", "unmapped"])):
+        tag = "f" if extra else "p"
+        for who, exe, more in (("ref", REF_BYCHR, []), ("own", EXE, ["--by-chr"])):
+            os.makedirs(os.path.join(d, who + tag))
+            run(exe, extra + more + ["-o", os.path.join(d, who + tag, "x.sam")])
+        assert sorted(os.listdir(os.path.join(d, "ref" + tag))) == sorted(os.listdir(os.path.join(d, "own" + tag))) == [f + ".sam" for f in files]
+        n = 0
+        for f in files:
+            a, b = os.path.join(d, "ref" + tag, f + ".sam"), os.path.join(d, "own" + tag, f + ".sam")
+            ra = _records(a)
+            assert ra == _records(b) and len(ra) > 100, f
+            assert open(a, "rb").read().count(b"\n@") == open(b, "rb").read().count(b"\n@")
+            n += len(ra) if f != "discordant" else 0
+        assert n == len(src)
+    # the reference's compressed writers lose records
+    run(REF_MAIN, ["-b", "-o", os.path.join(d, "ref_b")])
+    theirs = [ln for ln in gzip.decompress(open(os.path.join(d, "ref_b.bam"), "rb").read()).splitlines(keepends=True) if not ln.startswith(b"@")]
+    assert 0 < len(theirs) < len(plain) and set(theirs) <= set(plain)
