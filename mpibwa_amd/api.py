@@ -75,6 +75,12 @@ def load_library(build_if_missing=True):
     sig("mi355x_host_ksw_align2", None, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p])
     sig("mi355x_host_cpus", C.c_int, [])
     sig("mi355x_collect_sam", C.c_void_p, [P(abi.bseq1_t), C.c_int, P(C.c_size_t)])
+    sig("mi355x_fixmate_pair", C.c_int, [P(abi.bseq1_t), P(abi.bseq1_t), P(abi.bntseq_t)])
+    sig("mi355x_fixmate", C.c_int64, [P(abi.bseq1_t), C.c_int, P(abi.bntseq_t)])
+    sig("mi355x_bgzf_bound", C.c_size_t, [C.c_size_t])
+    sig("mi355x_bgzf_compress", C.c_size_t, [C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t])
+    sig("mi355x_bgzf_eof", C.c_size_t, [C.c_void_p])
+    sig("mi355x_route_by_chr", C.c_int64, [C.c_char_p, C.c_size_t, P(abi.bntseq_t), C.c_int, P(C.c_void_p), P(C.c_size_t)])
     sig("bwa_set_rg", C.c_void_p, [C.c_char_p])
     sig("bwa_insert_header", C.c_void_p, [C.c_char_p, C.c_void_p])
     sig("bwa_idx2mem", C.c_int, [P(abi.bwaidx_t)])

@@ -391,49 +391,79 @@ extern "C" int64_t mi355x_route_by_chr(const char *sam, size_t len, const bntseq
 	const ContigIndex ci(bns);
 	const int n_dest = bns->n_seqs + 1 + (discordant ? 1 : 0), d_unmapped = n_dest - 1, d_disc = discordant ? bns->n_seqs : -1;
 	struct Line { size_t at; uint32_t n; int dest; bool disc; };
-	std::vector<Line> lines;
-	lines.reserve(len / 256 + 16);
-	std::vector<size_t> bytes((size_t)n_dest, 0);
+	// the text in segments of whole lines, parsed side by side; a destination's records keep the order of the text (segment by segment)
+	struct Seg { size_t lo = 0, hi = 0; std::vector<Line> lines; std::vector<size_t> bytes; int64_t bad = -1; };
+	constexpr size_t SEG = 4u << 20;
+	std::vector<Seg> segs;
 	for (size_t at = 0; at < len;) {
-		const char *p = sam + at, *end = sam + len;
-		const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
-		const char *le = nl ? nl : end;
-		const size_t n = (size_t)(le - p) + (nl ? 1 : 0);
-		const char *q = p;
-		next_field(q, le); next_field(q, le);
-		if (q >= le) return -(int64_t)at - 1;
-		const std::string_view rname = next_field(q, le);
-		Line L{at, (uint32_t)n, d_unmapped, false};
-		if (rname != "*") {
-			const int chr = ci.find(rname);
-			if (chr >= 0) {
-				L.dest = chr;
-				if (discordant) {
-					next_field(q, le); next_field(q, le); next_field(q, le);   // POS, MAPQ, CIGAR
-					const std::string_view rnext = next_field(q, le);
-					const int mchr = rnext == "=" ? chr : rnext == "*" ? -1 : ci.find(rnext);
-					L.disc = mchr >= 0 && mchr != chr;
+		size_t hi = std::min(len, at + SEG);
+		if (hi < len) {
+			const void *nl = memchr(sam + hi, '\n', len - hi);
+			hi = nl ? (size_t)((const char *)nl - sam) + 1 : len;
+		}
+		Seg g;
+		g.lo = at; g.hi = hi;
+		segs.push_back(std::move(g));
+		at = hi;
+	}
+	run_parallel((int64_t)segs.size(), 1, [&](int64_t s0, int64_t s1) {
+		for (int64_t si = s0; si < s1; ++si) {
+			Seg &g = segs[(size_t)si];
+			g.bytes.assign((size_t)n_dest, 0);
+			g.lines.reserve((g.hi - g.lo) / 200 + 16);
+			for (size_t at = g.lo; at < g.hi;) {
+				const char *p = sam + at, *end = sam + g.hi;
+				const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+				const char *le = nl ? nl : end;
+				const size_t n = (size_t)(le - p) + (nl ? 1 : 0);
+				const char *q = p;
+				next_field(q, le); next_field(q, le);
+				if (q >= le) { g.bad = (int64_t)at; return; }
+				const std::string_view rname = next_field(q, le);
+				Line L{at, (uint32_t)n, d_unmapped, false};
+				if (rname != "*") {
+					const int chr = ci.find(rname);
+					if (chr >= 0) {
+						L.dest = chr;
+						if (discordant) {
+							next_field(q, le); next_field(q, le); next_field(q, le);   // POS, MAPQ, CIGAR
+							const std::string_view rnext = next_field(q, le);
+							const int mchr = rnext == "=" ? chr : rnext == "*" ? -1 : ci.find(rnext);
+							L.disc = mchr >= 0 && mchr != chr;
+						}
+					}
 				}
+				g.bytes[(size_t)L.dest] += n;
+				if (L.disc) g.bytes[(size_t)d_disc] += n;
+				g.lines.push_back(L);
+				at += n;
 			}
 		}
-		bytes[(size_t)L.dest] += n;
-		if (L.disc) bytes[(size_t)d_disc] += n;
-		lines.push_back(L);
-		at += n;
+	});
+	int64_t n_lines = 0;
+	std::vector<size_t> total((size_t)n_dest, 0);
+	for (Seg &g : segs) {
+		if (g.bad >= 0) return -g.bad - 1;
+		n_lines += (int64_t)g.lines.size();
+		for (int d = 0; d < n_dest; ++d) { const size_t b = g.bytes[(size_t)d]; g.bytes[(size_t)d] = total[(size_t)d]; total[(size_t)d] += b; }   // -> where the segment's records start
 	}
-	std::vector<size_t> w((size_t)n_dest, 0);
 	for (int d = 0; d < n_dest; ++d) {
-		out_len[d] = bytes[(size_t)d];
+		out_len[d] = total[(size_t)d];
 		out_text[d] = nullptr;
-		if (bytes[(size_t)d]) {
-			out_text[d] = (char *)malloc(bytes[(size_t)d] + 1);
+		if (total[(size_t)d]) {
+			out_text[d] = (char *)malloc(total[(size_t)d] + 1);
 			if (!out_text[d]) die("out of memory routing SAM records");
-			out_text[d][bytes[(size_t)d]] = 0;
+			out_text[d][total[(size_t)d]] = 0;
 		}
 	}
-	for (const Line &L : lines) {
-		memcpy(out_text[L.dest] + w[(size_t)L.dest], sam + L.at, L.n); w[(size_t)L.dest] += L.n;
-		if (L.disc) { memcpy(out_text[d_disc] + w[(size_t)d_disc], sam + L.at, L.n); w[(size_t)d_disc] += L.n; }
-	}
-	return (int64_t)lines.size();
+	run_parallel((int64_t)segs.size(), 1, [&](int64_t s0, int64_t s1) {
+		for (int64_t si = s0; si < s1; ++si) {
+			Seg &g = segs[(size_t)si];
+			for (const Line &L : g.lines) {
+				memcpy(out_text[L.dest] + g.bytes[(size_t)L.dest], sam + L.at, L.n); g.bytes[(size_t)L.dest] += L.n;
+				if (L.disc) { memcpy(out_text[d_disc] + g.bytes[(size_t)d_disc], sam + L.at, L.n); g.bytes[(size_t)d_disc] += L.n; }
+			}
+		}
+	});
+	return n_lines;
 }
