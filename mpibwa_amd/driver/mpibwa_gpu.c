@@ -326,8 +326,9 @@ static void *chunk_worker(void *arg)
 		memset(seqs, 0, sizeof(bseq1_t) * (size_t)n);
 		if (mi355x_fastq_fill(buf1, o1, buf2, o2, 0, count, L->copy_comment, L->lockstep, seqs) < 0) DIE("malformed record in chunk %lld", c);
 		const double t2 = MPI_Wtime();
-		/* n_processed: 0 for single end and equal-size pairs, the reads this rank has done for trimmed pairs (src/mainParallel.c:1314, 2355-2357, 3093) */
-		mem_process_seqs(L->opt, L->idx->bwt, L->idx->bns, L->idx->pac, L->trimmed ? n_before : 0, n, seqs, L->pes0);
+		/* n_processed: 0 for single end and equal-size pairs, the reads this rank has done for trimmed pairs (src/mainParallel.c:1314, 2355-2357, 3093);
+		 * mpiBWAByChr passes 0 in all three modes (src/mainParallelByChromosome.c:1249, 2502, 3407) */
+		mem_process_seqs(L->opt, L->idx->bwt, L->idx->bns, L->idx->pac, L->trimmed && !L->by_chr ? n_before : 0, n, seqs, L->pes0);
 		const double t3 = MPI_Wtime();
 		/* -f: the pairs' lines get their mates' fields and tags (call_fixmate, src/mainParallel.c:1321-1355) */
 		if (L->fixmate && paired) {
