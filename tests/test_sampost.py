@@ -299,3 +299,24 @@ def test_route_by_chr_matches_the_rule(genome, lib):
             assert all(len(g) > 0 for g in got), [len(g) for g in got]   # every contig, discordant and unmapped are exercised
             assert sum(len(g) for g in got) == len(text) + len(got[len(names)])
     assert lib.mi355x_route_by_chr(b"only\tone\n", 9, ref.bns, 0, (C.c_void_p * (len(names) + 1))(), (C.c_size_t * (len(names) + 1))()) == -1
+
+
+def test_fixmate_on_the_committed_vectors_of_the_reference(lib, tmp_path):
+    """tests/golden/fixmate_cases.json.gz: 288 pairs (default, -M, -a) as the reference's mem_process_seqs wrote them on the golden genome
+    and what the reference's fixmate() made of each (tools/make_golden_fixmate.py) — needs neither /root/reference nor oracle/_ref."""
+    import json
+    from golden_util import G, golden_index
+    from mpibwa_amd import api
+    eng = api.Engine(golden_index(tmp_path), upload=False)
+    gold = json.load(gzip.open(os.path.join(G, "fixmate_cases.json.gz"), "rt"))
+    assert gold["contigs"] == [eng.bns.contents.anns[i].name.decode() for i in range(eng.bns.contents.n_seqs)]
+    kinds = set()
+    for c in gold["cases"]:
+        pr = _Pair(c["name"].encode(), c["in"][0].encode(), c["in"][1].encode())
+        n = lib.mi355x_fixmate_pair(C.byref(pr.arr[0]), C.byref(pr.arr[1]), eng.bns)
+        assert n == c["in"][0].count("\n") + c["in"][1].count("\n")
+        assert [t.decode() for t in pr.take()] == c["out"], (c["opt"], c["name"])
+        for ln in (c["in"][0] + c["in"][1]).splitlines():
+            fl = int(ln.split("\t")[1])
+            kinds.add("supp" if fl & 0x800 else "sec" if fl & 0x100 else "both_un" if (fl & 12) == 12 else "one_un" if fl & 12 else "other" if ln.split("\t")[6] != "=" else "pair")
+    assert kinds == {"supp", "sec", "both_un", "one_un", "other", "pair"}
