@@ -60,7 +60,22 @@ def build(force=False, verbose=False):
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
     build_driver(force=force, verbose=verbose)
+    build_idx_tool(force=force, verbose=verbose)
     return OUT
+
+
+def build_idx_tool(force=False, verbose=False):
+    """mpibwa_amd/mpibwa_idx: the counterpart of the reference's mpiBWAIdx (driver/mpibwa_idx.c): REF.fa.map from the bwa index files,
+    --build for the files themselves.  Plain C on include/mpibwa_amd.h, no MPI."""
+    src = os.path.join(HERE, "driver", "mpibwa_idx.c")
+    exe = os.path.join(HERE, "mpibwa_idx")
+    if force or _stale(exe, [src, OUT, os.path.join(HERE, "..", "include", "mpibwa_amd.h")]):
+        cmd = ["gcc", "-O2", "-std=gnu99", "-Wall", "-I", os.path.join(HERE, "..", "include"), src, "-o", exe, "-L", HERE, "-lmpibwa_amd",
+               "-Wl,-rpath,/usr/lib/x86_64-linux-gnu:$ORIGIN", "-Wl,-rpath-link,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return exe
 
 
 def build_driver(force=False, verbose=False):

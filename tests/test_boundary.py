@@ -221,3 +221,44 @@ def test_declared_symbols_are_exported(built):
     for n in sorted(names):
         getattr(lib, n)
     assert set(api.EXPORTS) <= names | {"bwa_verbose", "bwa_rg_id"}
+
+
+IDX_TOOL = os.path.join(ROOT, "mpibwa_amd", "mpibwa_idx")
+REF_IDX_TOOL = os.path.join(ROOT, "oracle", "_ref", "mpiBWAIdx_ref")
+
+
+def test_mpibwa_idx_writes_the_image_of_the_reference_mpibwaidx_program(built, tmp_path):
+    """mpibwa_amd/mpibwa_idx (driver/mpibwa_idx.c), the counterpart of the reference's third program: on the reference's example genome
+    its REF.fa.map is the file the reference's own mpiBWAIdx (src/pidx.c compiled in place, oracle/_ref/mpiBWAIdx_ref) writes — the heap
+    addresses the packing process leaves in the pointer fields aside — and --build makes the five bwa files of the example from the FASTA,
+    byte for byte."""
+    import hashlib
+    import tarfile
+    assert os.path.exists(IDX_TOOL)
+    for who in ("own", "ref", "built"):
+        os.makedirs(tmp_path / who)
+        with tarfile.open(os.path.join(ROOT, "tests", "golden", "mpibwa_examples", "hg19.small.tar.gz")) as t:
+            t.extractall(tmp_path / who)
+    env = dict(os.environ)
+    env.pop("LD_LIBRARY_PATH", None)
+    fa = lambda who: str(tmp_path / who / "hg19.small.fa")
+    r = subprocess.run([IDX_TOOL, fa("own")], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    own = np.fromfile(fa("own") + ".map", dtype=np.uint8)
+    if os.path.exists(REF_IDX_TOOL):
+        r = subprocess.run([REF_IDX_TOOL, fa("ref")], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        theirs = np.fromfile(fa("ref") + ".map", dtype=np.uint8)
+        assert len(own) == len(theirs) and (_scrub(own, None) == _scrub(theirs, None)).all()
+        assert (own != theirs).sum() <= 8 * (5 + 2)   # (bwt, sa, anns, ambs, fp_pac and one contig's name / anno pointers)
+    # --build: the index files from the FASTA alone
+    shipped = {}
+    for ext in ("amb", "ann", "bwt", "pac", "sa"):
+        shipped[ext] = hashlib.md5(open(fa("built") + "." + ext, "rb").read()).hexdigest()
+        os.remove(fa("built") + "." + ext)
+    r = subprocess.run([IDX_TOOL, "--build", fa("built")], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    for ext, md5 in shipped.items():
+        assert hashlib.md5(open(fa("built") + "." + ext, "rb").read()).hexdigest() == md5, ext
+    assert (_scrub(np.fromfile(fa("built") + ".map", dtype=np.uint8), None) == _scrub(own, None)).all()
+    assert subprocess.run([IDX_TOOL], capture_output=True, env=env).returncode == 1
