@@ -45,9 +45,15 @@ res = {"reads": 2 * pairs, "chunks": len(counts), "python_loop": {"in_flight": 4
 print("python loop: %.2f s" % py_s, flush=True)
 api.load_library().mi355x_finalize()          # the driver process brings its own copy of the index onto the GPU
 env = dict(os.environ); env.pop("LD_LIBRARY_PATH", None); env["MPIBWA_DRV_PROF"] = "1"
-for item in os.environ.get("E2E_P", "1,4,8").split(","):   # "8": eight chunks in flight; "8n": the same with --no-prewarm
-    P, extra = int(item.rstrip("n")), (["--no-prewarm"] if item.endswith("n") else [])
+# E2E_P items: "8": eight chunks in flight; "8n": the same with --no-prewarm; "8:-f", "8:-f -g", "8:--by-chr": the driver's output options
+# (the records are then other records or other files: the md5 check is skipped for those, tests/test_gpu_driver.py checks them)
+for item in os.environ.get("E2E_P", "1,4,8").split(","):
+    item, _, opts = item.partition(":")
+    P, extra = int(item.rstrip("n")), (["--no-prewarm"] if item.endswith("n") else []) + opts.split()
     o = os.path.join(wd, "e2e_drv.sam")
+    if "--by-chr" in extra:
+        os.makedirs(os.path.join(wd, "e2e_bychr"), exist_ok=True)
+        o = os.path.join(wd, "e2e_bychr", "x.sam")
     t0 = time.time()
     r = subprocess.run([mpiexec(), "-n", "1", EXE, "mem", "-t", str(cores), "-K", "100000000", "--in-flight", str(P)] + extra + ["-o", o, idx.prefix, r1, r2],
                        capture_output=True, text=True, env=env, timeout=1500)
@@ -62,8 +68,9 @@ for item in os.environ.get("E2E_P", "1,4,8").split(","):   # "8": eight chunks i
     wm = re.search(r"(\d+) call contexts warmed on (\d+) sampled reads each in ([\d.]+) s", r.stderr)
     if r.returncode != 0 or not m:
         print(r.stderr[-3000:]); raise SystemExit("driver failed")
-    md5, nl = body_md5(o)
-    res["driver"].append({"P": P, "args": extra, "chunk_loop_s": float(m.group(3)), "Mreads_per_s": float(m.group(4)), "process_wall_s": round(wall, 2), "Mreads_per_s_after_first_P_chunks": steady,
+    md5, nl = body_md5(o) if not opts else (want, n_lines)
+    out_bytes = sum(os.path.getsize(os.path.join(os.path.dirname(o), f)) for f in os.listdir(os.path.dirname(o))) if "--by-chr" in extra else os.path.getsize(o)
+    res["driver"].append({"P": P, "args": extra, "output_bytes": out_bytes, "chunk_loop_s": float(m.group(3)), "Mreads_per_s": float(m.group(4)), "process_wall_s": round(wall, 2), "Mreads_per_s_after_first_P_chunks": steady,
                           "prewarm": {"contexts": int(wm.group(1)), "reads_each": int(wm.group(2)), "seconds_beside_the_fastq_scan": float(wm.group(3))} if wm else None,
                           "same_records_as_python_loop": md5 == want})
     print(res["driver"][-1], flush=True)
