@@ -1,6 +1,6 @@
 /* mpibwa_gpu.c — a thin MPI host program around the C ABI of libmpibwa_amd.so: one rank per GPU,
  *
- *     mpiexec -n N mpibwa_gpu mem [bwa mem options] [-f] [-g | -b] [--by-chr] [-K bases] [--in-flight chunks] [--no-prewarm] [--dry-run] -o OUT PREFIX R1.fastq [R2.fastq]
+ *     mpiexec -n N mpibwa_gpu mem [bwa mem options] [-f] [-g | -b] [--by-chr] [--ordered] [-K bases] [--in-flight chunks] [--no-prewarm] [--dry-run] -o OUT PREFIX R1.fastq [R2.fastq]
  *
  * The `mem` options are the reference's (src/mainParallel.c:291-398: -k -w -A -B -O -E -L -U -T -c -d -r -D -m -s -G -N -W -y -X -h -Q -I -R -H
  * -P -a -M -S -Y -V -5 -q -j -C -v -t -K -o, and its output options -f (fixmate, :395), -g (BGZF, :299), -b (BGZF + EOF block under the
@@ -200,6 +200,10 @@ typedef struct {
 	int serialize;               /* MPI_THREAD_SERIALIZED: one thread inside MPI at a time */
 	pthread_mutex_t mpi_mu, fetch_mu, write_mu;
 	int64_t n_fetched;           /* reads of the chunks this rank has taken so far (trimmed pairs: n_processed) */
+	int ordered;                 /* --ordered: a rank's chunks reach the file(s) in the order the rank took them */
+	int64_t tickets, now_writing;   /* chunks this rank has taken / the ticket whose turn it is to write */
+	pthread_mutex_t turn_mu;
+	pthread_cond_t turn_cv;
 	double t_start;
 } loop_t;
 
@@ -307,6 +311,7 @@ static void *chunk_worker(void *arg)
 		const int n = (int)(count * (paired ? 2 : 1));
 		n_before = L->n_fetched;
 		L->n_fetched += n;
+		const int64_t ticket = L->tickets++;
 		pthread_mutex_unlock(&L->fetch_mu);
 		const double t0 = MPI_Wtime();
 		int64_t len1 = tab[3 * (c + 1) + 1] - tab[3 * c + 1], len2 = paired ? tab[3 * (c + 1) + 2] - tab[3 * c + 2] : 0;
@@ -339,13 +344,25 @@ static void *chunk_worker(void *arg)
 		const size_t sam_len = mi355x_collect_sam_into(seqs, n, &sam, &csam);
 		const double t4 = MPI_Wtime();
 		/* Chunks are written as their workers finish them: with --in-flight > 1 the records of a file are not in input order (the
-		 * reference's are not across ranks either). */
+		 * reference's are not across ranks either).  --ordered: a worker waits until the chunks this rank took before its own are
+		 * written — one rank then writes the file the reference's blocking loop writes, whatever the number of chunks in flight. */
+		if (L->ordered) {
+			pthread_mutex_lock(&L->turn_mu);
+			while (L->now_writing != ticket) pthread_cond_wait(&L->turn_cv, &L->turn_mu);
+			pthread_mutex_unlock(&L->turn_mu);
+		}
 		if (!L->by_chr) write_text(L, L->out, sam, sam_len, &zbuf, &czbuf);
 		else {   /* every record to the file of its contig, pairs on two contigs to "discordant" as well, RNAME '*' to "unmapped" */
 			const int64_t r = mi355x_route_by_chr(sam, sam_len, L->idx->bns, L->n_dest == L->idx->bns->n_seqs + 2, dtext, dlen);
 			if (r < 0) DIE("chunk %lld: a SAM line without RNAME at byte %lld", c, (long long)(-r - 1));
 			for (int d = 0; d < L->n_dest; ++d)
 				if (dtext[d]) { write_text(L, L->dest[d], dtext[d], dlen[d], &zbuf, &czbuf); free(dtext[d]); dtext[d] = 0; }
+		}
+		if (L->ordered) {
+			pthread_mutex_lock(&L->turn_mu);
+			++L->now_writing;
+			pthread_cond_broadcast(&L->turn_cv);
+			pthread_mutex_unlock(&L->turn_mu);
 		}
 		if (prof)
 			fprintf(stderr, "[mpibwa_gpu] chunk %lld done at %.3f: read %.0f  scan+fill %.0f  align %.0f  fixmate %.0f  collect %.0f  write %.0f ms\n", c, MPI_Wtime() - L->t_start,
@@ -363,12 +380,13 @@ int main(int argc, char **argv)
 	MPI_Comm_size(MPI_COMM_WORLD, &g_size);
 	int n_threads = 0, copy_comment = 0, dry = 0, n_workers = 6, prewarm = 1;
 	int dofixmate = 0, write_format = 2, compression_level = 3, by_chr = 0;   /* src/mainParallel.c:223-227 */
+	int ordered = 0;
 	int scale_a = 0, set_b = 0, set_T = 0, set_U = 0, set_d = 0, set_O = 0, set_E = 0, set_L = 0;
 	int64_t K = 0;
 	const char *out_path = 0, *pos[4];
 	int n_pos = 0;
 	if (argc < 2 || strcmp(argv[1], "mem") != 0) {
-		if (g_rank == 0) fprintf(stderr, "usage: mpiexec -n N %s mem [bwa mem options] [-f] [-g | -b] [--by-chr] [-K bases] [--in-flight chunks] [--no-prewarm] [--dry-run] -o OUT PREFIX R1.fastq [R2.fastq]\n", argv[0]);
+		if (g_rank == 0) fprintf(stderr, "usage: mpiexec -n N %s mem [bwa mem options] [-f] [-g | -b] [--by-chr] [--ordered] [-K bases] [--in-flight chunks] [--no-prewarm] [--dry-run] -o OUT PREFIX R1.fastq [R2.fastq]\n", argv[0]);
 		MPI_Finalize();
 		return 1;
 	}
@@ -383,6 +401,7 @@ int main(int argc, char **argv)
 		if (!strcmp(a, "--dry-run")) { dry = 1; continue; }
 		if (!strcmp(a, "--no-prewarm")) { prewarm = 0; continue; }
 		if (!strcmp(a, "--by-chr")) { by_chr = 1; continue; }
+		if (!strcmp(a, "--ordered")) { ordered = 1; continue; }
 		if (!strcmp(a, "--level") && i + 1 < argc) { compression_level = atoi(argv[++i]); continue; }
 		if (!strcmp(a, "--in-flight") && i + 1 < argc) { n_workers = atoi(argv[++i]); continue; }
 		if (a[0] != '-' || !a[1]) { if (n_pos < 3) pos[n_pos++] = a; continue; }
@@ -682,6 +701,9 @@ int main(int argc, char **argv)
 	L.t_start = t_loop;
 	pthread_mutex_init(&L.mpi_mu, 0);
 	pthread_mutex_init(&L.fetch_mu, 0);
+	L.ordered = ordered;
+	pthread_mutex_init(&L.turn_mu, 0);
+	pthread_cond_init(&L.turn_cv, 0);
 	pthread_mutex_init(&L.write_mu, 0);
 	pthread_t th[MAX_WORKERS];
 	for (int w = 1; w < n_workers; ++w)

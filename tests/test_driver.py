@@ -151,6 +151,14 @@ def test_fixmate_and_by_chromosome_files_are_those_of_the_reference_programs(shi
     plain = _records(os.path.join(d, "ref_plain.sam"))
     run(EXE, ["-o", os.path.join(d, "own_plain.sam")])
     assert _records(os.path.join(d, "own_plain.sam")) == plain and len(plain) > 6000
+    # --ordered: one rank with four chunks in flight writes the file one chunk in flight writes (record for record, unsorted)
+    bodies = []
+    for extra in (["--in-flight", "1"], ["--in-flight", "4", "--ordered"]):
+        o = os.path.join(d, "own_%s.sam" % extra[1])
+        r = subprocess.run([mpiexec(), "-n", "1", EXE, "mem", "-K", "100000"] + extra + ["-o", o, prefix] + fq, capture_output=True, text=True, timeout=900, env=env, cwd=d)
+        assert r.returncode == 0, r.stderr[-3000:]
+        bodies.append([ln for ln in open(o, "rb").read().splitlines(keepends=True) if not ln.startswith(b"@")])
+    assert bodies[0] == bodies[1] and len(bodies[0]) > 6000
     # -f
     run(REF_MAIN, ["-f", "-o", os.path.join(d, "ref_f")])
     run(EXE, ["-f", "-o", os.path.join(d, "own_f.sam")])
