@@ -268,19 +268,12 @@ static void write_text(loop_t *L, MPI_File fh, const char *text, size_t len, voi
 }
 
 /* the header as the file's first bytes (rank 0, before the file is opened by everybody): text, or BGZF blocks of it
- * (create_sam_header / create_bam_header, src/parallel_aux.c:1846-2026) */
-static void create_with_header(const char *path, const char *hdr, size_t hdr_len, int format, int level)
+ * (create_sam_header / create_bam_header, src/parallel_aux.c:1846-2026); `bytes` is what goes into the file, made once for all files */
+static void create_with_header(const char *path, const void *bytes, size_t n)
 {
 	FILE *fp = fopen(path, "w");
 	if (!fp) DIE("cannot create %s", path);
-	if (hdr_len && format == 2) fwrite(hdr, 1, hdr_len, fp);
-	else if (hdr_len) {
-		const size_t cap = mi355x_bgzf_bound(hdr_len);
-		uint8_t *z = malloc(cap);
-		const size_t n = mi355x_bgzf_compress(hdr, hdr_len, level, z, cap);
-		fwrite(z, 1, n, fp);
-		free(z);
-	}
+	if (n && fwrite(bytes, 1, n, fp) != n) DIE("cannot write %s", path);
 	if (fclose(fp) != 0) DIE("cannot write %s", path);
 }
 
@@ -655,8 +648,18 @@ int main(int argc, char **argv)
 	}
 	MPI_File out = MPI_FILE_NULL, *dest = 0;
 	int n_dest = 0;
+	/* what a file starts with: the header text, or its BGZF blocks (made once, however many files there are) */
+	const void *hdr_bytes = hdr;
+	size_t hdr_n = hdr_len;
+	uint8_t *hdr_z = 0;
+	if (write_format != 2 && g_rank == 0) {
+		const size_t cap = mi355x_bgzf_bound(hdr_len);
+		hdr_z = malloc(cap);
+		hdr_n = mi355x_bgzf_compress(hdr, hdr_len, compression_level, hdr_z, cap);
+		hdr_bytes = hdr_z;
+	}
 	if (!by_chr) {
-		if (g_rank == 0) create_with_header(out_path, hdr, hdr_len, write_format, compression_level);
+		if (g_rank == 0) create_with_header(out_path, hdr_bytes, hdr_n);
 		MPI_Barrier(MPI_COMM_WORLD);
 		MPI_OK(MPI_File_open(MPI_COMM_WORLD, (char *)out_path, MPI_MODE_WRONLY | MPI_MODE_APPEND, MPI_INFO_NULL, &out));
 	} else {
@@ -673,17 +676,22 @@ int main(int argc, char **argv)
 		n_dest = idx->bns->n_seqs + 1 + disc;
 		dest = malloc(sizeof(MPI_File) * (size_t)n_dest);
 		const char *ext = write_format == 2 ? "sam" : write_format == 1 ? "bam" : "gz";
+		char **paths = malloc(sizeof(char *) * (size_t)n_dest);
 		for (int d = 0; d < n_dest; ++d) {
 			const char *nm = d < idx->bns->n_seqs ? idx->bns->anns[d].name : (disc && d == idx->bns->n_seqs) ? "discordant" : "unmapped";
-			char *path = malloc(strlen(dir) + strlen(nm) + 8);
-			sprintf(path, "%s/%s.%s", dir, nm, ext);
-			if (g_rank == 0) create_with_header(path, hdr, d < idx->bns->n_seqs || write_format != 2 ? hdr_len : 0, write_format, compression_level);
-			MPI_Barrier(MPI_COMM_WORLD);
-			MPI_OK(MPI_File_open(MPI_COMM_WORLD, path, MPI_MODE_WRONLY | MPI_MODE_APPEND, MPI_INFO_NULL, &dest[d]));
-			free(path);
+			paths[d] = malloc(strlen(dir) + strlen(nm) + 8);
+			sprintf(paths[d], "%s/%s.%s", dir, nm, ext);
+			if (g_rank == 0) create_with_header(paths[d], hdr_bytes, d < idx->bns->n_seqs || write_format != 2 ? hdr_n : 0);
 		}
+		MPI_Barrier(MPI_COMM_WORLD);
+		for (int d = 0; d < n_dest; ++d) {
+			MPI_OK(MPI_File_open(MPI_COMM_WORLD, paths[d], MPI_MODE_WRONLY | MPI_MODE_APPEND, MPI_INFO_NULL, &dest[d]));
+			free(paths[d]);
+		}
+		free(paths);
 		free(dir);
 	}
+	free(hdr_z);
 
 	/* ---- the chunk loop: next chunk by fetch-and-add on rank 0's counter ---- */
 	long long *counter_mem = 0;
