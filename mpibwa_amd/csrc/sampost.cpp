@@ -204,7 +204,7 @@ bool split_lines(const bseq1_t &s, const ContigIndex &ci, std::vector<Rec> &recs
 		const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
 		if (!nl) break;   // (the reference's line reader stops at text without a newline too: src/fixmate.c:301-315)
 		Rec r;
-		r.name = s.name;
+		r.name = s.name ? s.name : "";
 		if (!parse_line(p, nl, nl + 1, ci, r)) return false;
 		recs.push_back(r);
 		++n_lines;
