@@ -344,6 +344,13 @@ void mi355x_last_stats(mi355x_stats_t *st);
 void mi355x_host_ksw_align2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat, int o_del,
                             int e_del, int o_ins, int e_ins, int xtra, int portable, int out7[7]);
 
+/* host-logic test hook (no GPU involved): mem_sam_pe (src/bwamem_pair.c:250-393) as the library's host path runs it — the path of the
+ * pairs the pairing kernel leaves to the host: rescue loop, more than eight hits per end, XA, supplementary lines — on the regions of the
+ * two ends given as the reference's own mem_alnreg_t records (88 bytes each, src/bwamem.h:59-77; what mem_align1_core returns).
+ * s[k].seq: nt4 codes; s[k].sam is set.  Returns the number of rescued hits. */
+int   mi355x_host_sam_pe(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, const mem_pestat_t pes[4], uint64_t id, bseq1_t s[2],
+                         const void *regs0, int n0, const void *regs1, int n1);
+
 /* CPUs usable by this process (cgroup quota aware) — what the host stages are sized to. */
 int   mi355x_host_cpus(void);
 /* Caller-side convenience equal to mpiBWA's copy_buffer_thr (src/mainParallel.c:103-127): concatenates

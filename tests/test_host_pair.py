@@ -1,0 +1,130 @@
+"""The library's HOST path of mem_sam_pe (csrc/host_pair.cpp, host_regs.cpp, host_ksw.cpp: the path of every pair the pairing kernel leaves
+to the host — mate rescue, more than eight hits per end, XA, supplementary and secondary lines, -a / -5 / -P runs) against the reference's
+own mem_sam_pe, pair by pair, on the CPU: the regions of both ends come from the reference's mem_align1_core, the insert-size statistics
+from its mem_pestat, and both sides turn the same regions into SAM text — the reference through mem_sam_pe (src/bwamem_pair.c:250-393),
+the library through mi355x_host_sam_pe.  The genome is a third repeats, so that reads carry many regions and the rescue loop runs with
+several candidates per end; the reads include pairs on two contigs, unmapped and chimeric mates.  No GPU involved."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.skipif(not po.ref_available(), reason="oracle/_ref/libbwaref.so not built")
+
+
+class _alnreg_v(C.Structure):   # mem_alnreg_v (src/bwamem.h:79)
+    _fields_ = [("n", C.c_size_t), ("m", C.c_size_t), ("a", C.c_void_p)]
+
+
+@pytest.fixture(scope="module")
+def repeat_genome(tmp_path_factory, built):
+    from mpibwa_amd import api, simulate
+    d = tmp_path_factory.mktemp("repeat_genome")
+    names, seqs = simulate.make_genome(240_000, 3, seed=17, repeat_frac=0.35)
+    fa = str(d / "r.fa")
+    simulate.write_fasta(fa, names, seqs)
+    api.build_index(fa, fa)
+    return {"prefix": fa, "names": names, "seqs": seqs}
+
+
+def _batch(ref, lib_ref, opt, reads):
+    """phase 1 of the reference for every read: regions (mem_align1_core), reads as nt4 codes, the chunk's mem_pestat"""
+    from mpibwa_amd import abi
+    lib_ref.mem_align1_core.restype = _alnreg_v
+    lib_ref.mem_align1_core.argtypes = [C.POINTER(abi.mem_opt_t), C.POINTER(abi.bwt_t), C.POINTER(abi.bntseq_t), C.POINTER(C.c_uint8), C.c_int, C.c_char_p, C.c_void_p]
+    lib_ref.mem_pestat.restype = None
+    lib_ref.mem_pestat.argtypes = [C.POINTER(abi.mem_opt_t), C.c_int64, C.c_int, C.POINTER(_alnreg_v), C.POINTER(abi.mem_pestat_t)]
+    n = 2 * len(reads)
+    regs = (_alnreg_v * n)()
+    seqs = []
+    for p, (name, s1, s2) in enumerate(reads):
+        for k, sq in enumerate((s1, s2)):
+            buf = C.create_string_buffer(sq, len(sq) + 1)          # ASCII in, nt4 codes out (src/bwamem.c:1057-1058)
+            regs[2 * p + k] = lib_ref.mem_align1_core(opt, ref.bwt, ref.bns, ref.pac, len(sq), buf, None)
+            seqs.append(buf)
+    pes = (abi.mem_pestat_t * 4)()
+    lib_ref.mem_pestat(opt, ref.bns.contents.l_pac, n, regs, pes)
+    return regs, seqs, pes
+
+
+def _regs_copy(v):
+    if not v.n:
+        return np.zeros(0, dtype=po.ALNREG_DT)
+    return np.ctypeslib.as_array(C.cast(v.a, C.POINTER(C.c_uint8)), shape=(v.n * 88,)).view(po.ALNREG_DT).copy()
+
+
+CASES = [
+    dict(),
+    dict(flag_add="MEM_F_NO_MULTI"),
+    dict(flag_add="MEM_F_ALL"),
+    dict(flag_add="MEM_F_SOFTCLIP"),
+    dict(flag_add="MEM_F_PRIMARY5|MEM_F_KEEP_SUPP_MAPQ"),
+    dict(flag_add="MEM_F_NO_RESCUE"),
+    dict(flag_add="MEM_F_NOPAIRING"),
+    dict(max_matesw=3, pen_unpaired=9, max_XA_hits=2, max_XA_hits_alt=4, XA_drop_ratio=0.6),
+    dict(a=2, b=5, o_del=8, e_del=2, o_ins=7, e_ins=3, T=50, pen_clip5=8, pen_clip3=6, zdrop=150),
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_host_sam_pe_matches_the_reference_mem_sam_pe(repeat_genome, case):
+    from mpibwa_amd import abi, api, simulate
+    from test_sampost import _pairs_of_every_kind
+    lib = api.load_library()
+    lib_ref = po.ref_lib()
+    lib_ref.mem_sam_pe.restype = C.c_int
+    lib_ref.mem_sam_pe.argtypes = [C.POINTER(abi.mem_opt_t), C.POINTER(abi.bntseq_t), C.POINTER(C.c_uint8), C.POINTER(abi.mem_pestat_t), C.c_uint64,
+                                   C.POINTER(abi.bseq1_t), C.POINTER(_alnreg_v)]
+    ref = po.RefIndex(repeat_genome["prefix"])
+    kw = dict(CASES[case])
+    flag = abi.MEM_F_PE
+    for f in kw.pop("flag_add", "").split("|"):
+        if f:
+            flag |= getattr(abi, f)
+    opt = ref.opt(flag=flag, **kw)
+    if "a" in kw:
+        lib_ref.bwa_fill_scmat(kw["a"], kw["b"], opt.contents.mat)
+    reads = simulate.reads_to_ascii(_pairs_of_every_kind(repeat_genome, n=360, seed=40 + case))
+    regs, seqs, pes = _batch(ref, lib_ref, opt, reads)
+    libc = api.libc
+    n_rescued = n_many = n_xa = n_supp = n_lines = 0
+    for p, (name, _, _) in enumerate(reads):
+        nm = C.create_string_buffer(name.encode())
+        qual = [C.create_string_buffer(bytes((33 + (7 * i + p) % 40 for i in range(len(seqs[2 * p + k]) - 1)))) for k in range(2)]
+        copies = [_regs_copy(regs[2 * p + k]) for k in range(2)]
+        texts = []
+        for who in ("ref", "own"):
+            s = (abi.bseq1_t * 2)()
+            for k in range(2):
+                s[k].l_seq = len(seqs[2 * p + k]) - 1
+                s[k].name = C.addressof(nm)
+                s[k].seq = C.addressof(seqs[2 * p + k])
+                s[k].qual = C.addressof(qual[k])
+            if who == "ref":
+                a = (_alnreg_v * 2)(regs[2 * p], regs[2 * p + 1])
+                r = lib_ref.mem_sam_pe(opt, ref.bns, ref.pac, pes, p, s, a)
+                for k in range(2):   # (mem_sam_pe may have moved the arrays: they are freed through what it left)
+                    regs[2 * p + k] = a[k]
+            else:
+                r = lib.mi355x_host_sam_pe(opt, ref.bns, C.cast(ref.pac, C.c_void_p), C.cast(pes, C.c_void_p), p, s, copies[0].ctypes.data, len(copies[0]),
+                                           copies[1].ctypes.data, len(copies[1]))
+            t = []
+            for k in range(2):
+                t.append(C.string_at(s[k].sam))
+                libc.free(C.c_void_p(s[k].sam))
+            texts.append((r, t))
+        assert texts[0] == texts[1], (case, name, [len(c) for c in copies])
+        n_rescued += texts[0][0]
+        n_many += len(copies[0]) > 8 or len(copies[1]) > 8
+        both = texts[0][1][0] + texts[0][1][1]
+        n_xa += both.count(b"\tXA:Z:")
+        n_supp += sum(int(ln.split(b"\t")[1]) & 0x900 != 0 for ln in both.splitlines())
+        n_lines += both.count(b"\n")
+    for v in regs:
+        libc.free(C.c_void_p(v.a))
+    # the cases are the ones the kernel leaves to the host
+    if not flag & (abi.MEM_F_NO_RESCUE | abi.MEM_F_NOPAIRING):
+        assert n_rescued > 20, n_rescued
+    assert n_many > 20 and n_lines >= 2 * len(reads) and n_xa + n_supp > 40, (n_rescued, n_many, n_xa, n_supp, n_lines)
