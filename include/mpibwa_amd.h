@@ -350,6 +350,11 @@ void mi355x_host_ksw_align2(int qlen, const uint8_t *query, int tlen, const uint
  * s[k].seq: nt4 codes; s[k].sam is set.  Returns the number of rescued hits. */
 int   mi355x_host_sam_pe(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, const mem_pestat_t pes[4], uint64_t id, bseq1_t s[2],
                          const void *regs0, int n0, const void *regs1, int n1);
+/* the same kind of hook for mem_sort_dedup_patch (src/bwamem.c:437-489; the regions of one read as mem_chain2aln leaves them, kept ones
+ * written back in their new order, their number returned; query: nt4 codes) and for the single-end half of worker2 (src/bwamem.c:
+ * 1187-1203: mem_mark_primary_se with id, mem_reorder_primary5 under -5, mem_reg2sam; s->sam is set) */
+int   mi355x_host_sort_dedup_patch(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, uint8_t *query, void *regs, int n);
+void  mi355x_host_reg2sam_se(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, bseq1_t *s, const void *regs, int n, int64_t id);
 
 /* CPUs usable by this process (cgroup quota aware) — what the host stages are sized to. */
 int   mi355x_host_cpus(void);

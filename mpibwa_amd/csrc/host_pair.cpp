@@ -632,34 +632,76 @@ int sam_pe(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, const 
 
 } // namespace mbw
 
-// host-logic test hook (no GPU involved): mem_sam_pe (src/bwamem_pair.c:250-393) as the library's host path runs it — the rescue loop with
-// the host's ksw_align2, mem_mark_primary_se, mem_pair, the MAPQ arithmetic, mem_reg2sam with the host's global alignment — on the two ends'
-// regions given as the reference's own mem_alnreg_t records (88 bytes: src/bwamem.h:59-77), i.e. what the reference's mem_align1_core
-// returns.  s[k].seq holds nt4 codes; s[k].sam is set (malloc family).  Returns the number of rescued hits, as the reference does.
+// ---- host-logic test hooks (no GPU involved): the library's host stages on the reference's own records ----
+namespace {
+struct Ref88 {   // mem_alnreg_t as the reference lays it out (src/bwamem.h:59-77)
+	int64_t rb, re;
+	int32_t qb, qe, rid, score, truesc, sub, alt_sc, csub, sub_n, w, seedcov, secondary, secondary_all, seedlen0;
+	int32_t n_comp_is_alt;   // int n_comp:30, is_alt:2
+	float frac_rep;
+	uint64_t hash;
+};
+static_assert(sizeof(Ref88) == 88, "mem_alnreg_t is 88 bytes");
+void regs_in(const void *regs, int n, mbw::HRegV &v)
+{
+	const Ref88 *r = (const Ref88 *)regs;
+	for (int j = 0; j < n; ++j) {
+		const Ref88 &x = r[j];
+		mbw::HReg h;
+		h.rb = x.rb; h.re = x.re; h.qb = x.qb; h.qe = x.qe; h.rid = x.rid; h.score = x.score; h.truesc = x.truesc; h.sub = x.sub;
+		h.alt_sc = x.alt_sc; h.csub = x.csub; h.sub_n = x.sub_n; h.w = x.w; h.seedcov = x.seedcov; h.secondary = x.secondary;
+		h.secondary_all = x.secondary_all; h.seedlen0 = x.seedlen0;
+		h.n_comp = (int32_t)((uint32_t)x.n_comp_is_alt << 2) >> 2; h.is_alt = (x.n_comp_is_alt >> 30) & 3;
+		h.frac_rep = x.frac_rep; h.hash = x.hash;
+		v.push_back(h);
+	}
+}
+void regs_out(const mbw::HRegV &v, void *regs)
+{
+	Ref88 *r = (Ref88 *)regs;
+	for (size_t j = 0; j < v.size(); ++j) {
+		const mbw::HReg &h = v[j];
+		Ref88 &x = r[j];
+		x.rb = h.rb; x.re = h.re; x.qb = h.qb; x.qe = h.qe; x.rid = h.rid; x.score = h.score; x.truesc = h.truesc; x.sub = h.sub;
+		x.alt_sc = h.alt_sc; x.csub = h.csub; x.sub_n = h.sub_n; x.w = h.w; x.seedcov = h.seedcov; x.secondary = h.secondary;
+		x.secondary_all = h.secondary_all; x.seedlen0 = h.seedlen0;
+		x.n_comp_is_alt = (int32_t)(((uint32_t)h.n_comp & 0x3fffffffu) | ((uint32_t)h.is_alt & 3u) << 30);
+		x.frac_rep = h.frac_rep; x.hash = h.hash;
+	}
+}
+} // namespace
+
+// mem_sam_pe (src/bwamem_pair.c:250-393) as the library's host path runs it — the rescue loop with the host's ksw_align2,
+// mem_mark_primary_se, mem_pair, the MAPQ arithmetic, mem_reg2sam with the host's global alignment — on the two ends' regions given as the
+// reference's own mem_alnreg_t records, i.e. what the reference's mem_align1_core returns.  s[k].seq holds nt4 codes; s[k].sam is set
+// (malloc family).  Returns the number of rescued hits, as the reference does.
 extern "C" int mi355x_host_sam_pe(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, const mem_pestat_t pes[4], uint64_t id, bseq1_t s[2],
                                   const void *regs0, int n0, const void *regs1, int n1)
 {
-	struct Ref88 {   // mem_alnreg_t as the reference lays it out
-		int64_t rb, re;
-		int32_t qb, qe, rid, score, truesc, sub, alt_sc, csub, sub_n, w, seedcov, secondary, secondary_all, seedlen0;
-		int32_t n_comp_is_alt;   // int n_comp:30, is_alt:2
-		float frac_rep;
-		uint64_t hash;
-	};
-	static_assert(sizeof(Ref88) == 88, "mem_alnreg_t is 88 bytes");
-	const Ref88 *r[2] = {(const Ref88 *)regs0, (const Ref88 *)regs1};
-	const int n[2] = {n0, n1};
 	mbw::HRegV a[2];
-	for (int e = 0; e < 2; ++e)
-		for (int j = 0; j < n[e]; ++j) {
-			const Ref88 &x = r[e][j];
-			mbw::HReg h;
-			h.rb = x.rb; h.re = x.re; h.qb = x.qb; h.qe = x.qe; h.rid = x.rid; h.score = x.score; h.truesc = x.truesc; h.sub = x.sub;
-			h.alt_sc = x.alt_sc; h.csub = x.csub; h.sub_n = x.sub_n; h.w = x.w; h.seedcov = x.seedcov; h.secondary = x.secondary;
-			h.secondary_all = x.secondary_all; h.seedlen0 = x.seedlen0;
-			h.n_comp = (int32_t)((uint32_t)x.n_comp_is_alt << 2) >> 2; h.is_alt = (x.n_comp_is_alt >> 30) & 3;
-			h.frac_rep = x.frac_rep; h.hash = x.hash;
-			a[e].push_back(h);
-		}
+	regs_in(regs0, n0, a[0]);
+	regs_in(regs1, n1, a[1]);
 	return mbw::sam_pe(opt, bns, pac, pes, id, s, a);
+}
+
+// mem_sort_dedup_patch (src/bwamem.c:437-489, with mem_patch_reg :406-435) on the n regions mem_chain2aln left for one read (query: nt4
+// codes); the kept regions are written back to regs in their new order.  Returns their number.
+extern "C" int mi355x_host_sort_dedup_patch(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, uint8_t *query, void *regs, int n)
+{
+	mbw::HRegV v;
+	regs_in(regs, n, v);
+	const int m = mbw::sort_dedup_patch(opt, bns, pac, query, v);
+	regs_out(v, regs);
+	return m;
+}
+
+// the single-end half of worker2 (src/bwamem.c:1187-1203): mem_mark_primary_se with id, mem_reorder_primary5 under -5, mem_reg2sam.
+// s->seq: nt4 codes; s->sam is set.
+extern "C" void mi355x_host_reg2sam_se(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, bseq1_t *s, const void *regs, int n, int64_t id)
+{
+	mbw::HRegV v;
+	regs_in(regs, n, v);
+	mbw::mark_primary_se(opt, v, id);
+	if (opt->flag & MEM_F_PRIMARY5) mbw::reorder_primary5(opt->T, v);
+	mbw::reg2sam(opt, bns, pac, s, v, 0, nullptr);
 }

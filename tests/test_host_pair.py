@@ -128,3 +128,133 @@ def test_host_sam_pe_matches_the_reference_mem_sam_pe(repeat_genome, case):
     if not flag & (abi.MEM_F_NO_RESCUE | abi.MEM_F_NOPAIRING):
         assert n_rescued > 20, n_rescued
     assert n_many > 20 and n_lines >= 2 * len(reads) and n_xa + n_supp > 40, (n_rescued, n_many, n_xa, n_supp, n_lines)
+
+
+class _chain_v(C.Structure):   # mem_chain_v (src/bwamem.c:180)
+    _fields_ = [("n", C.c_size_t), ("m", C.c_size_t), ("a", C.c_void_p)]
+
+
+CHAIN_T_BYTES = 40   # mem_chain_t (src/bwamem.c:174-179): n, m, first, rid, w:29|kept:2|is_alt:1, frac_rep, pos, seeds*
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(a=2, b=5, o_del=8, e_del=2, o_ins=7, e_ins=3, T=50, zdrop=150), dict(mask_level_redun=0.8, w=40),
+                                dict(flag_add="MEM_F_PRIMARY5|MEM_F_KEEP_SUPP_MAPQ", T=20), dict(flag_add="MEM_F_ALL", max_XA_hits=3)])
+def test_host_dedup_patch_and_single_end_records_match_the_reference(repeat_genome, kw):
+    """mem_sort_dedup_patch with its patch alignments (src/bwamem.c:406-489) and the single-end half of worker2 (mem_mark_primary_se,
+    mem_reorder_primary5, mem_reg2sam with XA / SA / supplementary lines: src/bwamem.c:521-569, 978-1048) of the library's host path against
+    the reference's own functions: the regions come from the reference's mem_chain -> mem_chain_flt -> mem_flt_chained_seeds ->
+    mem_chain2aln, are copied, and go through both.  Reads of 150-400 bp built from two or three pieces a few bases apart on the genome,
+    from chimeric pieces, and — every fifth — from two long pieces a deletion apart that is wider than the band, so that two co-linear regions
+    are there for mem_patch_reg to join."""
+    from mpibwa_amd import abi, api
+    lib = api.load_library()
+    R = po.ref_lib()
+    ref = po.RefIndex(repeat_genome["prefix"])
+    kw = dict(kw)
+    flag = 0
+    for f in kw.pop("flag_add", "").split("|"):
+        if f:
+            flag |= getattr(abi, f)
+    opt = ref.opt(flag=flag, **kw)
+    if "a" in kw:
+        R.bwa_fill_scmat(kw["a"], kw["b"], opt.contents.mat)
+    P_opt, P_bwt, P_bns, P_u8 = C.POINTER(abi.mem_opt_t), C.POINTER(abi.bwt_t), C.POINTER(abi.bntseq_t), C.POINTER(C.c_uint8)
+    R.mem_chain.restype = _chain_v
+    R.mem_chain.argtypes = [P_opt, P_bwt, P_bns, C.c_int, C.c_char_p, C.c_void_p]
+    R.mem_chain_flt.restype = C.c_int
+    R.mem_chain_flt.argtypes = [P_opt, C.c_int, C.c_void_p]
+    R.mem_flt_chained_seeds.restype = None
+    R.mem_flt_chained_seeds.argtypes = [P_opt, P_bns, P_u8, C.c_int, C.c_char_p, C.c_int, C.c_void_p]
+    R.mem_chain2aln.restype = None
+    R.mem_chain2aln.argtypes = [P_opt, P_bns, P_u8, C.c_int, C.c_char_p, C.c_void_p, C.POINTER(_alnreg_v)]
+    R.mem_sort_dedup_patch.restype = C.c_int
+    R.mem_sort_dedup_patch.argtypes = [P_opt, P_bns, P_u8, C.c_char_p, C.c_int, C.c_void_p]
+    R.mem_mark_primary_se.restype = C.c_int
+    R.mem_mark_primary_se.argtypes = [P_opt, C.c_int, C.c_void_p, C.c_int64]
+    R.mem_reorder_primary5.restype = None
+    R.mem_reorder_primary5.argtypes = [C.c_int, C.POINTER(_alnreg_v)]
+    R.mem_reg2sam.restype = None
+    R.mem_reg2sam.argtypes = [P_opt, P_bns, P_u8, C.POINTER(abi.bseq1_t), C.POINTER(_alnreg_v), C.c_int, C.c_void_p]
+    rng = np.random.default_rng(77 + len(kw))
+    seqs = repeat_genome["seqs"]
+    lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    comp = np.array([3, 2, 1, 0, 4], dtype=np.uint8)
+    n_patched = n_dropped = n_multi = n_xa = n_sa = 0
+    for r in range(400):
+        c = int(rng.integers(0, len(seqs)))
+        kind = r % 5
+        w_opt = int(opt.contents.w)
+        if kind == 0:   # two long pieces a deletion apart that neither the chain's band nor an extension crosses, but mem_patch_reg's limits admit
+            gap = w_opt + 1 + int(rng.integers(0, w_opt // 2))
+            ln = int(gap * (11 + 3 * rng.random()))
+            pos = int(rng.integers(0, len(seqs[c]) - 2 * ln - gap - 10))
+            parts = [seqs[c][pos:pos + ln].copy(), seqs[c][pos + ln + gap:pos + 2 * ln + gap].copy()]
+        elif kind == 1:   # a chimeric read: pieces from anywhere, either strand (supplementary lines, SA tags)
+            parts = []
+            for _ in range(int(rng.integers(2, 4))):
+                cc = int(rng.integers(0, len(seqs)))
+                ln = int(rng.integers(60, 140))
+                pp = int(rng.integers(0, len(seqs[cc]) - ln))
+                piece = seqs[cc][pp:pp + ln].copy()
+                parts.append(comp[np.minimum(piece, 4)[::-1]] if rng.random() < 0.5 else piece)
+        else:   # two or three pieces of one contig with small gaps between them (deletions of 0-40 bases; sometimes an insertion)
+            pos = int(rng.integers(0, len(seqs[c]) - 1500))
+            parts = []
+            for _ in range(int(rng.integers(1, 4))):
+                ln = int(rng.integers(60, 160))
+                parts.append(seqs[c][pos:pos + ln].copy())
+                pos += ln + int(rng.integers(0, 41))
+                if rng.random() < 0.3:
+                    parts.append(rng.integers(0, 4, int(rng.integers(1, 12))).astype(np.uint8))
+        read = np.concatenate(parts)
+        read = np.where(read > 3, 0, read).astype(np.uint8)
+        m = rng.random(len(read)) < (0.003 if kind == 0 else 0.01)
+        read[m] = (read[m] + 1) & 3
+        if rng.random() < 0.5:
+            read = comp[read[::-1]]
+        ascii_read = lut[read].tobytes()
+        buf = C.create_string_buffer(ascii_read, len(read) + 1)
+        for i in range(len(read)):   # nt4 codes, as mem_align1_core makes them (src/bwamem.c:1057-1058)
+            buf[i] = bytes([int(read[i])])
+        chn = R.mem_chain(opt, ref.bwt, ref.bns, len(read), buf, None)
+        chn.n = R.mem_chain_flt(opt, chn.n, chn.a)
+        R.mem_flt_chained_seeds(opt, ref.bns, ref.pac, len(read), buf, chn.n, chn.a)
+        regs = _alnreg_v()
+        for i in range(chn.n):
+            R.mem_chain2aln(opt, ref.bns, ref.pac, len(read), buf, chn.a + i * CHAIN_T_BYTES, C.byref(regs))
+        raw = _regs_copy(regs)
+        # mem_sort_dedup_patch
+        n_ref = R.mem_sort_dedup_patch(opt, ref.bns, ref.pac, buf, regs.n, regs.a)
+        regs.n = n_ref
+        want = _regs_copy(regs)
+        mine = raw.copy()
+        n_own = lib.mi355x_host_sort_dedup_patch(opt, ref.bns, C.cast(ref.pac, C.c_void_p), C.cast(buf, C.c_void_p), mine.ctypes.data, len(mine))
+        assert n_own == n_ref, (r, len(raw), n_own, n_ref)
+        got = mine[:n_own]
+        for f in ("rb", "re", "qb", "qe", "rid", "score", "truesc", "w", "seedcov", "seedlen0", "frac_rep"):
+            assert (got[f] == want[f]).all(), (r, f, got[f], want[f])
+        n_dropped += len(raw) - n_ref
+        n_patched += int(sum(1 for x in want if not ((raw["rb"] == x["rb"]) & (raw["re"] == x["re"])).any()))
+        n_multi += n_ref > 1
+        # single end: primary marking with the read's id, -5, the records
+        qual = C.create_string_buffer(bytes((33 + (3 * i + r) % 41 for i in range(len(read)))))
+        nm = C.create_string_buffer(b"read%d" % r)
+        texts = []
+        for who in ("ref", "own"):
+            s = abi.bseq1_t()
+            s.l_seq = len(read); s.name = C.addressof(nm); s.seq = C.addressof(buf); s.qual = C.addressof(qual)
+            if who == "ref":
+                R.mem_mark_primary_se(opt, regs.n, regs.a, 1000 + r)
+                if flag & abi.MEM_F_PRIMARY5:
+                    R.mem_reorder_primary5(opt.contents.T, C.byref(regs))
+                R.mem_reg2sam(opt, ref.bns, ref.pac, C.byref(s), C.byref(regs), 0, None)
+            else:
+                lib.mi355x_host_reg2sam_se(opt, ref.bns, C.cast(ref.pac, C.c_void_p), C.byref(s), want.ctypes.data, len(want), 1000 + r)
+            texts.append(C.string_at(s.sam))
+            api.libc.free(C.c_void_p(s.sam))
+        assert texts[0] == texts[1], (r, kw)
+        n_xa += texts[0].count(b"\tXA:Z:")
+        n_sa += texts[0].count(b"\tSA:Z:")
+        api.libc.free(C.c_void_p(regs.a))
+    assert n_patched > 15 and n_dropped > 5 and n_multi > 100 and n_sa > 50, (n_patched, n_dropped, n_multi, n_xa, n_sa)
+    assert n_xa > 20 or flag & abi.MEM_F_ALL, n_xa   # (-a prints the secondary hits as lines of their own instead of XA)
