@@ -24,7 +24,7 @@
  *
  * Reading, aligning and writing overlap (the reference's docs/TODO:4, "overlaping reading, aligning and writing"): the
  * chunk loop runs on --in-flight worker threads per rank (default 6), each of them fetching the next chunk number, reading its bytes
- * with MPI-IO, building the bseq1_t array, calling mem_process_seqs() — the library runs up to eight calls side by side,
+ * with MPI-IO, building the bseq1_t array, calling mem_process_seqs() — the library runs up to mi355x_max_calls() = twelve calls side by side,
  * the GPU half of one chunk under the host half of another — and appending the SAM text through the shared file pointer.
  * With MPI_THREAD_MULTIPLE the workers call MPI concurrently; with MPI_THREAD_SERIALIZED a mutex takes turns; below that
  * one worker runs (the reference's blocking loop, src/mainParallel.c:1112-1391).
