@@ -355,6 +355,8 @@ int   mi355x_host_sam_pe(const mem_opt_t *opt, const bntseq_t *bns, const uint8_
  * 1187-1203: mem_mark_primary_se with id, mem_reorder_primary5 under -5, mem_reg2sam; s->sam is set) */
 int   mi355x_host_sort_dedup_patch(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, uint8_t *query, void *regs, int n);
 void  mi355x_host_reg2sam_se(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, bseq1_t *s, const void *regs, int n, int64_t id);
+/* ... and for mem_pestat (src/bwamem_pair.c:46-109): regs = the regions of n reads (mates interleaved) one after the other, n_regs[i] of read i */
+void  mi355x_host_pestat(const mem_opt_t *opt, int64_t l_pac, int n, const void *regs, const int *n_regs, mem_pestat_t pes[4], int n_threads);
 
 /* CPUs usable by this process (cgroup quota aware) — what the host stages are sized to. */
 int   mi355x_host_cpus(void);

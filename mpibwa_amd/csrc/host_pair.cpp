@@ -705,3 +705,13 @@ extern "C" void mi355x_host_reg2sam_se(const mem_opt_t *opt, const bntseq_t *bns
 	if (opt->flag & MEM_F_PRIMARY5) mbw::reorder_primary5(opt->T, v);
 	mbw::reg2sam(opt, bns, pac, s, v, 0, nullptr);
 }
+
+// mem_pestat (src/bwamem_pair.c:46-109) of the library's host path on the regions of n reads (mates interleaved) given as the reference's
+// records: regs = all reads' regions one after the other, n_regs[i] = how many read i has.  The messages go to stderr as the reference's do.
+extern "C" void mi355x_host_pestat(const mem_opt_t *opt, int64_t l_pac, int n, const void *regs, const int *n_regs, mem_pestat_t pes[4], int n_threads)
+{
+	std::vector<mbw::HRegV> v((size_t)n);
+	const Ref88 *r = (const Ref88 *)regs;
+	for (int i = 0; i < n; ++i) { regs_in(r, n_regs[i], v[(size_t)i]); r += n_regs[i]; }
+	mbw::pestat(opt, l_pac, n, v.data(), pes, n_threads);
+}

@@ -258,3 +258,41 @@ def test_host_dedup_patch_and_single_end_records_match_the_reference(repeat_geno
         api.libc.free(C.c_void_p(regs.a))
     assert n_patched > 15 and n_dropped > 5 and n_multi > 100 and n_sa > 50, (n_patched, n_dropped, n_multi, n_xa, n_sa)
     assert n_xa > 20 or flag & abi.MEM_F_ALL, n_xa   # (-a prints the secondary hits as lines of their own instead of XA)
+
+
+def test_host_pestat_matches_the_reference_mem_pestat(repeat_genome, capfd):
+    """mem_pestat (src/bwamem_pair.c:46-109) of the library's host path — the counting form (max_ins up to 2^20) and the sorting form, on one
+    and on several threads — against the reference's own on the regions of its mem_align1_core: libraries with one, two and four live
+    orientations (mates reverse-complemented to make FF / RF / RR pairs), too few pairs for any, a wide and a narrow insert-size
+    distribution; the four (low, high, failed, avg, std) records bit for bit and the lines on stderr."""
+    from mpibwa_amd import abi, api, simulate
+    lib = api.load_library()
+    R = po.ref_lib()
+    ref = po.RefIndex(repeat_genome["prefix"])
+    comp = {ord("A"): "T", ord("C"): "G", ord("G"): "C", ord("T"): "A", ord("N"): "N"}
+    rc = lambda s: s.decode().translate(comp)[::-1].encode()
+    l_pac = int(ref.bns.contents.l_pac)
+    n_live = []
+    for case, (n_pairs, sd, mix, kw) in enumerate([(1200, 50.0, (1, 0, 0, 0), {}), (1500, 120.0, (6, 2, 1, 1), {}), (1600, 30.0, (1, 1, 1, 1), dict(max_ins=3_000_000)),
+                                                   (12, 50.0, (1, 0, 0, 0), {}), (900, 200.0, (3, 0, 1, 0), dict(max_ins=700))]):
+        opt = ref.opt(flag=abi.MEM_F_PE, **kw)
+        rng = np.random.default_rng(90 + case)
+        base = simulate.reads_to_ascii(simulate.simulate_reads(repeat_genome["seqs"], n_pairs, 150, paired=True, seed=70 + case, frag_sd=sd))
+        kinds = rng.choice(4, size=n_pairs, p=np.array(mix) / sum(mix))
+        reads = [(n, a, b) if k == 0 else (n, a, rc(b)) if k == 1 else (n, rc(a), rc(b)) if k == 2 else (n, rc(a), b) for (n, a, b), k in zip(base, kinds)]
+        capfd.readouterr()
+        regs, seqs, want = _batch(ref, R, opt, reads)
+        ref_err = capfd.readouterr().err
+        flat = [_regs_copy(v) for v in regs]
+        n_regs = np.array([len(f) for f in flat], dtype=np.int32)
+        allregs = np.concatenate(flat) if len(flat) else np.zeros(0, dtype=po.ALNREG_DT)
+        for threads in (1, 4):
+            got = (abi.mem_pestat_t * 4)()
+            lib.mi355x_host_pestat(opt, l_pac, len(flat), allregs.ctypes.data, n_regs.ctypes.data, C.cast(got, C.c_void_p), threads)
+            own_err = capfd.readouterr().err
+            assert bytes(got) == bytes(want), (case, threads, [(p.low, p.high, p.failed, p.avg, p.std) for p in got], [(p.low, p.high, p.failed, p.avg, p.std) for p in want])
+            assert [l for l in own_err.splitlines() if l.startswith("[M::mem_pestat]")] == [l for l in ref_err.splitlines() if l.startswith("[M::mem_pestat]")]
+        n_live.append(sum(1 for p in want if not p.failed))
+        for v in regs:
+            api.libc.free(C.c_void_p(v.a))
+    assert n_live[0] == 1 and n_live[1] >= 3 and n_live[2] == 4 and n_live[3] == 0, n_live
