@@ -336,6 +336,35 @@ def main():
         alone["smem_bytes"] = sum(counted[c]["smem_bytes"] for c in range(n_chunks))
     else:
         acc["smem_bytes"] = 0
+    # the same kernel pair with the chip to itself and a whole chunk per launch (the production variant through the stage-level entry;
+    # no call in flight): what the kernel does when nothing else competes for the CUs' outstanding misses — the timed region's figure
+    # shares the chip with seven other calls' kernels, the lone caller's launches hold half a chunk.  Never part of `value`; a failure
+    # here only leaves the field out.
+    smem_alone = None
+    if not args.quick and rank == 0 and os.environ.get("MPIBWA_BENCH_SMEM_ALONE", "1") != "0":
+        try:
+            tr = bytes.maketrans(b"ACGTN", bytes([0, 1, 2, 3, 4]))
+            ends = [e.translate(tr) for _, a, b in chunk_reads[0] for e in (a, b)]
+            flat = np.frombuffer(b"".join(ends), dtype=np.uint8)
+            off = np.zeros(len(ends) + 1, dtype=np.int64)
+            off[1:] = np.cumsum([len(e) for e in ends])
+            cap = 96
+            out_iv = np.empty((len(ends), cap, 4), dtype=np.uint64)
+            out_n = np.zeros(len(ends), dtype=np.int32)
+            os.environ["MPIBWA_SMEM_COUNT"] = "0"
+            times = []
+            for _ in range(4):
+                ms, nb = C.c_double(0), C.c_uint64(0)
+                if lib.mi355x_smem_batch(opt, len(ends), flat.ctypes.data, off.ctypes.data, cap, out_iv.ctypes.data, out_n.ctypes.data, C.byref(ms), C.byref(nb)) != 0:
+                    raise RuntimeError("more than %d intervals for a read" % cap)
+                times.append(ms.value)
+            ms_alone = sum(times[1:]) / len(times[1:])   # (the first launch pays the allocation of its buffers' pages)
+            a_alone = counted[0]["smem_bytes"] / (ms_alone * 1e-3) / 1e9
+            smem_alone = {"launch_ms": round(ms_alone, 3), "launches": len(times) - 1, "reads_per_launch": len(ends), "achieved": round(a_alone, 1),
+                          "frac": round(a_alone / 8000.0, 4), "algo_bytes_per_launch": int(counted[0]["smem_bytes"])}
+            del out_iv, flat, ends
+        except Exception as e:   # (measurement extra: the bench line does not depend on it)
+            log("WARNING: seeding kernels alone on the chip not measured: %r" % (e,))
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -375,6 +404,8 @@ def main():
                         "the device by the counting variant of the kernel) / the production launches' duration; the production kernel takes results of up to 14 "
                         "bases from k-mer tables and results of the third pass's first 12 steps from a jump table instead of fetching those blocks: the HBM bytes "
                         "it really moves are `traffic` (PMC, ~0.46 x algorithmic)"}
+    if smem_alone:
+        roofline["alone_whole_chunk"] = smem_alone
     if alone.get("k_smem_ms") and alone.get("n_sub"):
         a1 = alone["smem_bytes"] / (alone["k_smem_ms"] * 1e-3) / 1e9
         roofline["one_call_in_flight"] = {"launch_ms": round(alone["k_smem_ms"] / alone["n_sub"], 3), "achieved": round(a1, 1),
