@@ -357,6 +357,11 @@ int   mi355x_host_sort_dedup_patch(const mem_opt_t *opt, const bntseq_t *bns, co
 void  mi355x_host_reg2sam_se(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, bseq1_t *s, const void *regs, int n, int64_t id);
 /* ... and for mem_pestat (src/bwamem_pair.c:46-109): regs = the regions of n reads (mates interleaved) one after the other, n_regs[i] of read i */
 void  mi355x_host_pestat(const mem_opt_t *opt, int64_t l_pac, int n, const void *regs, const int *n_regs, mem_pestat_t pes[4], int n_threads);
+/* ... and for mem_flt_chained_seeds / mem_seed_sw (src/bwamem.c:571-617; reads of ~700 bp and more): the chains of a read by their seeds
+ * (mem_seed_t records of 24 bytes, n_seeds[c] per chain, chain after chain); the kept seeds are written back at the start of every chain's
+ * slot with their scores, n_seeds[c] updated */
+void  mi355x_host_flt_chained_seeds(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, int l_query, const uint8_t *query, int n_chains,
+                                    void *seeds, int *n_seeds);
 
 /* CPUs usable by this process (cgroup quota aware) — what the host stages are sized to. */
 int   mi355x_host_cpus(void);

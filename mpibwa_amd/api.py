@@ -77,6 +77,7 @@ def load_library(build_if_missing=True):
     sig("mi355x_host_sort_dedup_patch", C.c_int, [P(abi.mem_opt_t), P(abi.bntseq_t), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int])
     sig("mi355x_host_reg2sam_se", None, [P(abi.mem_opt_t), P(abi.bntseq_t), C.c_void_p, P(abi.bseq1_t), C.c_void_p, C.c_int, C.c_int64])
     sig("mi355x_host_pestat", None, [P(abi.mem_opt_t), C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int])
+    sig("mi355x_host_flt_chained_seeds", None, [P(abi.mem_opt_t), P(abi.bntseq_t), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p])
     sig("mi355x_host_sam_pe", C.c_int, [P(abi.mem_opt_t), P(abi.bntseq_t), C.c_void_p, C.c_void_p, C.c_uint64, P(abi.bseq1_t), C.c_void_p, C.c_int, C.c_void_p, C.c_int])
     sig("mi355x_collect_sam", C.c_void_p, [P(abi.bseq1_t), C.c_int, P(C.c_size_t)])
     sig("mi355x_fixmate_pair", C.c_int, [P(abi.bseq1_t), P(abi.bseq1_t), P(abi.bntseq_t)])

@@ -715,3 +715,29 @@ extern "C" void mi355x_host_pestat(const mem_opt_t *opt, int64_t l_pac, int n, c
 	for (int i = 0; i < n; ++i) { regs_in(r, n_regs[i], v[(size_t)i]); r += n_regs[i]; }
 	mbw::pestat(opt, l_pac, n, v.data(), pes, n_threads);
 }
+
+// mem_flt_chained_seeds with mem_seed_sw (src/bwamem.c:571-617) of the library's host path — the rescoring of short seeds for reads of
+// ~700 bp and more — on chains given by their seeds alone: seeds = (rbeg, qbeg, len, score) records of 24 bytes (mem_seed_t), n_seeds[c] of
+// chain c, one chain after the other.  The kept seeds of every chain are written back in place (with their scores), n_seeds[c] updated.
+extern "C" void mi355x_host_flt_chained_seeds(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, int l_query, const uint8_t *query, int n_chains,
+                                              void *seeds, int *n_seeds)
+{
+	static_assert(sizeof(mbw::HSeed) == 24, "mem_seed_t is 24 bytes");
+	std::vector<mbw::HChain> chains((size_t)n_chains);
+	std::vector<mbw::HChain *> ptr;
+	mbw::HSeed *sd = (mbw::HSeed *)seeds;
+	size_t at = 0;
+	for (int c = 0; c < n_chains; ++c) {
+		chains[(size_t)c].seeds.assign(sd + at, sd + at + n_seeds[c]);
+		at += (size_t)n_seeds[c];
+		ptr.push_back(&chains[(size_t)c]);
+	}
+	mbw::filter_chained_seeds(opt, bns, pac, l_query, query, ptr);
+	at = 0;
+	for (int c = 0; c < n_chains; ++c) {
+		const size_t had = (size_t)n_seeds[c];
+		n_seeds[c] = (int)chains[(size_t)c].seeds.size();
+		for (size_t j = 0; j < chains[(size_t)c].seeds.size(); ++j) sd[at + j] = chains[(size_t)c].seeds[j];
+		at += had;
+	}
+}

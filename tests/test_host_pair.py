@@ -296,3 +296,83 @@ def test_host_pestat_matches_the_reference_mem_pestat(repeat_genome, capfd):
         for v in regs:
             api.libc.free(C.c_void_p(v.a))
     assert n_live[0] == 1 and n_live[1] >= 3 and n_live[2] == 4 and n_live[3] == 0, n_live
+
+
+SEED_DT = np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4"), ("score", "<i4"), ("pad", "<i4")])   # mem_seed_t (src/bwamem.c:168-172), 24 bytes
+CHAIN_DT = np.dtype([("n", "<i4"), ("m", "<i4"), ("first", "<i4"), ("rid", "<i4"), ("bits", "<u4"), ("frac_rep", "<f4"), ("pos", "<i8"), ("seeds", "<u8")])   # mem_chain_t, 40 bytes
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(min_chain_weight=30), dict(a=2, b=5, o_del=8, e_del=2, o_ins=7, e_ins=3)])
+def test_host_seed_rescoring_of_long_reads_matches_the_reference(repeat_genome, kw):
+    """mem_flt_chained_seeds / mem_seed_sw (src/bwamem.c:571-617): for reads of ~700 bp and more every short seed of a chain is rescored by a
+    local alignment of its neighbourhood and dropped when the score stays under min_HSP_score.  The chains of the reference's mem_chain +
+    mem_chain_flt are copied, go through the reference's function and through the library's host one (mi355x_host_flt_chained_seeds);
+    reads of 800-2 000 bp with 4 % errors, so that short seeds in noisy stretches are there to be dropped."""
+    from mpibwa_amd import abi, api
+    assert SEED_DT.itemsize == 24 and CHAIN_DT.itemsize == CHAIN_T_BYTES
+    lib = api.load_library()
+    R = po.ref_lib()
+    ref = po.RefIndex(repeat_genome["prefix"])
+    opt = ref.opt(**kw)
+    if "a" in kw:
+        R.bwa_fill_scmat(kw["a"], kw["b"], opt.contents.mat)
+    P_opt, P_bwt, P_bns, P_u8 = C.POINTER(abi.mem_opt_t), C.POINTER(abi.bwt_t), C.POINTER(abi.bntseq_t), C.POINTER(C.c_uint8)
+    R.mem_chain.restype = _chain_v
+    R.mem_chain.argtypes = [P_opt, P_bwt, P_bns, C.c_int, C.c_char_p, C.c_void_p]
+    R.mem_chain_flt.restype = C.c_int
+    R.mem_chain_flt.argtypes = [P_opt, C.c_int, C.c_void_p]
+    R.mem_flt_chained_seeds.restype = None
+    R.mem_flt_chained_seeds.argtypes = [P_opt, P_bns, P_u8, C.c_int, C.c_char_p, C.c_int, C.c_void_p]
+    rng = np.random.default_rng(123)
+    seqs = repeat_genome["seqs"]
+    comp = np.array([3, 2, 1, 0, 4], dtype=np.uint8)
+    n_dropped = n_rescored = n_seeds_all = 0
+
+    def chains_of(chn):
+        ch = np.ctypeslib.as_array(C.cast(chn.a, C.POINTER(C.c_uint8)), shape=(chn.n * CHAIN_T_BYTES,)).view(CHAIN_DT)
+        out = []
+        for c in ch:
+            sd = np.ctypeslib.as_array(C.cast(int(c["seeds"]), C.POINTER(C.c_uint8)), shape=(int(c["n"]) * 24,)).view(SEED_DT).copy()
+            out.append(sd)
+        return out
+    for r in range(120):
+        c = int(rng.integers(0, len(seqs)))
+        ln = int(rng.integers(800, 2001))
+        pos = int(rng.integers(0, len(seqs[c]) - ln))
+        read = np.where(seqs[c][pos:pos + ln] > 3, 0, seqs[c][pos:pos + ln]).astype(np.uint8)
+        m = rng.random(ln) < 0.04
+        read[m] = (read[m] + 1 + rng.integers(0, 3, int(m.sum()))) & 3
+        # behind it: random bases with a few exact 21-32-mers of the genome planted in them — seeds of chains of their own whose
+        # neighbourhood does not align: the ones the rescoring is there to drop
+        tail = []
+        for _ in range(int(rng.integers(1, 5))):
+            cc = int(rng.integers(0, len(seqs)))
+            k = int(rng.integers(21, 33))
+            pp = int(rng.integers(0, len(seqs[cc]) - k))
+            tail += [rng.integers(0, 4, int(rng.integers(80, 200))).astype(np.uint8), np.minimum(seqs[cc][pp:pp + k], 3).astype(np.uint8)]
+        read = np.concatenate([read] + tail + [rng.integers(0, 4, 100).astype(np.uint8)])
+        ln = len(read)
+        if r % 2:
+            read = comp[read[::-1]]
+        buf = C.create_string_buffer(bytes(read.tolist()), ln + 1)
+        chn = R.mem_chain(opt, ref.bwt, ref.bns, ln, buf, None)
+        chn.n = R.mem_chain_flt(opt, chn.n, chn.a)
+        if chn.n == 0:
+            continue
+        before = chains_of(chn)
+        R.mem_flt_chained_seeds(opt, ref.bns, ref.pac, ln, buf, chn.n, chn.a)
+        after = chains_of(chn)
+        flat = np.concatenate(before)
+        n_seeds = np.array([len(b) for b in before], dtype=np.int32)
+        lib.mi355x_host_flt_chained_seeds(opt, ref.bns, C.cast(ref.pac, C.c_void_p), ln, C.cast(buf, C.c_void_p), len(before), flat.ctypes.data, n_seeds.ctypes.data)
+        at = 0
+        for k, (b, a) in enumerate(zip(before, after)):
+            got = flat[at:at + n_seeds[k]]
+            assert len(got) == len(a), (r, k, len(got), len(a))
+            for f in ("rbeg", "qbeg", "len", "score"):
+                assert (got[f] == a[f]).all(), (r, k, f)
+            at += len(b)
+            n_dropped += len(b) - len(a)
+            n_rescored += int((a["score"] != a["len"] * opt.contents.a).sum())
+            n_seeds_all += len(b)
+    assert n_seeds_all > 2000 and n_dropped > 20 and n_rescored > 200, (n_seeds_all, n_dropped, n_rescored)
