@@ -14,6 +14,15 @@ from oracle import pyoracle as po
 pytestmark = pytest.mark.skipif(not po.ref_available(), reason="oracle/_ref/libbwaref.so not built")
 
 
+def _ref_handle():
+    """a ctypes handle of our own on the reference's library: the prototypes set here must not change those of oracle/pyoracle.py's handle"""
+    import os
+    po.ref_lib()
+    h = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(po.__file__)), "_ref", "libbwaref.so"))
+    h.bwa_fill_scmat.argtypes = [C.c_int, C.c_int, C.c_void_p]
+    return h
+
+
 class _alnreg_v(C.Structure):   # mem_alnreg_v (src/bwamem.h:79)
     _fields_ = [("n", C.c_size_t), ("m", C.c_size_t), ("a", C.c_void_p)]
 
@@ -73,7 +82,7 @@ def test_host_sam_pe_matches_the_reference_mem_sam_pe(repeat_genome, case):
     from mpibwa_amd import abi, api, simulate
     from test_sampost import _pairs_of_every_kind
     lib = api.load_library()
-    lib_ref = po.ref_lib()
+    lib_ref = _ref_handle()
     lib_ref.mem_sam_pe.restype = C.c_int
     lib_ref.mem_sam_pe.argtypes = [C.POINTER(abi.mem_opt_t), C.POINTER(abi.bntseq_t), C.POINTER(C.c_uint8), C.POINTER(abi.mem_pestat_t), C.c_uint64,
                                    C.POINTER(abi.bseq1_t), C.POINTER(_alnreg_v)]
@@ -148,7 +157,7 @@ def test_host_dedup_patch_and_single_end_records_match_the_reference(repeat_geno
     are there for mem_patch_reg to join."""
     from mpibwa_amd import abi, api
     lib = api.load_library()
-    R = po.ref_lib()
+    R = _ref_handle()
     ref = po.RefIndex(repeat_genome["prefix"])
     kw = dict(kw)
     flag = 0
@@ -267,12 +276,16 @@ def test_host_pestat_matches_the_reference_mem_pestat(repeat_genome, capfd):
     distribution; the four (low, high, failed, avg, std) records bit for bit and the lines on stderr."""
     from mpibwa_amd import abi, api, simulate
     lib = api.load_library()
-    R = po.ref_lib()
+    R = _ref_handle()
     ref = po.RefIndex(repeat_genome["prefix"])
     comp = {ord("A"): "T", ord("C"): "G", ord("G"): "C", ord("T"): "A", ord("N"): "N"}
     rc = lambda s: s.decode().translate(comp)[::-1].encode()
     l_pac = int(ref.bns.contents.l_pac)
     n_live = []
+    verbose = [C.c_int.in_dll(x, "bwa_verbose") for x in (lib, R)]   # (each library has its own; other tests leave them at other levels)
+    saved = [v.value for v in verbose]
+    for v in verbose:
+        v.value = 3
     for case, (n_pairs, sd, mix, kw) in enumerate([(1200, 50.0, (1, 0, 0, 0), {}), (1500, 120.0, (6, 2, 1, 1), {}), (1600, 30.0, (1, 1, 1, 1), dict(max_ins=3_000_000)),
                                                    (12, 50.0, (1, 0, 0, 0), {}), (900, 200.0, (3, 0, 1, 0), dict(max_ins=700))]):
         opt = ref.opt(flag=abi.MEM_F_PE, **kw)
@@ -295,6 +308,8 @@ def test_host_pestat_matches_the_reference_mem_pestat(repeat_genome, capfd):
         n_live.append(sum(1 for p in want if not p.failed))
         for v in regs:
             api.libc.free(C.c_void_p(v.a))
+    for v, x in zip(verbose, saved):
+        v.value = x
     assert n_live[0] == 1 and n_live[1] >= 3 and n_live[2] == 4 and n_live[3] == 0, n_live
 
 
@@ -311,7 +326,7 @@ def test_host_seed_rescoring_of_long_reads_matches_the_reference(repeat_genome, 
     from mpibwa_amd import abi, api
     assert SEED_DT.itemsize == 24 and CHAIN_DT.itemsize == CHAIN_T_BYTES
     lib = api.load_library()
-    R = po.ref_lib()
+    R = _ref_handle()
     ref = po.RefIndex(repeat_genome["prefix"])
     opt = ref.opt(**kw)
     if "a" in kw:
