@@ -3,8 +3,8 @@
  *     mpiexec -n N mpibwa_gpu mem [bwa mem options] [-f] [-g | -b] [--by-chr] [--ordered] [-K bases] [--in-flight chunks] [--no-prewarm] [--dry-run] -o OUT PREFIX R1.fastq [R2.fastq]
  *
  * The `mem` options are the reference's (src/mainParallel.c:291-398: -k -w -A -B -O -E -L -U -T -c -d -r -D -m -s -G -N -W -y -X -h -Q -I -R -H
- * -P -a -M -S -Y -V -5 -q -j -C -v -t -K -o, and its output options -f (fixmate, :395), -g (BGZF, :299), -b (BGZF + EOF block under the
- * name the reference calls BAM, :298)); -p, -x and -z are not offered.  --by-chr is mpiBWAByChr (src/mainParallelByChromosome.c): one file
+ * -P -a -M -S -Y -V -5 -q -j -C -v -t -K -x -o, and its output options -f (fixmate, :395), -g (BGZF, :299), -b (BGZF + EOF block under the
+ * name the reference calls BAM, :298)); -p and -z are not offered.  --by-chr is mpiBWAByChr (src/mainParallelByChromosome.c): one file
  * per contig plus discordant (pairs without -f) and unmapped in the directory of OUT.
  *
  * It does, with this repo's own code, what mpiBWA's main does around mem_process_seqs():
@@ -374,7 +374,8 @@ int main(int argc, char **argv)
 	int n_threads = 0, copy_comment = 0, dry = 0, n_workers = 6, prewarm = 1;
 	int dofixmate = 0, write_format = 2, compression_level = 3, by_chr = 0;   /* src/mainParallel.c:223-227 */
 	int ordered = 0;
-	int scale_a = 0, set_b = 0, set_T = 0, set_U = 0, set_d = 0, set_O = 0, set_E = 0, set_L = 0;
+	int scale_a = 0, set_b = 0, set_T = 0, set_U = 0, set_d = 0, set_O = 0, set_E = 0, set_L = 0, set_k = 0, set_r = 0, set_W = 0;
+	const char *mode = 0;   /* -x: a preset of the options the user did not set (src/mainParallel.c:294, 398-428) */
 	int64_t K = 0;
 	const char *out_path = 0, *pos[4];
 	int n_pos = 0;
@@ -417,10 +418,11 @@ int main(int argc, char **argv)
 			else if (c == 'g') write_format = 0;       /* :299 */
 			continue;
 		}
-		if (!strchr("kwABTUtcdvrDmsGNWyKXhQOELRHIo", c)) DIE("unknown or unsupported option %s", a);
+		if (!strchr("kwABTUtcdvrDmsGNWyKXhQOELRHIox", c)) DIE("unknown or unsupported option %s", a);
 		if (i + 1 >= argc) DIE("option %s needs a value", a);
 		char *v = argv[++i], *e = 0;
-		if (c == 'k') opt->min_seed_len = atoi(v);
+		if (c == 'k') { opt->min_seed_len = atoi(v); set_k = 1; }
+		else if (c == 'x') mode = v;
 		else if (c == 'w') opt->w = atoi(v);
 		else if (c == 'A') { opt->a = atoi(v); scale_a = 1; }
 		else if (c == 'B') { opt->b = atoi(v); set_b = 1; }
@@ -430,13 +432,13 @@ int main(int argc, char **argv)
 		else if (c == 'c') opt->max_occ = atoi(v);
 		else if (c == 'd') { opt->zdrop = atoi(v); set_d = 1; }
 		else if (c == 'v') bwa_verbose = atoi(v);
-		else if (c == 'r') opt->split_factor = (float)atof(v);
+		else if (c == 'r') { opt->split_factor = (float)atof(v); set_r = 1; }
 		else if (c == 'D') opt->drop_ratio = (float)atof(v);
 		else if (c == 'm') opt->max_matesw = atoi(v);
 		else if (c == 's') opt->split_width = atoi(v);
 		else if (c == 'G') opt->max_chain_gap = atoi(v);
 		else if (c == 'N') opt->max_chain_extend = atoi(v);
-		else if (c == 'W') opt->min_chain_weight = atoi(v);
+		else if (c == 'W') { opt->min_chain_weight = atoi(v); set_W = 1; }
 		else if (c == 'y') opt->max_mem_intv = (uint64_t)atol(v);
 		else if (c == 'K') K = atoll(v);
 		else if (c == 'X') opt->mask_level = (float)atof(v);
@@ -484,7 +486,22 @@ int main(int argc, char **argv)
 			if (*e != 0 && ispunct((unsigned char)*e) && isdigit((unsigned char)e[1])) pes[1].low = (int)(strtod(e + 1, &e) + .499);
 		} else if (c == 'o') out_path = v;
 	}
-	if (scale_a && opt->a != 1) {   /* -A scales the penalties the user did not set (src/mainParallel.c:430-440) */
+	if (mode) {   /* the presets of -x for what the user left alone (src/mainParallel.c:398-428); -A does not scale anything then */
+		if (!strcmp(mode, "intractg")) {
+			if (!set_O) opt->o_del = opt->o_ins = 16;
+			if (!set_b) opt->b = 9;
+			if (!set_L) opt->pen_clip5 = opt->pen_clip3 = 5;
+		} else if (!strcmp(mode, "pacbio") || !strcmp(mode, "pbref") || !strcmp(mode, "ont2d")) {   /* (reads beyond 8 998 bp are refused by the library) */
+			const int ont = !strcmp(mode, "ont2d");
+			if (!set_O) opt->o_del = opt->o_ins = 1;
+			if (!set_E) opt->e_del = opt->e_ins = 1;
+			if (!set_b) opt->b = 1;
+			if (!set_r) opt->split_factor = 10.f;
+			if (!set_W) opt->min_chain_weight = ont ? 20 : 40;
+			if (!set_k) opt->min_seed_len = ont ? 14 : 17;
+			if (!set_L) opt->pen_clip5 = opt->pen_clip3 = 0;
+		} else DIE("unknown read type '%s' (-x intractg | pacbio | pbref | ont2d)", mode);
+	} else if (scale_a && opt->a != 1) {   /* -A scales the penalties the user did not set (src/mainParallel.c:430-440) */
 		if (!set_b) opt->b *= opt->a;
 		if (!set_T) opt->T *= opt->a;
 		if (!set_O) { opt->o_del *= opt->a; opt->o_ins *= opt->a; }

@@ -151,6 +151,11 @@ def test_fixmate_and_by_chromosome_files_are_those_of_the_reference_programs(shi
     plain = _records(os.path.join(d, "ref_plain.sam"))
     run(EXE, ["-o", os.path.join(d, "own_plain.sam")])
     assert _records(os.path.join(d, "own_plain.sam")) == plain and len(plain) > 6000
+    # -x: the reference's preset of the options the user left alone (src/mainParallel.c:398-428), beside options the user did set
+    run(REF_MAIN, ["-x", "intractg", "-B", "7", "-o", os.path.join(d, "ref_x")])
+    run(EXE, ["-x", "intractg", "-B", "7", "-o", os.path.join(d, "own_x.sam")])
+    preset = _records(os.path.join(d, "ref_x.sam"))
+    assert _records(os.path.join(d, "own_x.sam")) == preset and preset != plain
     # --ordered: one rank with four chunks in flight writes the file one chunk in flight writes (record for record, unsorted)
     bodies = []
     for extra in (["--in-flight", "1"], ["--in-flight", "4", "--ordered"]):
