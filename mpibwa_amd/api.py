@@ -10,7 +10,7 @@ from . import abi
 HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-libc = C.CDLL("libc.so.6")
+libc = C.CDLL(None if os.environ.get("MPIBWA_SANITIZER_LIB") else "libc.so.6")   # (under tools/san_host.sh: the sanitizer's malloc / free)
 libc.free.argtypes = [C.c_void_p]
 
 EXPORTS = [
@@ -35,16 +35,26 @@ def load_library(build_if_missing=True):
     if _LIB is not None:
         return _LIB
     path = os.path.join(HERE, "libmpibwa_amd.so")
+    # tools/san_host.sh: the library's HOST sources alone, built with AddressSanitizer / UBSan — no kernels and none of the entry points
+    # that need the GPU; only the host-logic tests run on it
+    host_only = os.environ.get("MPIBWA_SANITIZER_LIB")
+    if host_only:
+        path = host_only
     if not os.path.exists(path):
-        if not build_if_missing:
-            raise RuntimeError("libmpibwa_amd.so is missing: run python -m mpibwa_amd.build")
+        if not build_if_missing or host_only:
+            raise RuntimeError("%s is missing: run python -m mpibwa_amd.build" % path)
         from .build import build
         build()
     lib = C.CDLL(path)
     P = C.POINTER
 
     def sig(name, restype, argtypes):
-        fn = getattr(lib, name)  # AttributeError here = the library does not export what include/mpibwa_amd.h declares
+        try:
+            fn = getattr(lib, name)  # AttributeError here = the library does not export what include/mpibwa_amd.h declares
+        except AttributeError:
+            if host_only:
+                return
+            raise
         fn.restype = restype
         fn.argtypes = argtypes
 

@@ -17,7 +17,7 @@ import numpy as np
 
 from . import abi
 
-_libc = C.CDLL("libc.so.6")
+_libc = C.CDLL(None if os.environ.get("MPIBWA_SANITIZER_LIB") else "libc.so.6")   # (under tools/san_host.sh: the sanitizer's malloc / free)
 _libc.free.argtypes = [C.c_void_p]
 
 

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 from mpibwa_amd import abi  # noqa: E402
 
-libc = C.CDLL("libc.so.6")
+libc = C.CDLL(None if os.environ.get("MPIBWA_SANITIZER_LIB") else "libc.so.6")   # (under tools/san_host.sh: the sanitizer's malloc / free)
 libc.free.argtypes = [C.c_void_p]
 libc.calloc.restype = C.c_void_p
 libc.calloc.argtypes = [C.c_size_t, C.c_size_t]

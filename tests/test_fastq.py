@@ -1,5 +1,6 @@
 """Caller-side row, host logic only: mpiBWA's FASTQ record scan, chunk rule and bseq1_t filling."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -174,7 +175,7 @@ def _stub_engine(lib, seen, delay=True):
     "<name>\t<n_processed + i>" per read and finishes every other call late."""
     import threading
     import time
-    libc = C.CDLL("libc.so.6")
+    libc = C.CDLL(None if os.environ.get("MPIBWA_SANITIZER_LIB") else "libc.so.6")   # (under tools/san_host.sh: the sanitizer's malloc / free)
     libc.malloc.restype = C.c_void_p
     libc.malloc.argtypes = [C.c_size_t]
     lock = threading.Lock()
