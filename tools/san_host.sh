@@ -20,4 +20,4 @@ export MPIBWA_SANITIZER_LIB=$O/libhost_san.so
 export LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)
 export ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
 # (not on this build: tests that go through entry points living in .hip files — mi355x_chain_batch, mem_process_seqs — or that list every export)
-exec python -m pytest -q -m "not gpu" -p no:cacheprovider -k "not exports and not align_files" ${@:-tests/test_sampost.py tests/test_host_pair.py tests/test_host_ksw.py tests/test_fastq.py tests/test_index.py}
+exec python -m pytest -q -m "not gpu" -p no:cacheprovider -k "not exports and not exported and not align_files" ${@:-tests/test_sampost.py tests/test_host_pair.py tests/test_host_ksw.py tests/test_fastq.py tests/test_index.py tests/test_boundary.py}
