@@ -90,9 +90,9 @@ int64_t to_int(std::string_view f)   // atoi / atol on a field (digits with an o
 	size_t i = 0;
 	bool neg = false;
 	if (i < f.size() && (f[i] == '-' || f[i] == '+')) neg = f[i++] == '-';
-	int64_t v = 0;
-	for (; i < f.size() && f[i] >= '0' && f[i] <= '9'; ++i) v = v * 10 + (f[i] - '0');
-	return neg ? -v : v;
+	uint64_t v = 0;   // (unsigned: a field of twenty digits wraps around instead of overflowing a signed number)
+	for (; i < f.size() && f[i] >= '0' && f[i] <= '9'; ++i) v = v * 10 + (uint64_t)(f[i] - '0');
+	return (int64_t)(neg ? 0 - v : v);
 }
 
 // readParsing (src/fixmate.c:160-298): [line, line_end) holds one record without its '\n'; `tail_end` is behind the '\n'
