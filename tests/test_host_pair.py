@@ -391,3 +391,67 @@ def test_host_seed_rescoring_of_long_reads_matches_the_reference(repeat_genome, 
             n_rescored += int((a["score"] != a["len"] * opt.contents.a).sum())
             n_seeds_all += len(b)
     assert n_seeds_all > 2000 and n_dropped > 20 and n_rescored > 200, (n_seeds_all, n_dropped, n_rescored)
+
+
+@pytest.mark.parametrize("which_pes,kw", [(0, {}), (1, {}), (2, {}), (0, dict(pen_unpaired=5, mask_level=0.3, XA_drop_ratio=0.5, max_matesw=4))])
+def test_host_sam_pe_on_adversarial_region_lists(repeat_genome, which_pes, kw):
+    """The region lists of tests/pair_cases.py (1-9 hits per end: equal scores, contained / shifted / overlapping hits, other strands and contigs, mates
+    at every distance; FR, RF and all-four-alive libraries) with random reads under them, so that every record is a low-identity alignment and the
+    rescue loop runs on windows that hold nothing: through the reference's mem_sort_dedup_patch, then the reference's mem_sam_pe and the library's host
+    path — the same text (the pairing kernel's stage test, tests/test_pair_stage.py, feeds the same lists to the device path)."""
+    from mpibwa_amd import abi, api
+    from pair_cases import adversarial_pairs
+    from test_pair_stage import _pes, PES_SETS
+    lib = api.load_library()
+    R = _ref_handle()
+    ref = po.RefIndex(repeat_genome["prefix"])
+    P = C.POINTER
+    R.mem_sam_pe.restype = C.c_int
+    R.mem_sam_pe.argtypes = [P(abi.mem_opt_t), P(abi.bntseq_t), P(C.c_uint8), P(abi.mem_pestat_t), C.c_uint64, P(abi.bseq1_t), P(_alnreg_v)]
+    R.mem_sort_dedup_patch.restype = C.c_int
+    R.mem_sort_dedup_patch.argtypes = [P(abi.mem_opt_t), P(abi.bntseq_t), P(C.c_uint8), C.c_char_p, C.c_int, C.c_void_p]
+    libc = api.libc
+    libc.malloc.restype = C.c_void_p
+    libc.malloc.argtypes = [C.c_size_t]
+    l_pac = int(ref.bns.contents.l_pac)
+    n_seqs = int(ref.bns.contents.n_seqs)
+    offs = np.array([int(ref.bns.contents.anns[k].offset) for k in range(n_seqs)] + [l_pac])
+    rng = np.random.default_rng(800 + which_pes + len(kw))
+    opt = ref.opt(flag=abi.MEM_F_PE, **kw)
+    pes = _pes(PES_SETS[which_pes][0])
+    pairs = adversarial_pairs(rng, 1200, l_pac, offs, orient=PES_SETS[which_pes][1])
+    n_rescued = n_many = 0
+    for k, ends in enumerate(pairs):
+        reads = [C.create_string_buffer(bytes(rng.integers(0, 4, 150).astype(np.uint8).tolist()), 151) for _ in range(2)]
+        quals = [C.create_string_buffer(b"I" * 150) for _ in range(2)]
+        nm = C.create_string_buffer(b"p%d" % k)
+        vs = []
+        for e in range(2):
+            a = np.ascontiguousarray(ends[e], dtype=po.ALNREG_DT)
+            p = libc.malloc(max(1, a.nbytes))
+            C.memmove(p, a.ctypes.data, a.nbytes)
+            v = _alnreg_v(len(a), len(a), p)
+            v.n = R.mem_sort_dedup_patch(opt, ref.bns, ref.pac, reads[e], v.n, v.a)
+            vs.append(v)
+        copies = [_regs_copy(v) for v in vs]
+        texts = []
+        for who in ("ref", "own"):
+            s = (abi.bseq1_t * 2)()
+            for e in range(2):
+                s[e].l_seq = 150; s[e].name = C.addressof(nm); s[e].seq = C.addressof(reads[e]); s[e].qual = C.addressof(quals[e])
+            if who == "ref":
+                a = (_alnreg_v * 2)(vs[0], vs[1])
+                r = R.mem_sam_pe(opt, ref.bns, ref.pac, pes, 1000 + k, s, a)
+                for e in range(2):
+                    libc.free(C.c_void_p(a[e].a))
+            else:
+                r = lib.mi355x_host_sam_pe(opt, ref.bns, C.cast(ref.pac, C.c_void_p), C.cast(pes, C.c_void_p), 1000 + k, s, copies[0].ctypes.data, len(copies[0]),
+                                           copies[1].ctypes.data, len(copies[1]))
+            t = [C.string_at(s[e].sam) for e in range(2)]
+            for e in range(2):
+                libc.free(C.c_void_p(s[e].sam))
+            texts.append((r, t))
+        assert texts[0] == texts[1], (which_pes, kw, k, [len(c) for c in copies])
+        n_rescued += texts[0][0]
+        n_many += len(copies[0]) > 4 or len(copies[1]) > 4
+    assert n_rescued > 500 and n_many > 100, (n_rescued, n_many)
