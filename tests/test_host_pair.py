@@ -420,7 +420,7 @@ def test_host_sam_pe_on_adversarial_region_lists(repeat_genome, which_pes, kw):
     opt = ref.opt(flag=abi.MEM_F_PE, **kw)
     pes = _pes(PES_SETS[which_pes][0])
     pairs = adversarial_pairs(rng, 1200, l_pac, offs, orient=PES_SETS[which_pes][1])
-    n_rescued = n_many = 0
+    n_rescued = n_many = n_dedup = 0
     for k, ends in enumerate(pairs):
         reads = [C.create_string_buffer(bytes(rng.integers(0, 4, 150).astype(np.uint8).tolist()), 151) for _ in range(2)]
         quals = [C.create_string_buffer(b"I" * 150) for _ in range(2)]
@@ -433,6 +433,14 @@ def test_host_sam_pe_on_adversarial_region_lists(repeat_genome, which_pes, kw):
             v = _alnreg_v(len(a), len(a), p)
             v.n = R.mem_sort_dedup_patch(opt, ref.bns, ref.pac, reads[e], v.n, v.a)
             vs.append(v)
+            # (the library's own pass over the same raw list: the same regions in the same order)
+            mine = a.copy()
+            m = lib.mi355x_host_sort_dedup_patch(opt, ref.bns, C.cast(ref.pac, C.c_void_p), C.cast(reads[e], C.c_void_p), mine.ctypes.data, len(mine))
+            want = _regs_copy(v)
+            assert m == v.n, (k, e, m, v.n)
+            for f in ("rb", "re", "qb", "qe", "rid", "score", "truesc", "w", "seedcov"):
+                assert (mine[:m][f] == want[f]).all(), (k, e, f)
+            n_dedup += len(a) - m
         copies = [_regs_copy(v) for v in vs]
         texts = []
         for who in ("ref", "own"):
@@ -454,4 +462,4 @@ def test_host_sam_pe_on_adversarial_region_lists(repeat_genome, which_pes, kw):
         assert texts[0] == texts[1], (which_pes, kw, k, [len(c) for c in copies])
         n_rescued += texts[0][0]
         n_many += len(copies[0]) > 4 or len(copies[1]) > 4
-    assert n_rescued > 500 and n_many > 100, (n_rescued, n_many)
+    assert n_rescued > 500 and n_many > 100 and n_dedup > 300, (n_rescued, n_many, n_dedup)
