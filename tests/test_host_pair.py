@@ -463,3 +463,67 @@ def test_host_sam_pe_on_adversarial_region_lists(repeat_genome, which_pes, kw):
         n_rescued += texts[0][0]
         n_many += len(copies[0]) > 4 or len(copies[1]) > 4
     assert n_rescued > 500 and n_many > 100 and n_dedup > 300, (n_rescued, n_many, n_dedup)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(flag_add="MEM_F_ALL"), dict(flag_add="MEM_F_PRIMARY5|MEM_F_KEEP_SUPP_MAPQ|MEM_F_SOFTCLIP", T=25),
+                                dict(flag_add="MEM_F_NO_MULTI", mask_level=0.3, drop_ratio=0.8, max_XA_hits=2, XA_drop_ratio=0.5)])
+def test_host_single_end_records_on_adversarial_region_lists(repeat_genome, kw):
+    """The same lists, every end as a single-end read with random bases under it: mem_sort_dedup_patch, mem_mark_primary_se (hash tie-breaks on the
+    read's id), -5, mem_reg2sam (XA / SA / supplementary / secondary lines, MAPQ) of the reference and of the library's host path — the same text."""
+    from mpibwa_amd import abi, api
+    from pair_cases import adversarial_pairs
+    lib = api.load_library()
+    R = _ref_handle()
+    ref = po.RefIndex(repeat_genome["prefix"])
+    kw = dict(kw)
+    flag = 0
+    for f in kw.pop("flag_add", "").split("|"):
+        if f:
+            flag |= getattr(abi, f)
+    opt = ref.opt(flag=flag, **kw)
+    P_opt, P_bns, P_u8 = C.POINTER(abi.mem_opt_t), C.POINTER(abi.bntseq_t), C.POINTER(C.c_uint8)
+    R.mem_sort_dedup_patch.restype = C.c_int
+    R.mem_sort_dedup_patch.argtypes = [P_opt, P_bns, P_u8, C.c_char_p, C.c_int, C.c_void_p]
+    R.mem_mark_primary_se.restype = C.c_int
+    R.mem_mark_primary_se.argtypes = [P_opt, C.c_int, C.c_void_p, C.c_int64]
+    R.mem_reorder_primary5.restype = None
+    R.mem_reorder_primary5.argtypes = [C.c_int, C.POINTER(_alnreg_v)]
+    R.mem_reg2sam.restype = None
+    R.mem_reg2sam.argtypes = [P_opt, P_bns, P_u8, C.POINTER(abi.bseq1_t), C.POINTER(_alnreg_v), C.c_int, C.c_void_p]
+    libc = api.libc
+    libc.malloc.restype = C.c_void_p
+    libc.malloc.argtypes = [C.c_size_t]
+    l_pac = int(ref.bns.contents.l_pac)
+    n_seqs = int(ref.bns.contents.n_seqs)
+    offs = np.array([int(ref.bns.contents.anns[k].offset) for k in range(n_seqs)] + [l_pac])
+    rng = np.random.default_rng(900 + len(kw) + flag)
+    n_lines = n_tags = 0
+    for k, ends in enumerate(adversarial_pairs(rng, 700, l_pac, offs)):
+        for e in range(2):
+            read = C.create_string_buffer(bytes(rng.integers(0, 4, 150).astype(np.uint8).tolist()), 151)
+            qual = C.create_string_buffer(bytes((33 + (5 * i + k) % 41 for i in range(150))))
+            nm = C.create_string_buffer(b"s%d_%d" % (k, e))
+            a = np.ascontiguousarray(ends[e], dtype=po.ALNREG_DT)
+            p = libc.malloc(max(1, a.nbytes))
+            C.memmove(p, a.ctypes.data, a.nbytes)
+            v = _alnreg_v(len(a), len(a), p)
+            v.n = R.mem_sort_dedup_patch(opt, ref.bns, ref.pac, read, v.n, v.a)
+            want = _regs_copy(v)
+            texts = []
+            for who in ("ref", "own"):
+                s = abi.bseq1_t()
+                s.l_seq = 150; s.name = C.addressof(nm); s.seq = C.addressof(read); s.qual = C.addressof(qual)
+                if who == "ref":
+                    R.mem_mark_primary_se(opt, v.n, v.a, 5000 + 2 * k + e)
+                    if flag & abi.MEM_F_PRIMARY5:
+                        R.mem_reorder_primary5(opt.contents.T, C.byref(v))
+                    R.mem_reg2sam(opt, ref.bns, ref.pac, C.byref(s), C.byref(v), 0, None)
+                else:
+                    lib.mi355x_host_reg2sam_se(opt, ref.bns, C.cast(ref.pac, C.c_void_p), C.byref(s), want.ctypes.data, len(want), 5000 + 2 * k + e)
+                texts.append(C.string_at(s.sam))
+                libc.free(C.c_void_p(s.sam))
+            libc.free(C.c_void_p(v.a))
+            assert texts[0] == texts[1], (kw, k, e, len(want))
+            n_lines += texts[0].count(b"\n")
+            n_tags += texts[0].count(b"\tXA:Z:") + texts[0].count(b"\tSA:Z:")
+    assert n_lines >= 1400 and n_tags > 40, (n_lines, n_tags)   # (-a: the secondary hits are lines, not XA entries)
