@@ -96,9 +96,20 @@ def test_host_sam_pe_matches_the_reference_mem_sam_pe(repeat_genome, case):
     if "a" in kw:
         lib_ref.bwa_fill_scmat(kw["a"], kw["b"], opt.contents.mat)
     reads = simulate.reads_to_ascii(_pairs_of_every_kind(repeat_genome, n=360, seed=40 + case))
+    n_rescued, n_many, n_xa, n_supp, n_lines = _compare_pairs(lib, lib_ref, ref, opt, reads, case)
+    # the cases are the ones the kernel leaves to the host
+    if not flag & (abi.MEM_F_NO_RESCUE | abi.MEM_F_NOPAIRING):
+        assert n_rescued > 20, n_rescued
+    assert n_many > 20 and n_lines >= 2 * len(reads) and n_xa + n_supp > 40, (n_rescued, n_many, n_xa, n_supp, n_lines)
+
+
+def _compare_pairs(lib, lib_ref, ref, opt, reads, tag):
+    """every pair of `reads` through the reference's mem_sam_pe and the library's host path on the regions of the reference's phase 1; -> counts"""
+    from mpibwa_amd import abi, api
     regs, seqs, pes = _batch(ref, lib_ref, opt, reads)
     libc = api.libc
     n_rescued = n_many = n_xa = n_supp = n_lines = 0
+    _compare_pairs.n_pa = 0
     for p, (name, _, _) in enumerate(reads):
         nm = C.create_string_buffer(name.encode())
         qual = [C.create_string_buffer(bytes((33 + (7 * i + p) % 40 for i in range(len(seqs[2 * p + k]) - 1)))) for k in range(2)]
@@ -124,19 +135,44 @@ def test_host_sam_pe_matches_the_reference_mem_sam_pe(repeat_genome, case):
                 t.append(C.string_at(s[k].sam))
                 libc.free(C.c_void_p(s[k].sam))
             texts.append((r, t))
-        assert texts[0] == texts[1], (case, name, [len(c) for c in copies])
+        assert texts[0] == texts[1], (tag, name, [len(c) for c in copies])
         n_rescued += texts[0][0]
         n_many += len(copies[0]) > 8 or len(copies[1]) > 8
         both = texts[0][1][0] + texts[0][1][1]
         n_xa += both.count(b"\tXA:Z:")
         n_supp += sum(int(ln.split(b"\t")[1]) & 0x900 != 0 for ln in both.splitlines())
         n_lines += both.count(b"\n")
+        _compare_pairs.n_pa += both.count(b"\tpa:f:")
     for v in regs:
         libc.free(C.c_void_p(v.a))
-    # the cases are the ones the kernel leaves to the host
-    if not flag & (abi.MEM_F_NO_RESCUE | abi.MEM_F_NOPAIRING):
-        assert n_rescued > 20, n_rescued
-    assert n_many > 20 and n_lines >= 2 * len(reads) and n_xa + n_supp > 40, (n_rescued, n_many, n_xa, n_supp, n_lines)
+    return n_rescued, n_many, n_xa, n_supp, n_lines
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(flag_add="MEM_F_ALL"), dict(max_XA_hits=2, max_XA_hits_alt=20, XA_drop_ratio=0.5)])
+def test_host_sam_pe_with_alt_contigs(genome_alt, kw):
+    """The same on a reference with four ALT contigs (diverged copies of primary regions, named in an .alt file as bwa's GRCh38 kit does): reads
+    from those regions hit the primary assembly and the ALT contig — the two rounds of mem_mark_primary_se, alt_sc, the pa:f tag, XA entries of
+    ALT hits (max_XA_hits_alt), MAPQ caps — text for text."""
+    from mpibwa_amd import abi, api, simulate
+    lib = api.load_library()
+    lib_ref = _ref_handle()
+    lib_ref.mem_sam_pe.restype = C.c_int
+    lib_ref.mem_sam_pe.argtypes = [C.POINTER(abi.mem_opt_t), C.POINTER(abi.bntseq_t), C.POINTER(C.c_uint8), C.POINTER(abi.mem_pestat_t), C.c_uint64,
+                                   C.POINTER(abi.bseq1_t), C.POINTER(_alnreg_v)]
+    ref = po.RefIndex(genome_alt["prefix"])
+    assert sum(ref.bns.contents.anns[i].is_alt for i in range(ref.bns.contents.n_seqs)) == len(genome_alt["alt"]) > 0
+    kw = dict(kw)
+    flag = abi.MEM_F_PE
+    for f in kw.pop("flag_add", "").split("|"):
+        if f:
+            flag |= getattr(abi, f)
+    opt = ref.opt(flag=flag, **kw)
+    # pairs from everywhere, and as many again from the ALT contigs alone (their twins on the primary assembly come along as hits)
+    alt_seqs = [s for n, s in zip(genome_alt["names"], genome_alt["seqs"]) if n in genome_alt["alt"]]
+    reads = simulate.reads_to_ascii(simulate.simulate_reads(genome_alt["seqs"], 250, 150, paired=True, seed=61) +
+                                    [("a" + n, a, b) for n, a, b in simulate.simulate_reads(alt_seqs, 250, 150, paired=True, seed=62, frag_mean=300.0, frag_sd=30.0)])
+    n_rescued, n_many, n_xa, n_supp, n_lines = _compare_pairs(lib, lib_ref, ref, opt, reads, str(kw))
+    assert n_lines >= 2 * len(reads) and _compare_pairs.n_pa > 50, (n_lines, _compare_pairs.n_pa, n_xa)   # (pa:f: = a primary hit that has an ALT twin)
 
 
 class _chain_v(C.Structure):   # mem_chain_v (src/bwamem.c:180)
