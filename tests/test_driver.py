@@ -220,3 +220,45 @@ def test_fixmate_and_by_chromosome_files_are_those_of_the_reference_programs(shi
     run(REF_MAIN, ["-b", "-o", os.path.join(d, "ref_b")])
     theirs = [ln for ln in gzip.decompress(open(os.path.join(d, "ref_b.bam"), "rb").read()).splitlines(keepends=True) if not ln.startswith(b"@")]
     assert 0 < len(theirs) < len(plain) and set(theirs) <= set(plain)
+
+
+OPTION_SETS = [
+    ["-A", "2"],                                                      # -A alone scales what the user left alone (src/mainParallel.c:430-440)
+    ["-A", "2", "-B", "5", "-T", "45", "-O", "5,7", "-E", "2,3", "-L", "3,9", "-U", "11"],
+    ["-k", "23", "-w", "60", "-c", "100", "-d", "70", "-r", "1.2", "-D", "0.6", "-m", "10", "-s", "5", "-G", "3000", "-N", "20", "-W", "25", "-y", "8", "-X", "0.4"],
+    ["-h", "3,9", "-a", "-Y", "-5", "-q"],
+    ["-I", "300,50,600,100", "-M", "-V", "-C", "-v", "2"],
+    ["-P", "-S", "-j", "-Q", "30", "-R", "@RG\\tID:x1\\tSM:s"],
+]
+
+
+@pytest.mark.skipif(not os.path.exists(REF_MAIN), reason="the reference's program is not built (oracle/_ref)")
+@pytest.mark.parametrize("k", range(len(OPTION_SETS)))
+def test_option_letters_mean_what_they_mean_to_the_reference_program(shim_env, genome, tmp_path, k):
+    """Every `mem` option of the reference's getopt string (src/mainParallel.c:291-398) through both programs' own parsers — mpibwa_gpu and the
+    reference's main() compiled in place — with the same library under both: the same records.  Pairs of every kind with comments on the read
+    names (-C), on three contigs."""
+    from mpibwa_amd import api, simulate
+    from test_sampost import _pairs_of_every_kind
+    d = str(tmp_path)
+    prefix = os.path.join(d, "g.fa")
+    for ext in ("", ".amb", ".ann", ".bwt", ".pac", ".sa"):
+        os.symlink(genome["prefix"] + ext, prefix + ext)
+    assert api.load_library().mi355x_write_map(prefix.encode(), (prefix + ".map").encode()) == 0
+    reads = simulate.reads_to_ascii(_pairs_of_every_kind(genome, n=500, seed=50 + k))
+    fq = [os.path.join(d, "r1.fastq"), os.path.join(d, "r2.fastq")]
+    for which in (0, 1):
+        with open(fq[which], "wb") as f:
+            for name, a, b in reads:
+                sq = (a, b)[which]
+                f.write(b"@" + name.encode() + b" BC:Z:ACGT\n" + sq + b"\n+\n" + b"I" * len(sq) + b"\n")
+    env = dict(os.environ)
+    env.pop("LD_LIBRARY_PATH", None)
+    env.update(shim_env)
+    outs = []
+    for exe, out in ((REF_MAIN, os.path.join(d, "ref")), (EXE, os.path.join(d, "own.sam"))):
+        r = subprocess.run([mpiexec(), "-n", "2", exe, "mem", "-t", "4", "-K", "150000"] + OPTION_SETS[k] + ["-o", out, prefix] + fq,
+                           capture_output=True, text=True, timeout=900, env=env, cwd=d)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(_records(out if out.endswith(".sam") else out + ".sam"))
+    assert outs[0] == outs[1] and len(outs[0]) >= 1000, (OPTION_SETS[k], len(outs[0]), len(outs[1]))
