@@ -202,6 +202,13 @@ def test_fixmate_and_by_chromosome_files_are_those_of_the_reference_programs(shi
     for f in names:
         ra = _records(os.path.join(d, "reft", f + ".sam"))
         assert ra == _records(os.path.join(d, "ownt", f + ".sam")) and len(ra) > 50, f
+    # trimmed pairs through mpiBWA itself: n_processed = the reads the rank has done before the chunk (src/mainParallel.c:2355-2357) seeds the hash
+    # tie-breaks; one rank each (with more ranks it depends on which rank gets which chunk), three chunks in flight on our side
+    for exe, out, more in ((REF_MAIN, os.path.join(d, "ref_trim"), []), (EXE, os.path.join(d, "own_trim.sam"), ["--in-flight", "3"])):
+        r = subprocess.run([mpiexec(), "-n", "1", exe, "mem", "-t", "4", "-K", "100000"] + more + ["-o", out, prefix] + tq, capture_output=True, text=True, timeout=900, env=env, cwd=d)
+        assert r.returncode == 0, r.stderr[-3000:]
+    trimmed_records = _records(os.path.join(d, "ref_trim.sam"))
+    assert _records(os.path.join(d, "own_trim.sam")) == trimmed_records and len(trimmed_records) > 3000
     # single end: the reference's mpiBWAByChr is no yardstick there (its single-end writer loses 17 to a few hundred of 4 997 records from run
     # to run and sometimes ends on a signal); ours are the records of the reference's mpiBWA on the same file, each in the file of its RNAME
     r = subprocess.run([mpiexec(), "-n", "2", REF_MAIN, "mem", "-t", "4", "-K", "200000", "-o", os.path.join(d, "ref_se"), prefix, fq[0]],
