@@ -264,7 +264,7 @@ def test_option_letters_mean_what_they_mean_to_the_reference_program(shim_env, g
     env.update(shim_env)
     outs = []
     for exe, out in ((REF_MAIN, os.path.join(d, "ref")), (EXE, os.path.join(d, "own.sam"))):
-        r = subprocess.run([mpiexec(), "-n", "2", exe, "mem", "-t", "4", "-K", "150000"] + OPTION_SETS[k] + ["-o", out, prefix] + fq,
+        r = subprocess.run([mpiexec(), "-n", "1", exe, "mem", "-t", "4", "-K", "150000"] + OPTION_SETS[k] + ["-o", out, prefix] + fq,
                            capture_output=True, text=True, timeout=900, env=env, cwd=d)
         assert r.returncode == 0, r.stderr[-3000:]
         outs.append(_records(out if out.endswith(".sam") else out + ".sam"))
